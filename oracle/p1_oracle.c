@@ -1,0 +1,541 @@
+/*
+ * p1_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A plain-C, single-threaded CPU restatement of the HyTeG algorithms on the P1 matrix-free
+ * hot path.  It is the checker the HIP kernels are compared against.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the
+ * product (hyteg_amd/, include/) never links, imports or calls anything in oracle/.
+ *
+ * Every function cites the reference file:line (relative to /root/reference/) it restates.
+ * Nothing here is copied from the reference: the generated kernels there spell out the index
+ * polynomial per access; here the same arithmetic is expressed through cell_index().
+ *
+ * Pinning: the reference ships no golden vectors for this path.  The oracle is pinned by the
+ * reference's own known-answer tests and properties (tests/test_oracle_pins.py): index tables
+ * (tests/hyteg/Indexing/VertexDoFMacroCellIndexingTest.cpp:61-108), array sizes
+ * (tests/hyteg/Indexing/CommonIndexingTest.cpp:166-170), Laplace annihilates constants/linears
+ * (tests/hyteg/P1/P1LaplaceOperator3DTest.cpp), stencil row-sum/halving
+ * (tests/hyteg/vertexdofspace/VertexDoFStencilAssemblyTest.cpp), prolongation exact on linears
+ * (tests/hyteg/vertexdofspace/VertexDoFLinearProlongation3DTest.cpp), and the FEniCS element
+ * matrix compiled in place from the reference (oracle/_ref, see oracle/Makefile).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared  (contraction off: the summation order below
+ * is the reference's, so results are reproducible across compilers).
+ *
+ * Stencil weight order w[15] (the C-ABI order, include/hyteg_hip.h): iteration order of the
+ * reference's std::map<indexing::Index,real_t>, i.e. sorted by (z, y, x)
+ * (src/hyteg/indexing/Common.hpp:67-71):
+ *   0:( 0, 0,-1) 1:( 1, 0,-1) 2:(-1, 1,-1) 3:( 0, 1,-1)
+ *   4:( 0,-1, 0) 5:( 1,-1, 0) 6:(-1, 0, 0) 7:( 0, 0, 0) 8:( 1, 0, 0) 9:(-1, 1, 0) 10:( 0, 1, 0)
+ *  11:( 0,-1, 1) 12:( 1,-1, 1) 13:(-1, 0, 1) 14:( 0, 0, 1)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define HO_API __attribute__( ( visibility( "default" ) ) )
+
+/* ---- stencil slots (see header comment) ---- */
+enum
+{
+   W_BC  = 0,  /* ( 0, 0,-1) */
+   W_BE  = 1,  /* ( 1, 0,-1) */
+   W_BNW = 2,  /* (-1, 1,-1) */
+   W_BN  = 3,  /* ( 0, 1,-1) */
+   W_S   = 4,  /* ( 0,-1, 0) */
+   W_SE  = 5,  /* ( 1,-1, 0) */
+   W_W   = 6,  /* (-1, 0, 0) */
+   W_C   = 7,  /* ( 0, 0, 0) */
+   W_E   = 8,  /* ( 1, 0, 0) */
+   W_NW  = 9,  /* (-1, 1, 0) */
+   W_N   = 10, /* ( 0, 1, 0) */
+   W_TS  = 11, /* ( 0,-1, 1) */
+   W_TSE = 12, /* ( 1,-1, 1) */
+   W_TW  = 13, /* (-1, 0, 1) */
+   W_TC  = 14  /* ( 0, 0, 1) */
+};
+
+static const int OFFS[15][3] = { { 0, 0, -1 }, { 1, 0, -1 }, { -1, 1, -1 }, { 0, 1, -1 }, { 0, -1, 0 },
+                                 { 1, -1, 0 }, { -1, 0, 0 }, { 0, 0, 0 },   { 1, 0, 0 },  { -1, 1, 0 },
+                                 { 0, 1, 0 },  { 0, -1, 1 }, { 1, -1, 1 },  { -1, 0, 1 }, { 0, 0, 1 } };
+
+/* ---------------------------------------------------------------------------------------------
+ * Layout.  src/hyteg/indexing/MacroCellIndexing.hpp:40-52 (linearMacroCellSize / -Index),
+ * src/hyteg/Levelinfo.hpp:36-115 (num_microvertices_per_edge = 2^level + 1).
+ * ------------------------------------------------------------------------------------------- */
+static inline int64_t tet_size( int64_t width ) { return ( ( width + 2 ) * ( width + 1 ) * width ) / 6; }
+
+static inline int64_t cell_index_w( int64_t width, int64_t x, int64_t y, int64_t z )
+{
+   const int64_t wms         = width - z;
+   const int64_t sliceOffset = tet_size( width ) - tet_size( wms );
+   const int64_t rowOffset   = y * ( wms + 1 ) - ( ( y + 1 ) * y ) / 2;
+   return sliceOffset + rowOffset + x;
+}
+
+HO_API int64_t ho_width( int level ) { return ( (int64_t) 1 << level ) + 1; }
+HO_API int64_t ho_cell_size( int level ) { return tet_size( ho_width( level ) ); }
+HO_API int64_t ho_cell_index( int level, int x, int y, int z ) { return cell_index_w( ho_width( level ), x, y, z ); }
+/* number of points the interior loops visit: C(2^L-1,3); CellIterator(level,1),
+ * src/hyteg/indexing/MacroCellIndexing.cpp:92-104 */
+HO_API int64_t ho_cell_inner_size( int level )
+{
+   const int64_t n = ( (int64_t) 1 << level ) - 1;
+   return n < 3 ? 0 : n * ( n - 1 ) * ( n - 2 ) / 6;
+}
+/* macro-face (triangle) layout: src/hyteg/indexing/MacroFaceIndexing.hpp:40-50 */
+HO_API int64_t ho_face_size_w( int64_t width ) { return ( ( width + 1 ) * width ) / 2; }
+HO_API int64_t ho_face_index_w( int64_t width, int64_t x, int64_t y )
+{
+   return y * ( width + 1 ) - ( ( y + 1 ) * y ) / 2 + x;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * a2: 15-point constant-stencil apply on the cell interior.
+ * src/constant_stencil_operator/P1generatedKernels/apply_3D_macrocell_vertexdof_to_vertexdof_replace.cpp:34-78
+ * (sum order xi_18+...+xi_32 at :73) and ..._add.cpp (same products, old dst value added LAST).
+ * update: 0 = Replace, 1 = Add  (src/hyteg/types/types.hpp:29-33).
+ * ------------------------------------------------------------------------------------------- */
+HO_API void ho_apply_cell( double* dst, const double* src, int level, const double* w, int update )
+{
+   const int64_t N = ho_width( level );
+   const int     n = 1 << level;
+   for ( int z = 1; z < n; ++z )
+      for ( int y = 1; y < n - z; ++y )
+         for ( int x = 1; x < n - y - z; ++x )
+         {
+#define S( dx, dy, dz ) src[cell_index_w( N, x + ( dx ), y + ( dy ), z + ( dz ) )]
+            /* the reference's summation order (replace.cpp:73): */
+            double acc = w[W_W] * S( -1, 0, 0 );
+            acc        = acc + w[W_BN] * S( 0, 1, -1 );
+            acc        = acc + w[W_N] * S( 0, 1, 0 );
+            acc        = acc + w[W_SE] * S( 1, -1, 0 );
+            acc        = acc + w[W_TSE] * S( 1, -1, 1 );
+            acc        = acc + w[W_BE] * S( 1, 0, -1 );
+            acc        = acc + w[W_E] * S( 1, 0, 0 );
+            acc        = acc + w[W_TW] * S( -1, 0, 1 );
+            acc        = acc + w[W_BNW] * S( -1, 1, -1 );
+            acc        = acc + w[W_NW] * S( -1, 1, 0 );
+            acc        = acc + w[W_S] * S( 0, -1, 0 );
+            acc        = acc + w[W_TS] * S( 0, -1, 1 );
+            acc        = acc + w[W_BC] * S( 0, 0, -1 );
+            acc        = acc + w[W_C] * S( 0, 0, 0 );
+            acc        = acc + w[W_TC] * S( 0, 0, 1 );
+#undef S
+            const int64_t i = cell_index_w( N, x, y, z );
+            dst[i]          = update ? acc + dst[i] : acc;
+         }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * a3: in-place lexicographic SOR / Gauss-Seidel sweeps on the cell interior.
+ * src/constant_stencil_operator/P1generatedKernels/sor_3D_macrocell_P1.cpp:32-90 (update at :74):
+ *     u_i = relax * (1/w_c) * ( -sum_14 w_k u_k + rhs_i ) + ( 1 + (-relax) ) * u_i
+ * with sum order xi_21..xi_35 (rhs last); sor_3D_macrocell_P1_backwards.cpp:52-57 (reversed loops);
+ * gaussseidel_3D_macrocell_P1.cpp:32-88 (u_i = (1/w_c) * ( -sum + rhs_i ), same term order, :72).
+ * ------------------------------------------------------------------------------------------- */
+static inline double residual_sum( const double* u, const double* rhs, const double* w, int64_t N, int x, int y, int z )
+{
+#define U( dx, dy, dz ) u[cell_index_w( N, x + ( dx ), y + ( dy ), z + ( dz ) )]
+   /* 14 terms -(w_k) * u_k in the reference's order, then rhs LAST (sor: xi_21..xi_35; gs: xi_19..xi_33) */
+   double acc = -w[W_BN] * U( 0, 1, -1 );
+   acc        = acc + -w[W_N] * U( 0, 1, 0 );
+   acc        = acc + -w[W_SE] * U( 1, -1, 0 );
+   acc        = acc + -w[W_TSE] * U( 1, -1, 1 );
+   acc        = acc + -w[W_BE] * U( 1, 0, -1 );
+   acc        = acc + -w[W_E] * U( 1, 0, 0 );
+   acc        = acc + -w[W_W] * U( -1, 0, 0 );
+   acc        = acc + -w[W_TW] * U( -1, 0, 1 );
+   acc        = acc + -w[W_BNW] * U( -1, 1, -1 );
+   acc        = acc + -w[W_NW] * U( -1, 1, 0 );
+   acc        = acc + -w[W_S] * U( 0, -1, 0 );
+   acc        = acc + -w[W_TS] * U( 0, -1, 1 );
+   acc        = acc + -w[W_BC] * U( 0, 0, -1 );
+   acc        = acc + -w[W_TC] * U( 0, 0, 1 );
+   acc        = acc + rhs[cell_index_w( N, x, y, z )];
+#undef U
+   return acc;
+}
+
+static inline double sor_point( double* u, const double* rhs, const double* w, int64_t N, int x, int y, int z, double invC,
+                                double relax, double oneMinusRelax )
+{
+   return relax * invC * residual_sum( u, rhs, w, N, x, y, z ) + oneMinusRelax * u[cell_index_w( N, x, y, z )];
+}
+
+HO_API void ho_sor_cell( double* u, const double* rhs, int level, const double* w, double relax, int backwards )
+{
+   const int64_t N    = ho_width( level );
+   const int     n    = 1 << level;
+   const double  invC = 1 / w[W_C];
+   const double  omr  = 1.0 + ( -relax );
+   if ( !backwards )
+   {
+      for ( int z = 1; z < n; ++z )
+         for ( int y = 1; y < n - z; ++y )
+            for ( int x = 1; x < n - y - z; ++x )
+               u[cell_index_w( N, x, y, z )] = sor_point( u, rhs, w, N, x, y, z, invC, relax, omr );
+   }
+   else
+   {
+      for ( int z = n - 1; z >= 1; --z )
+         for ( int y = n - z - 1; y >= 1; --y )
+            for ( int x = n - y - z - 1; x >= 1; --x )
+               u[cell_index_w( N, x, y, z )] = sor_point( u, rhs, w, N, x, y, z, invC, relax, omr );
+   }
+}
+
+HO_API void ho_gs_cell( double* u, const double* rhs, int level, const double* w )
+{
+   /* gaussseidel_3D_macrocell_P1.cpp:72: u_i = xi_17 * ( xi_19 + ... + xi_33 ), xi_17 = 1/w_c, xi_33 = rhs */
+   const int64_t N    = ho_width( level );
+   const int     n    = 1 << level;
+   const double  invC = 1 / w[W_C];
+   for ( int z = 1; z < n; ++z )
+      for ( int y = 1; y < n - z; ++y )
+         for ( int x = 1; x < n - y - z; ++x )
+            u[cell_index_w( N, x, y, z )] = invC * residual_sum( u, rhs, w, N, x, y, z );
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * a6: vector kernels on the cell interior.
+ * assign: src/hyteg/p1functionspace/generatedKernels/assign_3D_macrocell_vertexdof_{1,2,3}_rhsfunction(s).cpp
+ *         (dispatch src/hyteg/p1functionspace/VertexDoFFunction.cpp:1088-1128); generic n-ary form
+ *         src/hyteg/p1functionspace/VertexDoFMacroCell.hpp:376-402.
+ * add:    VertexDoFMacroCell.hpp:456-481 (dst += sum_k c_k src_k), scalar add :441-453.
+ * multElementwise: VertexDoFMacroCell.hpp:483-508.   dot: :511-529 (plain sequential +=).
+ * ------------------------------------------------------------------------------------------- */
+#define FOR_INNER( level )                    \
+   const int64_t N = ho_width( level );       \
+   const int     n = 1 << ( level );          \
+   for ( int z = 1; z < n; ++z )              \
+      for ( int y = 1; y < n - z; ++y )       \
+         for ( int x = 1; x < n - y - z; ++x )
+
+HO_API void ho_assign( double* dst, int nsrc, const double* const* srcs, const double* scalars, int level )
+{
+   FOR_INNER( level )
+   {
+      const int64_t i   = cell_index_w( N, x, y, z );
+      double        tmp = scalars[0] * srcs[0][i];
+      for ( int k = 1; k < nsrc; ++k )
+         tmp = tmp + scalars[k] * srcs[k][i];
+      dst[i] = tmp;
+   }
+}
+
+HO_API void ho_add( double* dst, int nsrc, const double* const* srcs, const double* scalars, int level )
+{
+   FOR_INNER( level )
+   {
+      const int64_t i   = cell_index_w( N, x, y, z );
+      double        tmp = scalars[0] * srcs[0][i];
+      for ( int k = 1; k < nsrc; ++k )
+         tmp = tmp + scalars[k] * srcs[k][i];
+      dst[i] = dst[i] + tmp;
+   }
+}
+
+HO_API void ho_add_scalar( double* dst, double scalar, int level )
+{
+   FOR_INNER( level ) { dst[cell_index_w( N, x, y, z )] += scalar; }
+}
+
+HO_API void ho_mult_elementwise( double* dst, int nsrc, const double* const* srcs, int level )
+{
+   FOR_INNER( level )
+   {
+      const int64_t i   = cell_index_w( N, x, y, z );
+      double        tmp = srcs[0][i];
+      for ( int k = 1; k < nsrc; ++k )
+         tmp = tmp * srcs[k][i];
+      dst[i] = tmp;
+   }
+}
+
+HO_API double ho_dot( const double* a, const double* b, int level )
+{
+   double sp = 0;
+   FOR_INNER( level )
+   {
+      const int64_t i = cell_index_w( N, x, y, z );
+      sp              = sp + a[i] * b[i];
+   }
+   return sp;
+}
+
+/* interpolate a constant onto the cell interior: VertexDoFMacroCell.hpp:79-93 */
+HO_API void ho_set_inner( double* dst, double value, int level )
+{
+   FOR_INNER( level ) { dst[cell_index_w( N, x, y, z )] = value; }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * a4: weighted Jacobi exactly as composed by P1Operator::smooth_jac,
+ * src/hyteg/p1functionspace/P1Operator.hpp:429-447:
+ *     apply(src,dst) ; dst = 1*rhs + (-1)*dst ; dst = invDiag .* dst ; dst = 1*src + relax*dst
+ * On a constant-stencil macro-cell invDiag is the constant 1/w_c in the interior
+ * (P1Operator.hpp:636-906 copies the centre weight, then invertElementwise).  invdiag may be
+ * NULL (use 1/w[7]) or a full cell array.
+ * ------------------------------------------------------------------------------------------- */
+HO_API void ho_jacobi_cell( double* dst, const double* rhs, const double* src, const double* invdiag, int level,
+                            const double* w, double relax )
+{
+   ho_apply_cell( dst, src, level, w, 0 );
+   const double invC = 1.0 / w[W_C];
+   FOR_INNER( level )
+   {
+      const int64_t i = cell_index_w( N, x, y, z );
+      double        t = 1.0 * rhs[i] + ( -1.0 ) * dst[i];
+      t               = ( invdiag ? invdiag[i] : invC ) * t;
+      dst[i]          = 1.0 * src[i] + relax * t;
+   }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Classification of a point of the cell array by the macro-primitive it lies on.
+ * src/hyteg/indexing/MacroCellIndexing.cpp:36-91 (isOnCellFace / isOnCellEdge / isOnCellVertex):
+ * faces: 0: z==0, 1: y==0, 2: x==0, 3: x+y+z==width-1;  edges by face pairs
+ * (0,1)->0 (0,2)->1 (0,3)->2 (1,2)->3 (1,3)->4 (2,3)->5; vertices 0:(0,0,0) 1:(w-1,0,0) 2:(0,w-1,0) 3:(0,0,w-1).
+ * Returns the slot in nnc[14] = { edge0..5, face0..3, vertex0..3 } (the argument order of the
+ * reference's grid-transfer kernels) or -1 for an interior point.
+ * ------------------------------------------------------------------------------------------- */
+static int prim_slot( int64_t width, int64_t x, int64_t y, int64_t z )
+{
+   const int f0 = ( z == 0 ), f1 = ( y == 0 ), f2 = ( x == 0 ), f3 = ( x + y + z == width - 1 );
+   const int cnt = f0 + f1 + f2 + f3;
+   if ( cnt == 0 )
+      return -1;
+   if ( cnt == 1 )
+      return 6 + ( f0 ? 0 : f1 ? 1 : f2 ? 2 : 3 );
+   if ( cnt == 2 )
+   {
+      if ( f0 && f1 ) return 0;
+      if ( f0 && f2 ) return 1;
+      if ( f0 && f3 ) return 2;
+      if ( f1 && f2 ) return 3;
+      if ( f1 && f3 ) return 4;
+      return 5;
+   }
+   /* vertex */
+   if ( f0 && f1 && f2 ) return 10;
+   if ( f0 && f1 && f3 ) return 11;
+   if ( f0 && f2 && f3 ) return 12;
+   return 13;
+}
+
+HO_API int ho_prim_slot( int level, int x, int y, int z ) { return prim_slot( ho_width( level ), x, y, z ); }
+
+/* ---------------------------------------------------------------------------------------------
+ * a7: restriction, pull form.
+ * src/hyteg/gridtransferoperators/generatedKernels/restrict_3D_macrocell_P1_pull_additive.cpp:33-1690
+ * (15 regions; caller src/hyteg/gridtransferoperators/P1toP1LinearRestriction.cpp:169-243).
+ * For EVERY coarse point i (boundary included):
+ *    coarse[i] = sum over d in {centre, 14 neighbours}, fine point f = 2i+d inside the cell, of
+ *                wt(d) * (1/nnc(primitive f lies on)) * fine[f],     wt(centre)=1, wt(else)=1/2,
+ * where nnc = number of macro-cells adjacent to that macro-primitive (1 for interior points).
+ * The per-cell partial sums are later added up across cells (additive communication,
+ * P1toP1LinearRestriction.cpp:343-345), which is why shared fine values are pre-divided.
+ * nnc[14] = { edge0..5, face0..3, vertex0..3 }.
+ * Term order: centre last (as in every region of the reference); neighbours in the fixed order
+ * of the table below.  The reference's per-region term order differs by reassociation only.
+ * ------------------------------------------------------------------------------------------- */
+static const int NB14[14][3] = { { -1, 0, 0 }, { -1, 0, 1 }, { -1, 1, -1 }, { -1, 1, 0 }, { 0, -1, 0 },
+                                 { 0, -1, 1 }, { 0, 0, -1 }, { 0, 0, 1 },   { 0, 1, -1 }, { 0, 1, 0 },
+                                 { 1, -1, 0 }, { 1, -1, 1 }, { 1, 0, -1 },  { 1, 0, 0 } };
+
+static inline int inside( int64_t width, int64_t x, int64_t y, int64_t z )
+{
+   return x >= 0 && y >= 0 && z >= 0 && x + y + z <= width - 1;
+}
+
+HO_API void ho_restrict_cell( double* coarse, const double* fine, int coarse_level, const double* nnc )
+{
+   const int64_t Nc = ho_width( coarse_level ), Nf = ho_width( coarse_level + 1 );
+   double        inv[14];
+   for ( int k = 0; k < 14; ++k )
+      inv[k] = 1 / nnc[k];
+   for ( int64_t z = 0; z < Nc; ++z )
+      for ( int64_t y = 0; y < Nc - z; ++y )
+         for ( int64_t x = 0; x < Nc - z - y; ++x )
+         {
+            double acc   = 0;
+            int    first = 1;
+            for ( int k = 0; k < 14; ++k )
+            {
+               const int64_t fx = 2 * x + NB14[k][0], fy = 2 * y + NB14[k][1], fz = 2 * z + NB14[k][2];
+               if ( !inside( Nf, fx, fy, fz ) )
+                  continue;
+               const int    slot = prim_slot( Nf, fx, fy, fz );
+               const double s    = slot < 0 ? 1.0 : inv[slot];
+               const double t    = s * 0.5 * fine[cell_index_w( Nf, fx, fy, fz )];
+               acc               = first ? t : acc + t;
+               first             = 0;
+            }
+            const int    slot = prim_slot( Nf, 2 * x, 2 * y, 2 * z );
+            const double s    = slot < 0 ? 1.0 : inv[slot];
+            const double t    = 1.0 * s * fine[cell_index_w( Nf, 2 * x, 2 * y, 2 * z )];
+            acc               = first ? t : acc + t;
+            coarse[cell_index_w( Nc, x, y, z )] = acc;
+         }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * a8: prolongation, push (scatter-add) form.
+ * src/hyteg/gridtransferoperators/generatedKernels/prolongate_3D_macrocell_P1_push_additive.cpp
+ * (caller + readable generic branch: src/hyteg/gridtransferoperators/P1toP1LinearProlongation.cpp:194-410).
+ * ho_prolongate_prepare restates :214-238 (Replace: zero the whole fine array; Add: zero only the
+ * points on the cell boundary).  ho_prolongate_cell then visits every coarse point i in
+ * lexicographic (z,y,x) order and does
+ *    fine[2i]   += (1/nnc(prim(2i)))       * coarse[i]
+ *    fine[2i+d] += 1/2 * (1/nnc(prim(2i+d))) * coarse[i]      for the 14 d with 2i+d inside the cell.
+ * ------------------------------------------------------------------------------------------- */
+HO_API void ho_prolongate_prepare( double* fine, int fine_level, int update )
+{
+   const int64_t Nf = ho_width( fine_level );
+   for ( int64_t z = 0; z < Nf; ++z )
+      for ( int64_t y = 0; y < Nf - z; ++y )
+         for ( int64_t x = 0; x < Nf - z - y; ++x )
+            if ( update == 0 || prim_slot( Nf, x, y, z ) >= 0 )
+               fine[cell_index_w( Nf, x, y, z )] = 0.0;
+}
+
+HO_API void ho_prolongate_cell( const double* coarse, double* fine, int coarse_level, const double* nnc )
+{
+   const int64_t Nc = ho_width( coarse_level ), Nf = ho_width( coarse_level + 1 );
+   double        inv[14];
+   for ( int k = 0; k < 14; ++k )
+      inv[k] = 1 / nnc[k];
+   for ( int64_t z = 0; z < Nc; ++z )
+      for ( int64_t y = 0; y < Nc - z; ++y )
+         for ( int64_t x = 0; x < Nc - z - y; ++x )
+         {
+            const double c = coarse[cell_index_w( Nc, x, y, z )];
+            {
+               const int    slot = prim_slot( Nf, 2 * x, 2 * y, 2 * z );
+               const double s    = slot < 0 ? 1.0 : inv[slot];
+               fine[cell_index_w( Nf, 2 * x, 2 * y, 2 * z )] += 1.0 * s * c;
+            }
+            for ( int k = 0; k < 14; ++k )
+            {
+               const int64_t fx = 2 * x + NB14[k][0], fy = 2 * y + NB14[k][1], fz = 2 * z + NB14[k][2];
+               if ( !inside( Nf, fx, fy, fz ) )
+                  continue;
+               const int    slot = prim_slot( Nf, fx, fy, fz );
+               const double s    = slot < 0 ? 1.0 : inv[slot];
+               fine[cell_index_w( Nf, fx, fy, fz )] += s * 0.5 * c;
+            }
+         }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * a11: stencil assembly (kernel INPUT).
+ * Element matrix: P1 stiffness matrix of one tetrahedron, the quantity
+ * src/hyteg/forms/form_fenics_generated/p1_tet_diffusion.h:4113-4240 (tabulate_tensor) computes:
+ *    K_ij = |det J| / 6 * ( grad lambda_i . grad lambda_j ).
+ * Here by the closed form via the inverse Jacobian (the generated code evaluates the same
+ * expression through 80 temporaries and the literal 0.1666666666666667; agreement is to rounding,
+ * checked against the header compiled in place, oracle/_ref).  coords = 4 vertices x 3, row-major.
+ * ------------------------------------------------------------------------------------------- */
+HO_API void ho_p1_tet_diffusion( double* A /*16, row-major*/, const double* c /*12*/ )
+{
+   double J[3][3]; /* J[r][k] = d x_r / d xi_k = c[k+1][r] - c[0][r] */
+   for ( int r = 0; r < 3; ++r )
+      for ( int k = 0; k < 3; ++k )
+         J[r][k] = c[3 * ( k + 1 ) + r] - c[r];
+   const double det = J[0][0] * ( J[1][1] * J[2][2] - J[1][2] * J[2][1] ) - J[0][1] * ( J[1][0] * J[2][2] - J[1][2] * J[2][0] ) +
+                      J[0][2] * ( J[1][0] * J[2][1] - J[1][1] * J[2][0] );
+   double Ji[3][3]; /* inverse: Ji[k][r] = d xi_k / d x_r */
+   Ji[0][0] = ( J[1][1] * J[2][2] - J[1][2] * J[2][1] ) / det;
+   Ji[0][1] = ( J[0][2] * J[2][1] - J[0][1] * J[2][2] ) / det;
+   Ji[0][2] = ( J[0][1] * J[1][2] - J[0][2] * J[1][1] ) / det;
+   Ji[1][0] = ( J[1][2] * J[2][0] - J[1][0] * J[2][2] ) / det;
+   Ji[1][1] = ( J[0][0] * J[2][2] - J[0][2] * J[2][0] ) / det;
+   Ji[1][2] = ( J[0][2] * J[1][0] - J[0][0] * J[1][2] ) / det;
+   Ji[2][0] = ( J[1][0] * J[2][1] - J[1][1] * J[2][0] ) / det;
+   Ji[2][1] = ( J[0][1] * J[2][0] - J[0][0] * J[2][1] ) / det;
+   Ji[2][2] = ( J[0][0] * J[1][1] - J[0][1] * J[1][0] ) / det;
+   double g[4][3]; /* physical gradients of the barycentric functions */
+   for ( int r = 0; r < 3; ++r )
+   {
+      g[1][r] = Ji[0][r];
+      g[2][r] = Ji[1][r];
+      g[3][r] = Ji[2][r];
+      g[0][r] = -( Ji[0][r] + Ji[1][r] + Ji[2][r] );
+   }
+   const double vol6 = fabs( det ) / 6.0;
+   for ( int i = 0; i < 4; ++i )
+      for ( int j = 0; j < 4; ++j )
+         A[4 * i + j] = vol6 * ( g[i][0] * g[j][0] + g[i][1] * g[j][1] + g[i][2] * g[j][2] );
+}
+
+/* P1 mass matrix of one tetrahedron (src/hyteg/forms/form_fenics_generated/p1_tet_mass.h):
+ * M_ij = |det J| / 120 * (1 + delta_ij). */
+HO_API void ho_p1_tet_mass( double* A, const double* c )
+{
+   double J[3][3];
+   for ( int r = 0; r < 3; ++r )
+      for ( int k = 0; k < 3; ++k )
+         J[r][k] = c[3 * ( k + 1 ) + r] - c[r];
+   const double det = J[0][0] * ( J[1][1] * J[2][2] - J[1][2] * J[2][1] ) - J[0][1] * ( J[1][0] * J[2][2] - J[1][2] * J[2][0] ) +
+                      J[0][2] * ( J[1][0] * J[2][1] - J[1][1] * J[2][0] );
+   for ( int i = 0; i < 4; ++i )
+      for ( int j = 0; j < 4; ++j )
+         A[4 * i + j] = fabs( det ) / 120.0 * ( i == j ? 2.0 : 1.0 );
+}
+
+/* The 24 micro-tetrahedra around an interior micro-vertex, each as 4 stencil slots with the
+ * centre first.  src/hyteg/p1functionspace/P1Elements.hpp:93-143 (white/blue/green up/down). */
+static const int MICRO_TETS[24][4] = {
+    /* whiteUp   */ { W_C, W_BC, W_BE, W_BN }, { W_C, W_S, W_SE, W_TS }, { W_C, W_W, W_NW, W_TW }, { W_C, W_N, W_E, W_TC },
+    /* whiteDown */ { W_C, W_W, W_BC, W_S },   { W_C, W_E, W_SE, W_BE }, { W_C, W_N, W_NW, W_BN }, { W_C, W_TS, W_TC, W_TW },
+    /* blueUp    */ { W_C, W_BC, W_BN, W_BNW }, { W_C, W_W, W_S, W_TS }, { W_C, W_E, W_SE, W_TSE }, { W_C, W_NW, W_N, W_TC },
+    /* blueDown  */ { W_C, W_BC, W_S, W_SE },  { W_C, W_W, W_NW, W_BNW }, { W_C, W_E, W_BN, W_N }, { W_C, W_TC, W_TS, W_TSE },
+    /* greenUp   */ { W_C, W_W, W_BC, W_BNW }, { W_C, W_E, W_BE, W_BN }, { W_C, W_TC, W_TW, W_NW }, { W_C, W_SE, W_TS, W_TSE },
+    /* greenDown */ { W_C, W_BC, W_BE, W_SE }, { W_C, W_BN, W_BNW, W_NW }, { W_C, W_E, W_TSE, W_TC }, { W_C, W_W, W_TS, W_TW } };
+
+/* Cell stencil at an interior micro-vertex (the reference assembles it at index (1,1,1),
+ * src/constant_stencil_operator/P1ConstantOperator.cpp:680-693 -> P1Operator.hpp:2123-2136 ->
+ * P1Elements.hpp:466-528; geometry src/hyteg/p1functionspace/VertexDoFMacroCell.hpp:70-77).
+ * form: 0 = Laplace (diffusion), 1 = mass.  cellcoords = 4 macro-vertices x 3. */
+HO_API void ho_assemble_cell_stencil( double* w, const double* cc, int level, int form )
+{
+   const double step = 1.0 / (double) ( (int64_t) 1 << level );
+   double       xs[3], ys[3], zs[3];
+   for ( int r = 0; r < 3; ++r )
+   {
+      xs[r] = ( cc[3 + r] - cc[r] ) * step;
+      ys[r] = ( cc[6 + r] - cc[r] ) * step;
+      zs[r] = ( cc[9 + r] - cc[r] ) * step;
+   }
+   for ( int k = 0; k < 15; ++k )
+      w[k] = 0.0;
+   for ( int t = 0; t < 24; ++t )
+   {
+      double coords[12], A[16];
+      for ( int v = 0; v < 4; ++v )
+      {
+         const int* o = OFFS[MICRO_TETS[t][v]];
+         for ( int r = 0; r < 3; ++r )
+            coords[3 * v + r] = cc[r] + xs[r] * (double) ( 1 + o[0] ) + ys[r] * (double) ( 1 + o[1] ) + zs[r] * (double) ( 1 + o[2] );
+      }
+      if ( form == 0 )
+         ho_p1_tet_diffusion( A, coords );
+      else
+         ho_p1_tet_mass( A, coords );
+      for ( int v = 0; v < 4; ++v )
+         w[MICRO_TETS[t][v]] += A[v]; /* first row of the element matrix */
+   }
+}
+
+/* physical coordinate of a micro-vertex: VertexDoFMacroCell.hpp:70-77 */
+HO_API void ho_coordinate_from_index( double* out, const double* cc, int level, int x, int y, int z )
+{
+   const double step = 1.0 / (double) ( (int64_t) 1 << level );
+   for ( int r = 0; r < 3; ++r )
+   {
+      const double xs = ( cc[3 + r] - cc[r] ) * step, ys = ( cc[6 + r] - cc[r] ) * step, zs = ( cc[9 + r] - cc[r] ) * step;
+      out[r] = cc[r] + xs * (double) x + ys * (double) y + zs * (double) z;
+   }
+}

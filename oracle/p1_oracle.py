@@ -1,0 +1,282 @@
+"""numpy/ctypes front end of the CPU oracle (oracle/p1_oracle.c).
+
+TEST INFRASTRUCTURE, NOT PRODUCT CODE: only tests/, __graft_entry__.smoke() and the
+``cpu_baseline`` leg of bench.py may import this module.  The product package ``hyteg_amd``
+never does (tests/test_product_isolation.py enforces it).
+
+Each wrapper mirrors one ``ho_*`` function; the reference file:line each restates is cited in
+p1_oracle.c.  Arrays are float64, C-contiguous, in HyTeG's linear tetrahedral cell layout.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_P = C.POINTER(C.c_double)
+
+# stencil slot -> logical offset, the C-ABI order (std::map<Index> iteration order: z, y, x)
+STENCIL_OFFSETS = (
+    (0, 0, -1), (1, 0, -1), (-1, 1, -1), (0, 1, -1),
+    (0, -1, 0), (1, -1, 0), (-1, 0, 0), (0, 0, 0), (1, 0, 0), (-1, 1, 0), (0, 1, 0),
+    (0, -1, 1), (1, -1, 1), (-1, 0, 1), (0, 0, 1),
+)
+# HyTeG stencilDirection names of the 15 slots (src/hyteg/StencilDirections.hpp)
+STENCIL_NAMES = ("BC", "BE", "BNW", "BN", "S", "SE", "W", "C", "E", "NW", "N", "TS", "TSE", "TW", "TC")
+REPLACE, ADD = 0, 1
+
+
+def _build(target: str) -> Path:
+    so = _HERE / "_build" / target
+    src = _HERE / "p1_oracle.c"
+    if not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
+        subprocess.run(["make", "-C", str(_HERE), f"_build/{target}"], check=True, capture_output=True)
+    return so
+
+
+def _bind(lib):
+    i, d, ll = C.c_int, C.c_double, C.c_int64
+    sig = {
+        "ho_width": (ll, [i]),
+        "ho_cell_size": (ll, [i]),
+        "ho_cell_index": (ll, [i, i, i, i]),
+        "ho_cell_inner_size": (ll, [i]),
+        "ho_face_size_w": (ll, [ll]),
+        "ho_face_index_w": (ll, [ll, ll, ll]),
+        "ho_apply_cell": (None, [_P, _P, i, _P, i]),
+        "ho_sor_cell": (None, [_P, _P, i, _P, d, i]),
+        "ho_gs_cell": (None, [_P, _P, i, _P]),
+        "ho_assign": (None, [_P, i, C.POINTER(_P), _P, i]),
+        "ho_add": (None, [_P, i, C.POINTER(_P), _P, i]),
+        "ho_add_scalar": (None, [_P, d, i]),
+        "ho_mult_elementwise": (None, [_P, i, C.POINTER(_P), i]),
+        "ho_dot": (d, [_P, _P, i]),
+        "ho_set_inner": (None, [_P, d, i]),
+        "ho_jacobi_cell": (None, [_P, _P, _P, _P, i, _P, d]),
+        "ho_prim_slot": (i, [i, i, i, i]),
+        "ho_restrict_cell": (None, [_P, _P, i, _P]),
+        "ho_prolongate_prepare": (None, [_P, i, i]),
+        "ho_prolongate_cell": (None, [_P, _P, i, _P]),
+        "ho_p1_tet_diffusion": (None, [_P, _P]),
+        "ho_p1_tet_mass": (None, [_P, _P]),
+        "ho_assemble_cell_stencil": (None, [_P, _P, i, i]),
+        "ho_coordinate_from_index": (None, [_P, _P, i, i, i, i]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(lib, name)
+        f.restype, f.argtypes = res, args
+    return lib
+
+
+_lib = None
+_lib_fast = None
+
+
+def lib(fast: bool = False):
+    """The strict (-O2, no contraction) oracle, or the -O3 -march=native build used as CPU baseline."""
+    global _lib, _lib_fast
+    if fast:
+        if _lib_fast is None:
+            _lib_fast = _bind(C.CDLL(str(_build_fast())))
+        return _lib_fast
+    if _lib is None:
+        _lib = _bind(C.CDLL(str(_build("libp1_oracle.so"))))
+    return _lib
+
+
+def _build_fast() -> Path:
+    """-march=native must be compiled on the machine it runs on (the GPU box's host differs from
+    the dev container), so the fast build goes to a per-host temp dir, never into the repo."""
+    import hashlib
+    import platform
+    import tempfile
+
+    src = _HERE / "p1_oracle.c"
+    tag = hashlib.sha1((platform.processor() + open("/proc/cpuinfo").read().split("\n\n")[0]).encode()
+                       + src.read_bytes()).hexdigest()[:12]
+    out = Path(tempfile.gettempdir()) / f"libp1_oracle_fast_{tag}.so"
+    if not out.exists():
+        tmp = str(out) + f".{os.getpid()}"
+        subprocess.run(["gcc", "-O3", "-march=native", "-fPIC", "-fvisibility=hidden", "-shared", "-o", tmp,
+                        str(src), "-lm"], check=True)
+        os.replace(tmp, out)
+    return out
+
+
+def _p(a):
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return a.ctypes.data_as(_P)
+
+
+def _pp(arrs):
+    arr = (_P * len(arrs))(*[_p(a) for a in arrs])
+    return arr
+
+
+def _w(w):
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    assert w.shape == (15,)
+    return w
+
+
+# ---- layout ----------------------------------------------------------------------------------
+def width(level): return int(lib().ho_width(level))
+def cell_size(level): return int(lib().ho_cell_size(level))
+def cell_inner_size(level): return int(lib().ho_cell_inner_size(level))
+def cell_index(level, x, y, z): return int(lib().ho_cell_index(level, x, y, z))
+def face_size_w(w): return int(lib().ho_face_size_w(w))
+def face_index_w(w, x, y): return int(lib().ho_face_index_w(w, x, y))
+def prim_slot(level, x, y, z): return int(lib().ho_prim_slot(level, x, y, z))
+
+
+def cell_coords(level):
+    """(size,3) int array of logical (x,y,z) per array slot, in memory order."""
+    n = width(level)
+    out = np.empty((cell_size(level), 3), dtype=np.int64)
+    k = 0
+    for z in range(n):
+        for y in range(n - z):
+            m = n - z - y
+            out[k:k + m, 0] = np.arange(m)
+            out[k:k + m, 1] = y
+            out[k:k + m, 2] = z
+            k += m
+    return out
+
+
+def inner_mask(level):
+    c = cell_coords(level)
+    n = width(level)
+    return (c[:, 0] >= 1) & (c[:, 1] >= 1) & (c[:, 2] >= 1) & (c.sum(axis=1) <= n - 2)
+
+
+# ---- kernels ---------------------------------------------------------------------------------
+def apply_cell(dst, src, level, w, update=REPLACE, fast=False):
+    lib(fast).ho_apply_cell(_p(dst), _p(src), level, _p(_w(w)), update)
+    return dst
+
+
+def sor_cell(u, rhs, level, w, relax, backwards=False, fast=False):
+    lib(fast).ho_sor_cell(_p(u), _p(rhs), level, _p(_w(w)), float(relax), int(backwards))
+    return u
+
+
+def gs_cell(u, rhs, level, w, fast=False):
+    lib(fast).ho_gs_cell(_p(u), _p(rhs), level, _p(_w(w)))
+    return u
+
+
+def assign(dst, scalars, srcs, level):
+    s = np.ascontiguousarray(scalars, dtype=np.float64)
+    lib().ho_assign(_p(dst), len(srcs), _pp(srcs), _p(s), level)
+    return dst
+
+
+def add(dst, scalars, srcs, level):
+    s = np.ascontiguousarray(scalars, dtype=np.float64)
+    lib().ho_add(_p(dst), len(srcs), _pp(srcs), _p(s), level)
+    return dst
+
+
+def add_scalar(dst, scalar, level):
+    lib().ho_add_scalar(_p(dst), float(scalar), level)
+    return dst
+
+
+def mult_elementwise(dst, srcs, level):
+    lib().ho_mult_elementwise(_p(dst), len(srcs), _pp(srcs), level)
+    return dst
+
+
+def dot(a, b, level): return float(lib().ho_dot(_p(a), _p(b), level))
+
+
+def set_inner(dst, value, level):
+    lib().ho_set_inner(_p(dst), float(value), level)
+    return dst
+
+
+def jacobi_cell(dst, rhs, src, level, w, relax, invdiag=None, fast=False):
+    lib(fast).ho_jacobi_cell(_p(dst), _p(rhs), _p(src), _p(invdiag) if invdiag is not None else None, level,
+                             _p(_w(w)), float(relax))
+    return dst
+
+
+def _nnc(nnc):
+    n = np.ascontiguousarray(nnc, dtype=np.float64)
+    assert n.shape == (14,)  # edge0..5, face0..3, vertex0..3
+    return n
+
+
+def restrict_cell(coarse, fine, coarse_level, nnc):
+    lib().ho_restrict_cell(_p(coarse), _p(fine), coarse_level, _p(_nnc(nnc)))
+    return coarse
+
+
+def prolongate_prepare(fine, fine_level, update):
+    lib().ho_prolongate_prepare(_p(fine), fine_level, update)
+    return fine
+
+
+def prolongate_cell(coarse, fine, coarse_level, nnc):
+    lib().ho_prolongate_cell(_p(coarse), _p(fine), coarse_level, _p(_nnc(nnc)))
+    return fine
+
+
+# ---- stencil assembly -------------------------------------------------------------------------
+def p1_tet_diffusion(coords):
+    c = np.ascontiguousarray(coords, dtype=np.float64).reshape(12)
+    A = np.empty(16)
+    lib().ho_p1_tet_diffusion(_p(A), _p(c))
+    return A.reshape(4, 4)
+
+
+def p1_tet_mass(coords):
+    c = np.ascontiguousarray(coords, dtype=np.float64).reshape(12)
+    A = np.empty(16)
+    lib().ho_p1_tet_mass(_p(A), _p(c))
+    return A.reshape(4, 4)
+
+
+def assemble_cell_stencil(cell_vertex_coords, level, form=0):
+    c = np.ascontiguousarray(cell_vertex_coords, dtype=np.float64).reshape(12)
+    w = np.empty(15)
+    lib().ho_assemble_cell_stencil(_p(w), _p(c), level, form)
+    return w
+
+
+def coordinate_from_index(cell_vertex_coords, level, x, y, z):
+    c = np.ascontiguousarray(cell_vertex_coords, dtype=np.float64).reshape(12)
+    out = np.empty(3)
+    lib().ho_coordinate_from_index(_p(out), _p(c), level, x, y, z)
+    return out
+
+
+def interpolate(cell_vertex_coords, level, fn):
+    """Evaluate fn(x,y,z) (vectorised over arrays) at every micro-vertex of the cell array."""
+    cc = np.asarray(cell_vertex_coords, dtype=np.float64).reshape(4, 3)
+    ijk = cell_coords(level).astype(np.float64)
+    step = 1.0 / float(1 << level)
+    xs, ys, zs = (cc[1] - cc[0]) * step, (cc[2] - cc[0]) * step, (cc[3] - cc[0]) * step
+    p = cc[0][None, :] + ijk[:, 0:1] * xs[None, :] + ijk[:, 1:2] * ys[None, :] + ijk[:, 2:3] * zs[None, :]
+    return np.ascontiguousarray(fn(p[:, 0], p[:, 1], p[:, 2]), dtype=np.float64)
+
+
+# ---- the reference's own FEniCS element matrices, compiled in place (oracle/_ref) ---------------
+def ref_fenics():
+    """ctypes handle on oracle/_ref/libhyteg_ref_fenics.so or None if it was never built
+    (it can only be built where /root/reference is mounted)."""
+    so = _HERE / "_ref" / "libhyteg_ref_fenics.so"
+    if not so.exists():
+        if Path("/root/reference/src/hyteg/forms/form_fenics_generated").is_dir():
+            subprocess.run(["make", "-C", str(_HERE), "ref"], check=True, capture_output=True)
+        if not so.exists():
+            return None
+    l = C.CDLL(str(so))
+    for n in ("ref_p1_tet_diffusion", "ref_p1_tet_mass"):
+        getattr(l, n).restype, getattr(l, n).argtypes = None, [_P, _P]
+    return l
