@@ -1,0 +1,153 @@
+"""ctypes binding of libhyteg_hip.so (include/hyteg_hip.h).  Plumbing only: every call goes straight to
+the C-ABI; device memory comes from the caller (e.g. torch CUDA tensors' data_ptr()) or hyteg_hip_malloc."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+_LIB_PATH = _PKG / "lib" / "libhyteg_hip.so"
+
+REPLACE, ADD = 0, 1
+MIN_LEVEL, MAX_LEVEL, MAX_SRCS = 2, 11, 4
+
+# every symbol include/hyteg_hip.h declares: (restype, argtypes)
+_vp, _i, _d, _sz, _i64 = C.c_void_p, C.c_int, C.c_double, C.c_size_t, C.c_int64
+_dp = C.POINTER(C.c_double)
+SIGNATURES = {
+    "hyteg_hip_version": (C.c_char_p, []),
+    "hyteg_hip_last_error": (C.c_char_p, []),
+    "hyteg_hip_device_count": (_i, [C.POINTER(_i)]),
+    "hyteg_hip_set_device": (_i, [_i]),
+    "hyteg_hip_device_name": (_i, [C.c_char_p, _sz]),
+    "hyteg_hip_malloc": (_i, [C.POINTER(_vp), _sz]),
+    "hyteg_hip_free": (_i, [_vp]),
+    "hyteg_hip_memset_zero": (_i, [_vp, _sz, _vp]),
+    "hyteg_hip_upload": (_i, [_vp, _vp, _sz, _vp]),
+    "hyteg_hip_download": (_i, [_vp, _vp, _sz, _vp]),
+    "hyteg_hip_copy": (_i, [_vp, _vp, _sz, _vp]),
+    "hyteg_hip_stream_create": (_i, [C.POINTER(_vp)]),
+    "hyteg_hip_stream_destroy": (_i, [_vp]),
+    "hyteg_hip_stream_synchronize": (_i, [_vp]),
+    "hyteg_hip_prepare_level": (_i, [_i]),
+    "hyteg_hip_cell_width": (_i64, [_i]),
+    "hyteg_hip_cell_size": (_i64, [_i]),
+    "hyteg_hip_cell_inner_size": (_i64, [_i]),
+    "hyteg_hip_cell_index": (_i64, [_i, _i, _i, _i]),
+    "hyteg_hip_p1_apply_cell": (_i, [_vp, _vp, _i, _dp, _i, _vp]),
+    "hyteg_hip_p1_jacobi_cell": (_i, [_vp, _vp, _vp, _vp, _i, _dp, _d, _vp]),
+    "hyteg_hip_p1_sor_cell": (_i, [_vp, _vp, _i, _dp, _d, _i, _vp]),
+    "hyteg_hip_p1_assign_cell": (_i, [_vp, _i, C.POINTER(_vp), _dp, _i, _vp]),
+    "hyteg_hip_p1_add_cell": (_i, [_vp, _i, C.POINTER(_vp), _dp, _i, _vp]),
+    "hyteg_hip_p1_mult_cell": (_i, [_vp, _i, C.POINTER(_vp), _i, _vp]),
+    "hyteg_hip_dot_workspace_bytes": (_sz, []),
+    "hyteg_hip_p1_dot_cell": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "hyteg_hip_p1_restrict_cell": (_i, [_vp, _vp, _i, _dp, _vp]),
+    "hyteg_hip_p1_prolongate_cell": (_i, [_vp, _vp, _i, _dp, _i, _vp]),
+}
+
+
+class HytegHipError(RuntimeError):
+    pass
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """The loaded C-ABI library.  Raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not _LIB_PATH.exists():
+            raise HytegHipError(
+                f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  hyteg_amd has no CPU fallback.")
+        l = C.CDLL(str(_LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(l, name)  # AttributeError here = header and library out of sync
+            f.restype, f.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().hyteg_hip_last_error().decode(errors="replace")
+        raise HytegHipError(f"{what or 'hyteg_hip call'} failed (code {rc}): {msg}")
+
+
+def _w15(w):
+    arr = (C.c_double * 15)(*[float(v) for v in w])
+    return arr
+
+
+def _f14(v):
+    return (C.c_double * 14)(*[float(x) for x in v])
+
+
+def _ptrs(ptrs):
+    return (_vp * len(ptrs))(*[int(p) for p in ptrs])
+
+
+def _scal(s):
+    return (C.c_double * len(s))(*[float(x) for x in s])
+
+
+# ---- thin, checked wrappers (pointers are ints: device addresses) -------------------------------------------
+def cell_size(level): return int(lib().hyteg_hip_cell_size(level))
+def cell_inner_size(level): return int(lib().hyteg_hip_cell_inner_size(level))
+def cell_width(level): return int(lib().hyteg_hip_cell_width(level))
+def cell_index(level, x, y, z): return int(lib().hyteg_hip_cell_index(level, x, y, z))
+def prepare_level(level): check(lib().hyteg_hip_prepare_level(level), "prepare_level")
+
+
+def device_name() -> str:
+    buf = C.create_string_buffer(256)
+    check(lib().hyteg_hip_device_name(buf, 256), "device_name")
+    return buf.value.decode()
+
+
+def p1_apply_cell(dst, src, level, w, update=REPLACE, stream=0):
+    check(lib().hyteg_hip_p1_apply_cell(dst, src, level, _w15(w), update, stream), "p1_apply_cell")
+
+
+def p1_jacobi_cell(dst, rhs, src, level, w, relax, invdiag=None, stream=0):
+    check(lib().hyteg_hip_p1_jacobi_cell(dst, rhs, src, invdiag, level, _w15(w), float(relax), stream),
+          "p1_jacobi_cell")
+
+
+def p1_sor_cell(u, rhs, level, w, relax, backwards=False, stream=0):
+    check(lib().hyteg_hip_p1_sor_cell(u, rhs, level, _w15(w), float(relax), int(backwards), stream), "p1_sor_cell")
+
+
+def p1_assign_cell(dst, scalars, srcs, level, stream=0):
+    check(lib().hyteg_hip_p1_assign_cell(dst, len(srcs), _ptrs(srcs), _scal(scalars), level, stream),
+          "p1_assign_cell")
+
+
+def p1_add_cell(dst, scalars, srcs, level, stream=0):
+    check(lib().hyteg_hip_p1_add_cell(dst, len(srcs), _ptrs(srcs), _scal(scalars), level, stream), "p1_add_cell")
+
+
+def p1_mult_cell(dst, srcs, level, stream=0):
+    check(lib().hyteg_hip_p1_mult_cell(dst, len(srcs), _ptrs(srcs), level, stream), "p1_mult_cell")
+
+
+def dot_workspace_bytes(): return int(lib().hyteg_hip_dot_workspace_bytes())
+
+
+def p1_dot_cell(a, b, level, result_dev, workspace_dev, stream=0):
+    check(lib().hyteg_hip_p1_dot_cell(a, b, level, result_dev, workspace_dev, stream), "p1_dot_cell")
+
+
+def p1_restrict_cell(coarse, fine, coarse_level, nnc, stream=0):
+    check(lib().hyteg_hip_p1_restrict_cell(coarse, fine, coarse_level, _f14(nnc), stream), "p1_restrict_cell")
+
+
+def p1_prolongate_cell(coarse, fine, coarse_level, nnc, update=REPLACE, stream=0):
+    check(lib().hyteg_hip_p1_prolongate_cell(coarse, fine, coarse_level, _f14(nnc), update, stream),
+          "p1_prolongate_cell")

@@ -1,0 +1,107 @@
+// Shared host/device helpers of libhyteg_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/hyteg_hip.h"
+
+namespace hyteg_hip {
+
+// ---- error plumbing -------------------------------------------------------------------------
+void set_error( const std::string& msg );
+int  fail( int code, const std::string& msg );
+
+#define HH_CHECK_HIP( expr )                                                                                         \
+   do                                                                                                                \
+   {                                                                                                                 \
+      hipError_t _e = ( expr );                                                                                      \
+      if ( _e != hipSuccess )                                                                                        \
+         return ::hyteg_hip::fail( _e == hipErrorOutOfMemory ? HYTEG_HIP_ENOMEM : HYTEG_HIP_ELAUNCH,                 \
+                                   std::string( #expr ) + ": " + hipGetErrorString( _e ) );                          \
+   } while ( 0 )
+
+#define HH_REQUIRE( cond, msg )                                         \
+   do                                                                   \
+   {                                                                    \
+      if ( !( cond ) )                                                  \
+         return ::hyteg_hip::fail( HYTEG_HIP_EINVAL, std::string( msg ) ); \
+   } while ( 0 )
+
+inline bool level_ok( int level ) { return level >= HYTEG_HIP_MIN_LEVEL && level <= HYTEG_HIP_MAX_LEVEL; }
+
+// ---- HyTeG macro-cell layout (src/hyteg/indexing/MacroCellIndexing.hpp:40-52) ----------------
+__host__ __device__ inline int tri( int w ) { return ( w * ( w + 1 ) ) / 2; }
+__host__ __device__ inline int64_t tet64( int64_t w ) { return ( w * ( w + 1 ) * ( w + 2 ) ) / 6; }
+// start of slice z in a cell array of width N
+__host__ __device__ inline int slice_start( int N, int z )
+{
+   return (int) ( tet64( N ) - tet64( N - z ) );
+}
+// start of row y inside a slice whose row 0 has length W
+__host__ __device__ inline int row_start( int W, int y ) { return y * W - ( y * ( y - 1 ) ) / 2; }
+__host__ __device__ inline int cell_index( int N, int x, int y, int z )
+{
+   return slice_start( N, z ) + row_start( N - z, y ) + x;
+}
+
+// Row of the slice-local offset j in a slice whose row 0 has length W: largest y with row_start(W,y) <= j.
+__device__ inline int row_of( int W, int j )
+{
+   const float b    = (float) ( 2 * W + 1 );
+   const float disc = b * b - 8.0f * (float) j;
+   int         y    = (int) ( ( b - __builtin_sqrtf( disc > 0.0f ? disc : 0.0f ) ) * 0.5f );
+   y                = y < 0 ? 0 : ( y > W - 1 ? W - 1 : y );
+   while ( row_start( W, y ) > j )
+      --y;
+   while ( y + 1 < W && row_start( W, y + 1 ) <= j )
+      ++y;
+   return y;
+}
+
+// ---- tile tables ------------------------------------------------------------------------------
+// A tile is a run of `cnt` consecutive array entries inside ONE z-slice.  Kernels map one workgroup
+// to one tile; because the layout is linear, everything a tile's stencils touch is three contiguous
+// spans of the source array (slices z-1, z, z+1).
+struct Tile
+{
+   int a;   // global index of the first entry
+   int cnt; // number of entries (<= tile capacity)
+   int z;   // slice
+   int ya;  // row of the first entry
+   int yb;  // row of the last entry
+   int pad[3];
+};
+static_assert( sizeof( Tile ) == 32, "Tile must be 32 bytes" );
+
+enum TileKind
+{
+   TILES_INNER = 0, // cover rows 1..W-3 of slices 1..N-3 (the range the interior kernels loop over)
+   TILES_FULL  = 1  // cover every entry of the array
+};
+
+struct TileTable
+{
+   const Tile* dev   = nullptr;
+   int         count = 0;
+};
+
+// Returns the (cached, device-resident) tile table for (current device, level, kind, capacity).
+// First use allocates and uploads synchronously; later uses are lookup only.
+int get_tiles( int level, TileKind kind, int capacity, TileTable* out );
+
+inline hipStream_t as_stream( hyteg_hip_stream_t s ) { return reinterpret_cast< hipStream_t >( s ); }
+
+struct Stencil15
+{
+   double w[15];
+};
+struct Nnc14
+{
+   double inv[14]; // 1 / numNeighborCells: edge0..5, face0..3, vertex0..3
+};
+
+} // namespace hyteg_hip

@@ -1,0 +1,83 @@
+// C-ABI entry points: constant-stencil apply and fused weighted Jacobi on one macro-cell.
+#include "kernels_apply.hpp"
+
+using namespace hyteg_hip;
+
+namespace {
+
+constexpr int kTile = 1024;
+
+template < int MODE >
+int launch_apply( double* dst, const double* src, const double* rhs, const double* invdiag, int level, const double* w,
+                  double relax, hipStream_t stream )
+{
+   TileTable tt;
+   int       rc = get_tiles( level, TILES_INNER, kTile, &tt );
+   if ( rc != HYTEG_HIP_OK )
+      return rc;
+   if ( tt.count == 0 )
+      return HYTEG_HIP_OK;
+
+   ApplyArgs A;
+   A.dst     = dst;
+   A.src     = src;
+   A.rhs     = rhs;
+   A.invdiag = invdiag;
+   A.tiles   = tt.dev;
+   A.ntiles  = tt.count;
+   A.N       = ( 1 << level ) + 1;
+   A.total   = (int) tet64( A.N );
+   A.relax   = relax;
+   for ( int k = 0; k < 15; ++k )
+      A.st.w[k] = w[k];
+   const int nblocks = ( tt.count + 7 ) & ~7;
+   A.xcd_chunk       = nblocks / 8;
+
+   const size_t lds_bytes = (size_t) apply_lds_doubles( kTile, A.N ) * sizeof( double );
+   const bool   vec       = ( reinterpret_cast< uintptr_t >( src ) & 15 ) == 0;
+   auto         kern      = vec ? p1_apply_tiled_kernel< MODE, true > : p1_apply_tiled_kernel< MODE, false >;
+   if ( lds_bytes > 48 * 1024 )
+      HH_CHECK_HIP( hipFuncSetAttribute( reinterpret_cast< const void* >( kern ),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int) lds_bytes ) );
+   hipLaunchKernelGGL( kern, dim3( nblocks ), dim3( kApplyThreads ), lds_bytes, stream, A );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+HYTEG_HIP_API int hyteg_hip_p1_apply_cell( double*            dst,
+                                           const double*      src,
+                                           int                level,
+                                           const double*      w,
+                                           int                update,
+                                           hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( dst && src && w, "p1_apply_cell: null pointer" );
+   HH_REQUIRE( level_ok( level ), "p1_apply_cell: level out of range [2,11]" );
+   HH_REQUIRE( dst != src, "p1_apply_cell: src and dst must not alias" );
+   HH_REQUIRE( update == HYTEG_HIP_REPLACE || update == HYTEG_HIP_ADD, "p1_apply_cell: bad update type" );
+   if ( update == HYTEG_HIP_REPLACE )
+      return launch_apply< APPLY_REPLACE >( dst, src, nullptr, nullptr, level, w, 0.0, as_stream( stream ) );
+   return launch_apply< APPLY_ADD >( dst, src, nullptr, nullptr, level, w, 0.0, as_stream( stream ) );
+}
+
+HYTEG_HIP_API int hyteg_hip_p1_jacobi_cell( double*            dst,
+                                            const double*      rhs,
+                                            const double*      src,
+                                            const double*      invdiag,
+                                            int                level,
+                                            const double*      w,
+                                            double             relax,
+                                            hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( dst && rhs && src && w, "p1_jacobi_cell: null pointer" );
+   HH_REQUIRE( level_ok( level ), "p1_jacobi_cell: level out of range [2,11]" );
+   HH_REQUIRE( dst != src, "p1_jacobi_cell: src and dst must not alias" );
+   HH_REQUIRE( w[7] != 0.0, "p1_jacobi_cell: zero centre weight" );
+   return launch_apply< APPLY_JACOBI >( dst, src, rhs, invdiag, level, w, relax, as_stream( stream ) );
+}
+}

@@ -1,0 +1,260 @@
+// C-ABI entry points: assign / add / multElementwise / dot on the interior of one macro-cell.
+// Pure streaming kernels: one workgroup per inner tile, 8-byte coalesced accesses, the only extra
+// work being the row decode that masks the two boundary entries of every row.
+#include "common.hpp"
+
+using namespace hyteg_hip;
+
+namespace {
+
+constexpr int kTile    = 1024;
+constexpr int kThreads = 256;
+
+struct VecArgs
+{
+   double*       dst;
+   const double* src[HYTEG_HIP_MAX_SRCS];
+   double        c[HYTEG_HIP_MAX_SRCS];
+   const Tile*   tiles;
+   int           ntiles;
+   int           N;
+   int           nsrc;
+};
+
+enum VecOp
+{
+   OP_ASSIGN = 0,
+   OP_ADD    = 1,
+   OP_MULT   = 2
+};
+
+__device__ inline bool inner_entry( int N, const Tile& tl, int s0, int i )
+{
+   const int W = N - tl.z;
+   const int j = i - s0;
+   const int y = row_of( W, j );
+   const int x = j - row_start( W, y );
+   return x >= 1 && x <= W - y - 2;
+}
+
+template < int OP, int NSRC >
+__global__ __launch_bounds__( kThreads ) void p1_vector_kernel( const VecArgs A )
+{
+   const int t = blockIdx.x;
+   if ( t >= A.ntiles )
+      return;
+   const Tile tl = A.tiles[t];
+   const int  s0 = slice_start( A.N, tl.z );
+   for ( int e = threadIdx.x; e < tl.cnt; e += kThreads )
+   {
+      const int i = tl.a + e;
+      if ( !inner_entry( A.N, tl, s0, i ) )
+         continue;
+      double tmp;
+      if ( OP == OP_MULT )
+      {
+         tmp = A.src[0][i];
+#pragma unroll
+         for ( int k = 1; k < NSRC; ++k )
+            tmp *= A.src[k][i];
+         A.dst[i] = tmp;
+      }
+      else
+      {
+         tmp = A.c[0] * A.src[0][i];
+#pragma unroll
+         for ( int k = 1; k < NSRC; ++k )
+            tmp += A.c[k] * A.src[k][i];
+         A.dst[i] = ( OP == OP_ADD ) ? A.dst[i] + tmp : tmp;
+      }
+   }
+}
+
+template < int OP >
+int launch_vec( double* dst, int nsrc, const double* const* srcs, const double* scalars, int level, hipStream_t stream )
+{
+   TileTable tt;
+   int       rc = get_tiles( level, TILES_INNER, kTile, &tt );
+   if ( rc != HYTEG_HIP_OK )
+      return rc;
+   if ( tt.count == 0 )
+      return HYTEG_HIP_OK;
+   VecArgs A{};
+   A.dst = dst;
+   for ( int k = 0; k < nsrc; ++k )
+   {
+      A.src[k] = srcs[k];
+      A.c[k]   = scalars ? scalars[k] : 1.0;
+   }
+   A.tiles  = tt.dev;
+   A.ntiles = tt.count;
+   A.N      = ( 1 << level ) + 1;
+   A.nsrc   = nsrc;
+   switch ( nsrc )
+   {
+   case 1:
+      hipLaunchKernelGGL( ( p1_vector_kernel< OP, 1 > ), dim3( tt.count ), dim3( kThreads ), 0, stream, A );
+      break;
+   case 2:
+      hipLaunchKernelGGL( ( p1_vector_kernel< OP, 2 > ), dim3( tt.count ), dim3( kThreads ), 0, stream, A );
+      break;
+   case 3:
+      hipLaunchKernelGGL( ( p1_vector_kernel< OP, 3 > ), dim3( tt.count ), dim3( kThreads ), 0, stream, A );
+      break;
+   default:
+      hipLaunchKernelGGL( ( p1_vector_kernel< OP, 4 > ), dim3( tt.count ), dim3( kThreads ), 0, stream, A );
+      break;
+   }
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
+// ---- dot ---------------------------------------------------------------------------------------
+constexpr int kDotBlocks = 1024; // partial sums; also the workspace size in doubles
+
+__device__ inline double wave_sum( double v )
+{
+#pragma unroll
+   for ( int off = 32; off > 0; off >>= 1 )
+      v += __shfl_down( v, off, 64 );
+   return v;
+}
+
+__device__ inline double block_sum( double v, double* sh /* >= kThreads/64 */ )
+{
+   v = wave_sum( v );
+   if ( ( threadIdx.x & 63 ) == 0 )
+      sh[threadIdx.x >> 6] = v;
+   __syncthreads();
+   double r = 0.0;
+   if ( threadIdx.x == 0 )
+   {
+#pragma unroll
+      for ( int k = 0; k < kThreads / 64; ++k )
+         r += sh[k];
+   }
+   return r; // valid in thread 0
+}
+
+__global__ __launch_bounds__( kThreads ) void p1_dot_partial_kernel( const double* __restrict__ a,
+                                                                      const double* __restrict__ b,
+                                                                      const Tile* tiles,
+                                                                      int         ntiles,
+                                                                      int         N,
+                                                                      double*     partial )
+{
+   __shared__ double sh[kThreads / 64];
+   double            acc = 0.0;
+   // fixed tile -> workgroup assignment: deterministic summation order
+   for ( int t = blockIdx.x; t < ntiles; t += gridDim.x )
+   {
+      const Tile tl = tiles[t];
+      const int  s0 = slice_start( N, tl.z );
+      for ( int e = threadIdx.x; e < tl.cnt; e += kThreads )
+      {
+         const int i = tl.a + e;
+         if ( inner_entry( N, tl, s0, i ) )
+            acc = fma( a[i], b[i], acc );
+      }
+   }
+   const double r = block_sum( acc, sh );
+   if ( threadIdx.x == 0 )
+      partial[blockIdx.x] = r;
+}
+
+__global__ __launch_bounds__( kThreads ) void p1_dot_final_kernel( const double* partial, int n, double* result )
+{
+   __shared__ double sh[kThreads / 64];
+   double            acc = 0.0;
+   for ( int k = threadIdx.x; k < n; k += kThreads )
+      acc += partial[k];
+   const double r = block_sum( acc, sh );
+   if ( threadIdx.x == 0 )
+      *result = r;
+}
+
+} // namespace
+
+extern "C" {
+
+#define VEC_COMMON_CHECKS( name )                                                                          \
+   HH_REQUIRE( dst && srcs, name ": null pointer" );                                                       \
+   HH_REQUIRE( level_ok( level ), name ": level out of range [2,11]" );                                    \
+   HH_REQUIRE( nsrc >= 1 && nsrc <= HYTEG_HIP_MAX_SRCS, name ": nsrc must be 1..HYTEG_HIP_MAX_SRCS" );     \
+   for ( int k = 0; k < nsrc; ++k )                                                                        \
+      HH_REQUIRE( srcs[k] != nullptr, name ": null source pointer" );
+
+HYTEG_HIP_API int hyteg_hip_p1_assign_cell( double*              dst,
+                                            int                  nsrc,
+                                            const double* const* srcs,
+                                            const double*        scalars,
+                                            int                  level,
+                                            hyteg_hip_stream_t   stream )
+{
+   VEC_COMMON_CHECKS( "p1_assign_cell" );
+   HH_REQUIRE( scalars != nullptr, "p1_assign_cell: null scalars" );
+   return launch_vec< OP_ASSIGN >( dst, nsrc, srcs, scalars, level, as_stream( stream ) );
+}
+
+HYTEG_HIP_API int hyteg_hip_p1_add_cell( double*              dst,
+                                         int                  nsrc,
+                                         const double* const* srcs,
+                                         const double*        scalars,
+                                         int                  level,
+                                         hyteg_hip_stream_t   stream )
+{
+   VEC_COMMON_CHECKS( "p1_add_cell" );
+   HH_REQUIRE( scalars != nullptr, "p1_add_cell: null scalars" );
+   return launch_vec< OP_ADD >( dst, nsrc, srcs, scalars, level, as_stream( stream ) );
+}
+
+HYTEG_HIP_API int
+    hyteg_hip_p1_mult_cell( double* dst, int nsrc, const double* const* srcs, int level, hyteg_hip_stream_t stream )
+{
+   VEC_COMMON_CHECKS( "p1_mult_cell" );
+   return launch_vec< OP_MULT >( dst, nsrc, srcs, nullptr, level, as_stream( stream ) );
+}
+
+HYTEG_HIP_API size_t hyteg_hip_dot_workspace_bytes( void ) { return kDotBlocks * sizeof( double ); }
+
+HYTEG_HIP_API int hyteg_hip_p1_dot_cell( const double*      a,
+                                         const double*      b,
+                                         int                level,
+                                         double*            result_dev,
+                                         void*              workspace_dev,
+                                         hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( a && b && result_dev && workspace_dev, "p1_dot_cell: null pointer" );
+   HH_REQUIRE( level_ok( level ), "p1_dot_cell: level out of range [2,11]" );
+   TileTable tt;
+   int       rc = get_tiles( level, TILES_INNER, kTile, &tt );
+   if ( rc != HYTEG_HIP_OK )
+      return rc;
+   const int nblocks = tt.count < kDotBlocks ? ( tt.count > 0 ? tt.count : 1 ) : kDotBlocks;
+   double*   partial = static_cast< double* >( workspace_dev );
+   hipLaunchKernelGGL( p1_dot_partial_kernel,
+                       dim3( nblocks ),
+                       dim3( kThreads ),
+                       0,
+                       as_stream( stream ),
+                       a,
+                       b,
+                       tt.dev,
+                       tt.count,
+                       ( 1 << level ) + 1,
+                       partial );
+   hipLaunchKernelGGL( p1_dot_final_kernel, dim3( 1 ), dim3( kThreads ), 0, as_stream( stream ), partial, nblocks, result_dev );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_prepare_level( int level )
+{
+   HH_REQUIRE( level_ok( level ), "prepare_level: level out of range [2,11]" );
+   TileTable tt;
+   int       rc = get_tiles( level, TILES_INNER, kTile, &tt );
+   if ( rc != HYTEG_HIP_OK )
+      return rc;
+   return get_tiles( level, TILES_FULL, kTile, &tt );
+}
+}

@@ -1,0 +1,211 @@
+// Runtime part of the C-ABI: errors, device/memory/stream helpers, layout helpers, tile tables.
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include "common.hpp"
+
+namespace hyteg_hip {
+
+static thread_local std::string g_last_error;
+
+void set_error( const std::string& msg ) { g_last_error = msg; }
+int  fail( int code, const std::string& msg )
+{
+   g_last_error = msg;
+   return code;
+}
+
+// ---- tile tables --------------------------------------------------------------------------------
+static std::vector< Tile > build_tiles( int level, TileKind kind, int capacity )
+{
+   const int           N = ( 1 << level ) + 1;
+   std::vector< Tile > tiles;
+   const int           zlo = kind == TILES_INNER ? 1 : 0;
+   const int           zhi = kind == TILES_INNER ? N - 4 : N - 1;
+   for ( int z = zlo; z <= zhi; ++z )
+   {
+      const int W  = N - z;
+      const int s0 = slice_start( N, z );
+      int       first, last; // slice-local offsets, inclusive
+      if ( kind == TILES_INNER )
+      {
+         first = row_start( W, 1 ) + 1;
+         last  = row_start( W, W - 3 ) + 1;
+      }
+      else
+      {
+         first = 0;
+         last  = tri( W ) - 1;
+      }
+      // balance the tiles of a slice: equal sizes rather than full tiles plus a short tail
+      const int total  = last - first + 1;
+      const int ntiles = ( total + capacity - 1 ) / capacity;
+      int       y      = 0;
+      for ( int t = 0; t < ntiles; ++t )
+      {
+         const int lo = first + (int) ( ( (int64_t) total * t ) / ntiles );
+         const int hi = first + (int) ( ( (int64_t) total * ( t + 1 ) ) / ntiles ) - 1;
+         Tile      tl{};
+         tl.a   = s0 + lo;
+         tl.cnt = hi - lo + 1;
+         tl.z   = z;
+         while ( y + 1 < W && row_start( W, y + 1 ) <= lo )
+            ++y;
+         tl.ya  = y;
+         int yb = y;
+         while ( yb + 1 < W && row_start( W, yb + 1 ) <= hi )
+            ++yb;
+         tl.yb = yb;
+         tiles.push_back( tl );
+      }
+   }
+   return tiles;
+}
+
+int get_tiles( int level, TileKind kind, int capacity, TileTable* out )
+{
+   static std::mutex                                                  mtx;
+   static std::map< std::tuple< int, int, int, int >, TileTable >    cache;
+   int                                                                dev = 0;
+   HH_CHECK_HIP( hipGetDevice( &dev ) );
+   std::lock_guard< std::mutex > lock( mtx );
+   auto                          key = std::make_tuple( dev, level, (int) kind, capacity );
+   auto                          it  = cache.find( key );
+   if ( it != cache.end() )
+   {
+      *out = it->second;
+      return HYTEG_HIP_OK;
+   }
+   std::vector< Tile > host = build_tiles( level, kind, capacity );
+   TileTable           tt;
+   tt.count = (int) host.size();
+   if ( tt.count > 0 )
+   {
+      void* p = nullptr;
+      HH_CHECK_HIP( hipMalloc( &p, host.size() * sizeof( Tile ) ) );
+      HH_CHECK_HIP( hipMemcpy( p, host.data(), host.size() * sizeof( Tile ), hipMemcpyHostToDevice ) );
+      tt.dev = static_cast< const Tile* >( p );
+   }
+   cache[key] = tt;
+   *out       = tt;
+   return HYTEG_HIP_OK;
+}
+
+} // namespace hyteg_hip
+
+using namespace hyteg_hip;
+
+extern "C" {
+
+HYTEG_HIP_API const char* hyteg_hip_version( void ) { return "hyteg_hip 0.1 (gfx950)"; }
+HYTEG_HIP_API const char* hyteg_hip_last_error( void ) { return g_last_error.c_str(); }
+
+HYTEG_HIP_API int hyteg_hip_device_count( int* count )
+{
+   HH_REQUIRE( count != nullptr, "device_count: null out pointer" );
+   hipError_t e = hipGetDeviceCount( count );
+   if ( e != hipSuccess )
+   {
+      *count = 0;
+      return fail( HYTEG_HIP_ENODEV, std::string( "hipGetDeviceCount: " ) + hipGetErrorString( e ) );
+   }
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_set_device( int device )
+{
+   HH_CHECK_HIP( hipSetDevice( device ) );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_device_name( char* buf, size_t buflen )
+{
+   HH_REQUIRE( buf != nullptr && buflen > 0, "device_name: bad buffer" );
+   int dev = 0;
+   HH_CHECK_HIP( hipGetDevice( &dev ) );
+   hipDeviceProp_t prop;
+   HH_CHECK_HIP( hipGetDeviceProperties( &prop, dev ) );
+   snprintf( buf, buflen, "%s (%s)", prop.name, prop.gcnArchName );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_malloc( void** dev_ptr, size_t bytes )
+{
+   HH_REQUIRE( dev_ptr != nullptr, "malloc: null out pointer" );
+   *dev_ptr = nullptr;
+   HH_CHECK_HIP( hipMalloc( dev_ptr, bytes ) );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_free( void* dev_ptr )
+{
+   HH_CHECK_HIP( hipFree( dev_ptr ) );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_memset_zero( void* dev_ptr, size_t bytes, hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( dev_ptr != nullptr || bytes == 0, "memset_zero: null pointer" );
+   HH_CHECK_HIP( hipMemsetAsync( dev_ptr, 0, bytes, as_stream( stream ) ) );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_upload( void* dev_dst, const void* host_src, size_t bytes, hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( ( dev_dst && host_src ) || bytes == 0, "upload: null pointer" );
+   HH_CHECK_HIP( hipMemcpyAsync( dev_dst, host_src, bytes, hipMemcpyHostToDevice, as_stream( stream ) ) );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_download( void* host_dst, const void* dev_src, size_t bytes, hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( ( host_dst && dev_src ) || bytes == 0, "download: null pointer" );
+   HH_CHECK_HIP( hipMemcpyAsync( host_dst, dev_src, bytes, hipMemcpyDeviceToHost, as_stream( stream ) ) );
+   HH_CHECK_HIP( hipStreamSynchronize( as_stream( stream ) ) );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_copy( void* dev_dst, const void* dev_src, size_t bytes, hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( ( dev_dst && dev_src ) || bytes == 0, "copy: null pointer" );
+   HH_CHECK_HIP( hipMemcpyAsync( dev_dst, dev_src, bytes, hipMemcpyDeviceToDevice, as_stream( stream ) ) );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_stream_create( hyteg_hip_stream_t* stream )
+{
+   HH_REQUIRE( stream != nullptr, "stream_create: null out pointer" );
+   hipStream_t s;
+   HH_CHECK_HIP( hipStreamCreateWithFlags( &s, hipStreamNonBlocking ) );
+   *stream = reinterpret_cast< hyteg_hip_stream_t >( s );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_stream_destroy( hyteg_hip_stream_t stream )
+{
+   HH_CHECK_HIP( hipStreamDestroy( as_stream( stream ) ) );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_stream_synchronize( hyteg_hip_stream_t stream )
+{
+   HH_CHECK_HIP( hipStreamSynchronize( as_stream( stream ) ) );
+   return HYTEG_HIP_OK;
+}
+
+// ---- layout ---------------------------------------------------------------------------------------
+HYTEG_HIP_API int64_t hyteg_hip_cell_width( int level ) { return ( (int64_t) 1 << level ) + 1; }
+HYTEG_HIP_API int64_t hyteg_hip_cell_size( int level ) { return tet64( hyteg_hip_cell_width( level ) ); }
+HYTEG_HIP_API int64_t hyteg_hip_cell_inner_size( int level )
+{
+   const int64_t n = ( (int64_t) 1 << level ) - 1;
+   return n < 3 ? 0 : n * ( n - 1 ) * ( n - 2 ) / 6;
+}
+HYTEG_HIP_API int64_t hyteg_hip_cell_index( int level, int x, int y, int z )
+{
+   const int64_t N = hyteg_hip_cell_width( level ), W = N - z;
+   return tet64( N ) - tet64( W ) + (int64_t) y * W - ( (int64_t) y * ( y - 1 ) ) / 2 + x;
+}
+}

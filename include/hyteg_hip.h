@@ -1,0 +1,214 @@
+/*
+ * hyteg_hip.h -- C-ABI of libhyteg_hip.so: MI355X (gfx950) kernels for HyTeG's matrix-free P1
+ * hot path (constant-stencil apply, smoothers, vector kernels, grid transfer on macro-cells).
+ *
+ * This is the drop-in boundary.  HyTeG has no plugin/FFI mechanism; the seam is the set of free
+ * functions in namespace hyteg::vertexdof::macrocell::generated that P1ConstantOperator and
+ * VertexDoFFunction call with raw pointers.  Each entry point below names
+ * the reference function (file:line under /root/reference/) it replaces.  INTEGRATION.md shows the
+ * binding a HyTeG maintainer would add on the reference side.
+ *
+ * Conventions
+ *  - plain C, no C++/torch types.  All array pointers are DEVICE pointers (hipMalloc'ed or any
+ *    pointer valid on the current HIP device, e.g. a torch tensor's data_ptr()).
+ *  - arrays use HyTeG's linear tetrahedral macro-cell layout
+ *    (src/hyteg/indexing/MacroCellIndexing.hpp:40-52): width = 2^level + 1, x fastest, then y,
+ *    then z; size = width (width+1) (width+2) / 6.
+ *  - stencil weights w[15] are passed BY VALUE from host memory in the iteration order of the
+ *    reference's std::map<indexing::Index, real_t> (sorted by z, then y, then x;
+ *    src/hyteg/indexing/Common.hpp:67-71):
+ *       0:( 0, 0,-1)  1:( 1, 0,-1)  2:(-1, 1,-1)  3:( 0, 1,-1)
+ *       4:( 0,-1, 0)  5:( 1,-1, 0)  6:(-1, 0, 0)  7:( 0, 0, 0)  8:( 1, 0, 0)  9:(-1, 1, 0) 10:( 0, 1, 0)
+ *      11:( 0,-1, 1) 12:( 1,-1, 1) 13:(-1, 0, 1) 14:( 0, 0, 1)
+ *    so a binding fills it with   for (auto& e : stencilMap) w[k++] = e.second;
+ *  - neighbour-cell counts nnc[14] = { edge0..5, face0..3, vertex0..3 }, the argument order of the
+ *    reference's grid-transfer kernels.
+ *  - every kernel launch is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *    legacy default stream) and stream-ordered with respect to other work on that stream.
+ *  - return value: HYTEG_HIP_OK or an error code; hyteg_hip_last_error() gives a message.
+ *    The reference aborts the process on failure (WALBERLA_ABORT); a binding should do the same.
+ *  - fp64 only, like the reference's generated 3-D kernels (non-double aborts there:
+ *    src/constant_stencil_operator/P1ConstantOperator.cpp:417-420).
+ *  - levels 2..11 (int32 indexing, as in the reference's generated kernels).  The operator loops
+ *    in the reference only run for level >= 2 (src/hyteg/p1functionspace/P1Operator.hpp:293).
+ */
+#ifndef HYTEG_HIP_H
+#define HYTEG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined( HYTEG_HIP_BUILDING )
+#define HYTEG_HIP_API __attribute__( ( visibility( "default" ) ) )
+#else
+#define HYTEG_HIP_API
+#endif
+
+enum
+{
+   HYTEG_HIP_OK      = 0,
+   HYTEG_HIP_EINVAL  = 1, /* bad argument (null pointer, level out of range, aliasing src==dst ...) */
+   HYTEG_HIP_ELAUNCH = 2, /* HIP runtime reported an error for a launch / memcpy */
+   HYTEG_HIP_ENOMEM  = 3,
+   HYTEG_HIP_ENODEV  = 4 /* no usable gfx950 device */
+};
+
+/* UpdateType, src/hyteg/types/types.hpp:29-33 */
+enum
+{
+   HYTEG_HIP_REPLACE = 0,
+   HYTEG_HIP_ADD     = 1
+};
+
+#define HYTEG_HIP_MIN_LEVEL 2
+#define HYTEG_HIP_MAX_LEVEL 11
+#define HYTEG_HIP_MAX_SRCS 4 /* assign/add/mult take at most this many source functions */
+
+typedef void* hyteg_hip_stream_t;
+
+/* ---- runtime -------------------------------------------------------------------------------- */
+HYTEG_HIP_API const char* hyteg_hip_version( void );
+HYTEG_HIP_API const char* hyteg_hip_last_error( void );
+HYTEG_HIP_API int         hyteg_hip_device_count( int* count );
+HYTEG_HIP_API int         hyteg_hip_set_device( int device );
+/* name + gcnArchName of the current device, e.g. "AMD Instinct MI355X (gfx950:sramecc+:xnack-)" */
+HYTEG_HIP_API int hyteg_hip_device_name( char* buf, size_t buflen );
+
+/* device memory standing in for FunctionMemory<double>'s per-level std::vector
+ * (src/hyteg/memory/FunctionMemory.hpp:109-113,216) */
+HYTEG_HIP_API int hyteg_hip_malloc( void** dev_ptr, size_t bytes );
+HYTEG_HIP_API int hyteg_hip_free( void* dev_ptr );
+HYTEG_HIP_API int hyteg_hip_memset_zero( void* dev_ptr, size_t bytes, hyteg_hip_stream_t stream );
+HYTEG_HIP_API int hyteg_hip_upload( void* dev_dst, const void* host_src, size_t bytes, hyteg_hip_stream_t stream );
+HYTEG_HIP_API int hyteg_hip_download( void* host_dst, const void* dev_src, size_t bytes, hyteg_hip_stream_t stream );
+HYTEG_HIP_API int hyteg_hip_copy( void* dev_dst, const void* dev_src, size_t bytes, hyteg_hip_stream_t stream );
+HYTEG_HIP_API int hyteg_hip_stream_create( hyteg_hip_stream_t* stream );
+HYTEG_HIP_API int hyteg_hip_stream_destroy( hyteg_hip_stream_t stream );
+HYTEG_HIP_API int hyteg_hip_stream_synchronize( hyteg_hip_stream_t stream );
+
+/* Builds and uploads the per-level launch tables (tile descriptors) so that later launches at that
+ * level allocate nothing (HIP-graph capturable).  Launches do this lazily on first use otherwise. */
+HYTEG_HIP_API int hyteg_hip_prepare_level( int level );
+
+/* ---- layout (host-side helpers; same arithmetic as the kernels) ---------------------------------
+ * src/hyteg/indexing/MacroCellIndexing.hpp:40-52, src/hyteg/Levelinfo.hpp:36-115 */
+HYTEG_HIP_API int64_t hyteg_hip_cell_width( int level );      /* 2^level + 1 */
+HYTEG_HIP_API int64_t hyteg_hip_cell_size( int level );       /* number of doubles in a cell array */
+HYTEG_HIP_API int64_t hyteg_hip_cell_inner_size( int level ); /* DoFs the interior kernels update */
+HYTEG_HIP_API int64_t hyteg_hip_cell_index( int level, int x, int y, int z );
+
+/* ---- a2: constant-stencil apply on one macro-cell ---------------------------------------------------
+ * replaces hyteg::vertexdof::macrocell::generated::apply_3D_macrocell_vertexdof_to_vertexdof_replace / _add
+ *   src/constant_stencil_operator/P1generatedKernels/apply_3D_macrocell_vertexdof_to_vertexdof_replace.cpp:34-101
+ *   src/constant_stencil_operator/P1generatedKernels/apply_3D_macrocell_vertexdof_to_vertexdof_add.cpp
+ *   (caller src/constant_stencil_operator/P1ConstantOperator.cpp:392-428)
+ * dst_i (=|+=) sum_k w_k src_{i+o_k} on the cell interior; boundary entries of dst are not touched.
+ * src and dst must not alias (src/hyteg/p1functionspace/P1Operator.hpp:198). */
+HYTEG_HIP_API int hyteg_hip_p1_apply_cell( double*            dst,
+                                           const double*      src,
+                                           int                level,
+                                           const double*      w /* host, 15 */,
+                                           int                update,
+                                           hyteg_hip_stream_t stream );
+
+/* ---- a4: weighted Jacobi sweep, fused ------------------------------------------------------------------
+ * replaces the 1 apply + 3 vector passes of P1Operator::smooth_jac
+ *   src/hyteg/p1functionspace/P1Operator.hpp:429-447
+ * dst = src + relax * invDiag .* ( rhs - A src )  on the cell interior.
+ * invdiag: cell array of inverse diagonal values (getInverseDiagonalValues()), or NULL to use the
+ * constant 1/w[7] (what computeInverseDiagonalOperatorValues() stores on a constant-stencil cell,
+ * P1Operator.hpp:636-906).  dst must not alias src. */
+HYTEG_HIP_API int hyteg_hip_p1_jacobi_cell( double*            dst,
+                                            const double*      rhs,
+                                            const double*      src,
+                                            const double*      invdiag /* device or NULL */,
+                                            int                level,
+                                            const double*      w /* host, 15 */,
+                                            double             relax,
+                                            hyteg_hip_stream_t stream );
+
+/* ---- a3: SOR / Gauss-Seidel sweep, in place, in the reference's lexicographic order -----------------
+ * replaces sor_3D_macrocell_P1, sor_3D_macrocell_P1_backwards, gaussseidel_3D_macrocell_P1 (relax = 1)
+ *   src/constant_stencil_operator/P1generatedKernels/sor_3D_macrocell_P1.cpp:32-90
+ *   src/constant_stencil_operator/P1generatedKernels/sor_3D_macrocell_P1_backwards.cpp:52-57
+ *   src/constant_stencil_operator/P1generatedKernels/gaussseidel_3D_macrocell_P1.cpp:32-88
+ *   (caller P1ConstantOperator.cpp:639-677)
+ * The sweep is executed as hyperplanes x + 2y + 3z = const, which reproduces the sequential
+ * (z, y, x) update order of the reference exactly (every already-updated neighbour lies on an
+ * earlier plane, every not-yet-updated one on a later plane). */
+HYTEG_HIP_API int hyteg_hip_p1_sor_cell( double*            u,
+                                         const double*      rhs,
+                                         int                level,
+                                         const double*      w /* host, 15 */,
+                                         double             relax,
+                                         int                backwards,
+                                         hyteg_hip_stream_t stream );
+
+/* ---- a6: vector kernels on the cell interior ---------------------------------------------------------
+ * assign:  dst = sum_k c_k src_k      replaces assign_3D_macrocell_vertexdof_{1,2,3}_rhs_function(s)
+ *   src/hyteg/p1functionspace/generatedKernels/assign_3D_macrocell_vertexdof_*.cpp
+ *   (dispatch src/hyteg/p1functionspace/VertexDoFFunction.cpp:1088-1128; generic
+ *    src/hyteg/p1functionspace/VertexDoFMacroCell.hpp:376-402)
+ * add:     dst += sum_k c_k src_k     VertexDoFMacroCell.hpp:456-481, add_3D_macrocell_vertexdof_1_rhsfunction.cpp
+ * mult:    dst = prod_k src_k         VertexDoFMacroCell.hpp:483-508 (multElementwise)
+ * srcs: HOST array of nsrc device pointers (1 <= nsrc <= HYTEG_HIP_MAX_SRCS); sources may alias dst. */
+HYTEG_HIP_API int hyteg_hip_p1_assign_cell( double*              dst,
+                                            int                  nsrc,
+                                            const double* const* srcs,
+                                            const double*        scalars /* host, nsrc */,
+                                            int                  level,
+                                            hyteg_hip_stream_t   stream );
+HYTEG_HIP_API int hyteg_hip_p1_add_cell( double*              dst,
+                                         int                  nsrc,
+                                         const double* const* srcs,
+                                         const double*        scalars /* host, nsrc */,
+                                         int                  level,
+                                         hyteg_hip_stream_t   stream );
+HYTEG_HIP_API int
+    hyteg_hip_p1_mult_cell( double* dst, int nsrc, const double* const* srcs, int level, hyteg_hip_stream_t stream );
+
+/* dot: sum over the cell interior of a_i * b_i   replaces vertexdof::macrocell::dot
+ *   src/hyteg/p1functionspace/VertexDoFMacroCell.hpp:511-529
+ * Two deterministic passes (per-workgroup partial sums, then one workgroup adds them in fixed
+ * order); the result is written to *result_dev (device memory, stream-ordered).  workspace_dev must
+ * hold hyteg_hip_dot_workspace_bytes() bytes and must not be shared by dots in flight on different
+ * streams.  The reference's plain sequential sum differs by reassociation only. */
+HYTEG_HIP_API size_t hyteg_hip_dot_workspace_bytes( void );
+HYTEG_HIP_API int    hyteg_hip_p1_dot_cell( const double*      a,
+                                            const double*      b,
+                                            int                level,
+                                            double*            result_dev,
+                                            void*              workspace_dev,
+                                            hyteg_hip_stream_t stream );
+
+/* ---- a7 / a8: grid transfer on one macro-cell ----------------------------------------------------------
+ * restrict: replaces restrict_3D_macrocell_P1_pull_additive<double>
+ *   src/hyteg/gridtransferoperators/generatedKernels/restrict_3D_macrocell_P1_pull_additive.cpp:33-1690
+ *   (caller src/hyteg/gridtransferoperators/P1toP1LinearRestriction.cpp:169-243)
+ *   writes EVERY coarse point (boundary included) with this cell's partial sum.
+ * prolongate: replaces the zeroing at P1toP1LinearProlongation.cpp:214-238 plus
+ *   prolongate_3D_macrocell_P1_push_additive<double>
+ *   src/hyteg/gridtransferoperators/generatedKernels/prolongate_3D_macrocell_P1_push_additive.cpp
+ *   The reference scatters from coarse points; here every fine point gathers its (at most two)
+ *   coarse parents, adding them in the order the scatter would have.  update = REPLACE overwrites
+ *   the whole fine array; update = ADD overwrites the boundary shell and adds to the interior. */
+HYTEG_HIP_API int hyteg_hip_p1_restrict_cell( double*            coarse,
+                                              const double*      fine,
+                                              int                coarse_level,
+                                              const double*      nnc /* host, 14 */,
+                                              hyteg_hip_stream_t stream );
+HYTEG_HIP_API int hyteg_hip_p1_prolongate_cell( const double*      coarse,
+                                                double*            fine,
+                                                int                coarse_level,
+                                                const double*      nnc /* host, 14 */,
+                                                int                update,
+                                                hyteg_hip_stream_t stream );
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYTEG_HIP_H */
