@@ -192,7 +192,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "p1_apply_tiled_kernel<REPLACE>",
+                "kernel": "p1_apply_zmarch_kernel<REPLACE,4,4>",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -93,7 +93,23 @@ struct TileTable
 // First use allocates and uploads synchronously; later uses are lookup only.
 int get_tiles( int level, TileKind kind, int capacity, TileTable* out );
 
+// Brick task tables of the z-march apply kernel (kernels_apply_zmarch.hpp), cached like tile tables.
+struct BrickTask;
+struct BrickTable
+{
+   const BrickTask* dev   = nullptr;
+   int              count = 0;
+};
+int get_bricks( int level, int NY, int LZ, BrickTable* out );
+
 inline hipStream_t as_stream( hyteg_hip_stream_t s ) { return reinterpret_cast< hipStream_t >( s ); }
+
+enum ApplyMode
+{
+   APPLY_REPLACE = 0,
+   APPLY_ADD     = 1,
+   APPLY_JACOBI  = 2
+};
 
 struct Stencil15
 {

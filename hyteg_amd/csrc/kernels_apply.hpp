@@ -18,13 +18,6 @@
 
 namespace hyteg_hip {
 
-enum ApplyMode
-{
-   APPLY_REPLACE = 0,
-   APPLY_ADD     = 1,
-   APPLY_JACOBI  = 2
-};
-
 constexpr int kApplyThreads = 256;
 
 struct ApplyArgs

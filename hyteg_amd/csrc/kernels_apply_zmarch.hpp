@@ -1,0 +1,240 @@
+// "z-march" kernel for the 15-point constant-stencil apply / fused Jacobi on one macro-cell.
+//
+// Measured facts that shape it (MI355X, level 8; DESIGN.md has the numbers):
+//   * the apply moves only 46 MB; a plain copy of that size takes ~10 us, of which ~1.7 us is launch/ramp;
+//   * arithmetic, index decode, DPP shifts are NOT the bound (removing all arithmetic changes nothing);
+//   * what costs time is (a) re-reading every source row ~4x through L1/L2 and (b) issuing all loads first
+//     and all stores last, so that HBM reads and the write-back of dst never overlap.
+// So: one WAVE owns a brick of NY rows x 64 x-positions (lanes 1..62 produce outputs) x LZ slices and marches
+// in +z.  Slice z+1's rows are loaded ONCE and serve as "up" rows for slice z, centre rows for z+1 and "down"
+// rows for z+2 straight from registers ((LZ(NY+2)+2(NY+1))/(LZ NY) ~ 1.8 row loads per output row instead of
+// 4), and the loads of slice z+2 are issued before slice z is evaluated and stored, so loads and stores are
+// in flight together in every wave.  Everything is fully unrolled (compile-time NY, LZ): no loop-carried
+// register copies, exact s_waitcnt accounting.  x-1/x+1 neighbours come from wave-wide DPP shifts; addresses
+// are wave-uniform row bases + lane*8 through a buffer descriptor whose range check returns 0 past the array
+// end and drops stores whose offset is forced out of range (no exec masking, no clamping).
+//
+// Index algebra: W = N-z; element (x,y,z) -> (x,y,z+1): + tri(W) - y;  (x,y,z) -> (x,y+1,z): + (W-y).
+#pragma once
+
+#include <algorithm>
+#include <vector>
+
+#include "common.hpp"
+
+namespace hyteg_hip {
+
+struct BrickTask
+{
+   int i0;  // element index of (xb, y0-1, z0-1): first row segment of the first slice
+   int W0;  // N - (z0-1): row-0 length of slice z0-1
+   int y0;  // first output row
+   int xb;  // x held by lane 0 (= x0 - 1, x0 = first output x)
+   int nz;  // slices of this brick that exist (<= LZ)
+   int pad[3];
+};
+static_assert( sizeof( BrickTask ) == 32, "BrickTask must be 32 bytes" );
+
+struct ZMarchArgs
+{
+   double*          dst;
+   const double*    src;
+   const double*    rhs;     // JACOBI only
+   const double*    invdiag; // JACOBI only, may be null
+   const BrickTask* tasks;
+   int              ntasks;
+   unsigned         bytes;     // size of the cell array in bytes (buffer range)
+   int              xcd_chunk; // workgroups per XCD group (0: identity map)
+   int              pad;
+   double           relax;
+   Stencil15        st;
+};
+
+constexpr int kZMarchWavesPerBlock = 4;
+
+typedef int zm_v2i_t __attribute__( ( ext_vector_type( 2 ) ) );
+
+template < int AUX = 0 >
+__device__ inline double zm_load( __amdgpu_buffer_rsrc_t r, int byte_off )
+{
+   zm_v2i_t v = __builtin_amdgcn_raw_buffer_load_b64( r, byte_off, 0, AUX );
+   return *reinterpret_cast< double* >( &v );
+}
+template < int AUX = 0 >
+__device__ inline void zm_store( __amdgpu_buffer_rsrc_t r, int byte_off, double d )
+{
+   __builtin_amdgcn_raw_buffer_store_b64( *reinterpret_cast< zm_v2i_t* >( &d ), r, byte_off, 0, AUX );
+}
+__device__ inline double zm_lane_minus_1( double v )
+{
+   int lo = __double2loint( v ), hi = __double2hiint( v );
+   lo     = __builtin_amdgcn_mov_dpp( lo, 0x138, 0xf, 0xf, true ); // wave_shr:1
+   hi     = __builtin_amdgcn_mov_dpp( hi, 0x138, 0xf, 0xf, true );
+   return __hiloint2double( hi, lo );
+}
+__device__ inline double zm_lane_plus_1( double v )
+{
+   int lo = __double2loint( v ), hi = __double2hiint( v );
+   lo     = __builtin_amdgcn_mov_dpp( lo, 0x130, 0xf, 0xf, true ); // wave_shl:1
+   hi     = __builtin_amdgcn_mov_dpp( hi, 0x130, 0xf, 0xf, true );
+   return __hiloint2double( hi, lo );
+}
+
+// Cache policy (gfx950 "aux" bits: 1 = sc0, 2 = nt, 16 = sc1).  dst is written once and never re-read by this
+// kernel: nontemporal stores took the level-8 apply from 14.5 to 10.4 us (they do not leave 22 MB of dirty
+// lines for the end-of-kernel L2 write-back).  ABL: developer ablation switches, 0 in production
+// (4 = no stores, 8 = no stencil arithmetic).
+constexpr int kStoreAuxDefault = 2;
+template < int MODE, int NY, int LZ, int ABL = 0, int ST_AUX = kStoreAuxDefault, int LD_AUX = 0 >
+__global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_kernel( const ZMarchArgs A )
+{
+   int b = blockIdx.x;
+   if ( A.xcd_chunk > 0 )
+      b = ( blockIdx.x & 7 ) * A.xcd_chunk + ( blockIdx.x >> 3 );
+   const int task = __builtin_amdgcn_readfirstlane( b * kZMarchWavesPerBlock + ( threadIdx.x >> 6 ) );
+   if ( task >= A.ntasks )
+      return;
+   const BrickTask t    = A.tasks[task];
+   const int       lane = threadIdx.x & 63;
+
+   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc( const_cast< double* >( A.src ), 0, A.bytes, 0x00020000 );
+   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc( A.dst, 0, A.bytes, 0x00020000 );
+   const __amdgpu_buffer_rsrc_t rr =
+       __builtin_amdgcn_make_buffer_rsrc( const_cast< double* >( MODE == APPLY_JACOBI ? A.rhs : A.src ), 0, A.bytes, 0x00020000 );
+   const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(
+       const_cast< double* >( ( MODE == APPLY_JACOBI && A.invdiag ) ? A.invdiag : A.src ), 0, A.bytes, 0x00020000 );
+
+   const int lane_off = lane * 8;
+   const int ym       = t.y0 - 1; // first row held per slice
+
+   // S[q][r]: slice z0-1+q, row ym+r (r = 0..NY+1), x = xb + lane.  q = 0..LZ+1.
+   double S[LZ + 2][NY + 2];
+   // wave-uniform element index of (xb, ym, z0-1+q) and row-0 length of that slice
+   int base = t.i0;
+   int Wq   = t.W0;
+
+   auto load_slice = [&]( auto qc, int base_q, int W_q ) {
+      constexpr int q  = decltype( qc )::value;
+      int           ix = base_q;
+#pragma unroll
+      for ( int r = 0; r < NY + 2; ++r )
+      {
+         // slice 0 is only ever a "down" slice (rows y0..y0+NY), the last one only an "up" slice (rows ym..)
+         const bool need = ( q == 0 ) ? ( r >= 1 ) : ( q == LZ + 1 ? ( r <= NY ) : true );
+         if ( need )
+            S[q][r] = zm_load< LD_AUX >( rs, ix * 8 + lane_off );
+         ix += W_q - ( ym + r ); // next row of the same slice
+      }
+   };
+
+   // prologue: slices 0, 1, 2
+   int baseq[LZ + 2], Wqs[LZ + 2];
+#pragma unroll
+   for ( int q = 0; q < LZ + 2; ++q )
+   {
+      baseq[q] = base;
+      Wqs[q]   = Wq;
+      base += tri( Wq ) - ym; // (x, ym, z) -> (x, ym, z+1)
+      Wq -= 1;
+   }
+   load_slice( std::integral_constant< int, 0 >{}, baseq[0], Wqs[0] );
+   load_slice( std::integral_constant< int, 1 >{}, baseq[1], Wqs[1] );
+   load_slice( std::integral_constant< int, 2 >{}, baseq[2], Wqs[2] );
+
+   const double* w       = A.st.w;
+   const double  invc    = 1.0 / w[7];
+   const bool    lane_ok = lane >= 1 && lane <= 62;
+   const int     x       = t.xb + lane;
+
+   auto step = [&]( auto sc ) {
+      constexpr int s = decltype( sc )::value; // output slice z0 + s, centre q = s+1
+      constexpr int q = s + 1;
+      if constexpr ( q + 2 <= LZ + 1 )
+         load_slice( std::integral_constant< int, q + 2 >{}, baseq[q + 2], Wqs[q + 2] );
+
+      const int W  = Wqs[q];
+      int       io = baseq[q] + ( W - ym ); // (xb, y0, z)
+#pragma unroll
+      for ( int j = 0; j < NY; ++j )
+      {
+         const int    R  = W - ( t.y0 + j );
+         const double am = S[q][j], a0 = S[q][j + 1], ap = S[q][j + 2];
+         const double um = S[q + 1][j], u0 = S[q + 1][j + 1];
+         const double d0 = S[q - 1][j + 1], dp = S[q - 1][j + 2];
+         double       acc;
+         if constexpr ( ( ABL & 8 ) != 0 )
+            acc = am + a0 + ap + um + u0 + d0 + dp;
+         else
+         {
+         acc = w[6] * zm_lane_minus_1( a0 );           // W
+         acc = fma( w[3], dp, acc );                   // BN
+         acc = fma( w[10], ap, acc );                  // N
+         acc = fma( w[5], zm_lane_plus_1( am ), acc ); // SE
+         acc = fma( w[12], zm_lane_plus_1( um ), acc ); // TSE
+         acc = fma( w[1], zm_lane_plus_1( d0 ), acc ); // BE
+         acc = fma( w[8], zm_lane_plus_1( a0 ), acc ); // E
+         acc = fma( w[13], zm_lane_minus_1( u0 ), acc ); // TW
+         acc = fma( w[2], zm_lane_minus_1( dp ), acc ); // BNW
+         acc = fma( w[9], zm_lane_minus_1( ap ), acc ); // NW
+         acc = fma( w[4], am, acc );                   // S
+         acc = fma( w[11], um, acc );                  // TS
+         acc = fma( w[0], d0, acc );                   // BC
+         acc = fma( w[7], a0, acc );                   // C
+         acc = fma( w[14], u0, acc );                  // TC
+         }
+
+         const bool active = lane_ok && x <= R - 2 && s < t.nz;
+         const int  off    = io * 8 + lane_off;
+         double     out;
+         if ( MODE == APPLY_REPLACE )
+            out = acc;
+         else if ( MODE == APPLY_ADD )
+            out = acc + zm_load( rd, off );
+         else
+         {
+            const double rv = zm_load( rr, off );
+            const double iv = A.invdiag ? zm_load( ri, off ) : invc;
+            out             = a0 + A.relax * ( iv * ( rv - acc ) );
+         }
+         if constexpr ( ( ABL & 4 ) != 0 )
+         {
+            if ( out == 1.2345e-300 )
+               zm_store< 0 >( rd, off, out );
+         }
+         else
+            zm_store< ST_AUX >( rd, active ? off : -8, out );
+         io += R;
+      }
+   };
+
+   // fully unrolled march
+   [&]< int... Is >( std::integer_sequence< int, Is... > ) { ( step( std::integral_constant< int, Is >{} ), ... ); }
+   ( std::make_integer_sequence< int, LZ >{} );
+}
+
+// host: bricks of NY rows x 62 outputs x LZ slices, ordered z-chunk, y-chunk, x-chunk (memory order)
+inline void build_brick_tasks( int level, int NY, int LZ, std::vector< BrickTask >& out )
+{
+   const int N = ( 1 << level ) + 1;
+   out.clear();
+   for ( int z0 = 1; z0 <= N - 4; z0 += LZ )
+   {
+      const int W = N - z0; // row-0 length of the first output slice
+      for ( int y0 = 1; y0 <= W - 3; y0 += NY )
+      {
+         const int xmax = W - y0 - 2; // last interior x of the brick's longest row
+         for ( int x0 = 1; x0 <= xmax; x0 += 62 )
+         {
+            BrickTask t{};
+            t.xb = x0 - 1;
+            t.y0 = y0;
+            t.W0 = W + 1;
+            t.i0 = slice_start( N, z0 - 1 ) + row_start( W + 1, y0 - 1 ) + t.xb;
+            t.nz = std::min( LZ, N - 4 - z0 + 1 );
+            out.push_back( t );
+         }
+      }
+   }
+}
+
+} // namespace hyteg_hip

@@ -1,5 +1,6 @@
 // C-ABI entry points: constant-stencil apply and fused weighted Jacobi on one macro-cell.
 #include "kernels_apply.hpp"
+#include "kernels_apply_zmarch.hpp"
 
 using namespace hyteg_hip;
 
@@ -7,10 +8,53 @@ namespace {
 
 constexpr int kTile = 1024;
 
+// brick shape of the z-march kernel: rows x slices per wave (sweep on MI355X level 8: (2..4) x (4..8) all within 2 %)
+constexpr int kBrickNY = 4;
+constexpr int kBrickLZ = 4;
+
+template < int MODE >
+int launch_zmarch( double* dst, const double* src, const double* rhs, const double* invdiag, int level, const double* w,
+                   double relax, hipStream_t stream )
+{
+   BrickTable bt;
+   int        rc = get_bricks( level, kBrickNY, kBrickLZ, &bt );
+   if ( rc != HYTEG_HIP_OK )
+      return rc;
+   if ( bt.count == 0 )
+      return HYTEG_HIP_OK;
+   ZMarchArgs A{};
+   A.dst     = dst;
+   A.src     = src;
+   A.rhs     = rhs;
+   A.invdiag = invdiag;
+   A.tasks   = bt.dev;
+   A.ntasks  = bt.count;
+   A.bytes   = (unsigned) ( tet64( ( 1 << level ) + 1 ) * 8 );
+   A.relax   = relax;
+   for ( int k = 0; k < 15; ++k )
+      A.st.w[k] = w[k];
+   int nblocks = ( bt.count + kZMarchWavesPerBlock - 1 ) / kZMarchWavesPerBlock;
+   nblocks     = ( nblocks + 7 ) & ~7;
+   A.xcd_chunk = nblocks / 8;
+   hipLaunchKernelGGL( ( p1_apply_zmarch_kernel< MODE, kBrickNY, kBrickLZ > ),
+                       dim3( nblocks ),
+                       dim3( 64 * kZMarchWavesPerBlock ),
+                       0,
+                       stream,
+                       A );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
 template < int MODE >
 int launch_apply( double* dst, const double* src, const double* rhs, const double* invdiag, int level, const double* w,
                   double relax, hipStream_t stream )
 {
+   // z-march register kernel whenever byte offsets fit the 32-bit buffer addressing (level <= 10);
+   // the LDS-tiled kernel (pointer addressing) covers level 11
+   if ( tet64( ( 1 << level ) + 1 ) * 8 < ( (int64_t) 1 << 31 ) )
+      return launch_zmarch< MODE >( dst, src, rhs, invdiag, level, w, relax, stream );
+
    TileTable tt;
    int       rc = get_tiles( level, TILES_INNER, kTile, &tt );
    if ( rc != HYTEG_HIP_OK )

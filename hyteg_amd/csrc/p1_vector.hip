@@ -255,6 +255,10 @@ HYTEG_HIP_API int hyteg_hip_prepare_level( int level )
    int       rc = get_tiles( level, TILES_INNER, kTile, &tt );
    if ( rc != HYTEG_HIP_OK )
       return rc;
-   return get_tiles( level, TILES_FULL, kTile, &tt );
+   rc = get_tiles( level, TILES_FULL, kTile, &tt );
+   if ( rc != HYTEG_HIP_OK )
+      return rc;
+   BrickTable bt;
+   return get_bricks( level, 4, 4, &bt );
 }
 }

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "kernels_apply_zmarch.hpp"
 
 namespace hyteg_hip {
 
@@ -90,6 +91,36 @@ int get_tiles( int level, TileKind kind, int capacity, TileTable* out )
    }
    cache[key] = tt;
    *out       = tt;
+   return HYTEG_HIP_OK;
+}
+
+int get_bricks( int level, int NY, int LZ, BrickTable* out )
+{
+   static std::mutex                                             mtx;
+   static std::map< std::tuple< int, int, int, int >, BrickTable > cache;
+   int                                                           dev = 0;
+   HH_CHECK_HIP( hipGetDevice( &dev ) );
+   std::lock_guard< std::mutex > lock( mtx );
+   auto                          key = std::make_tuple( dev, level, NY, LZ );
+   auto                          it  = cache.find( key );
+   if ( it != cache.end() )
+   {
+      *out = it->second;
+      return HYTEG_HIP_OK;
+   }
+   std::vector< BrickTask > host;
+   build_brick_tasks( level, NY, LZ, host );
+   BrickTable bt;
+   bt.count = (int) host.size();
+   if ( bt.count > 0 )
+   {
+      void* p = nullptr;
+      HH_CHECK_HIP( hipMalloc( &p, host.size() * sizeof( BrickTask ) ) );
+      HH_CHECK_HIP( hipMemcpy( p, host.data(), host.size() * sizeof( BrickTask ), hipMemcpyHostToDevice ) );
+      bt.dev = static_cast< const BrickTask* >( p );
+   }
+   cache[key] = bt;
+   *out       = bt;
    return HYTEG_HIP_OK;
 }
 
