@@ -44,7 +44,17 @@ SIGNATURES = {
     "hyteg_hip_p1_dot_cell": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "hyteg_hip_p1_restrict_cell": (_i, [_vp, _vp, _i, _dp, _vp]),
     "hyteg_hip_p1_prolongate_cell": (_i, [_vp, _vp, _i, _dp, _i, _vp]),
+    "hyteg_hip_p1_apply_cell_boundary": (_i, [_vp, _vp, _i, _dp, C.c_uint, _i, _vp]),
+    "hyteg_hip_p1_vector_cell_masked": (_i, [_i, _vp, _i, C.POINTER(_vp), _dp, _i, C.c_uint, _vp]),
+    "hyteg_hip_p1_set_cell_masked": (_i, [_vp, _d, _i, C.c_uint, _vp]),
+    "hyteg_hip_p1_dot_cell_masked": (_i, [_vp, _vp, _i, C.c_uint, _vp, _vp, _vp]),
+    "hyteg_hip_p1_restrict_cell_masked": (_i, [_vp, _vp, _i, _dp, C.c_uint, _vp]),
+    "hyteg_hip_p1_prolongate_cell_masked": (_i, [_vp, _vp, _i, _dp, C.c_uint, _vp]),
+    "hyteg_hip_sum_shared": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "hyteg_hip_copy_shared": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "hyteg_hip_gather_entries": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
 }
+MASK_INNER, MASK_SHELL, MASK_ALL = 1 << 14, 0x3FFF, 0x7FFF
 
 
 class HytegHipError(RuntimeError):
@@ -151,3 +161,41 @@ def p1_restrict_cell(coarse, fine, coarse_level, nnc, stream=0):
 def p1_prolongate_cell(coarse, fine, coarse_level, nnc, update=REPLACE, stream=0):
     check(lib().hyteg_hip_p1_prolongate_cell(coarse, fine, coarse_level, _f14(nnc), update, stream),
           "p1_prolongate_cell")
+
+
+def p1_apply_cell_boundary(dst, src, level, w_slots, mask=MASK_SHELL, update=REPLACE, stream=0):
+    flat = [float(v) for row in w_slots for v in row]
+    arr = (C.c_double * 210)(*flat)
+    check(lib().hyteg_hip_p1_apply_cell_boundary(dst, src, level, arr, mask, update, stream), "p1_apply_cell_boundary")
+
+
+def p1_vector_cell_masked(op, dst, scalars, srcs, level, mask, stream=0):
+    sc = _scal(scalars) if scalars is not None else None
+    check(lib().hyteg_hip_p1_vector_cell_masked(op, dst, len(srcs), _ptrs(srcs), sc, level, mask, stream),
+          "p1_vector_cell_masked")
+
+
+def p1_set_cell_masked(dst, value, level, mask, stream=0):
+    check(lib().hyteg_hip_p1_set_cell_masked(dst, float(value), level, mask, stream), "p1_set_cell_masked")
+
+
+def p1_dot_cell_masked(a, b, level, mask, result_dev, workspace_dev, stream=0):
+    check(lib().hyteg_hip_p1_dot_cell_masked(a, b, level, mask, result_dev, workspace_dev, stream), "p1_dot_cell_masked")
+
+
+def p1_restrict_cell_masked(coarse, fine, coarse_level, nnc, mask, stream=0):
+    check(lib().hyteg_hip_p1_restrict_cell_masked(coarse, fine, coarse_level, _f14(nnc), mask, stream),
+          "p1_restrict_cell_masked")
+
+
+def p1_prolongate_cell_masked(coarse, fine, coarse_level, nnc, mask, stream=0):
+    check(lib().hyteg_hip_p1_prolongate_cell_masked(coarse, fine, coarse_level, _f14(nnc), mask, stream),
+          "p1_prolongate_cell_masked")
+
+
+def sum_shared(bases, group_ptr, entry_buf, entry_off, ngroups, n_writable, stream=0):
+    check(lib().hyteg_hip_sum_shared(bases, group_ptr, entry_buf, entry_off, ngroups, n_writable, stream), "sum_shared")
+
+
+def gather_entries(out, bases, entry_buf, entry_off, n, stream=0):
+    check(lib().hyteg_hip_gather_entries(out, bases, entry_buf, entry_off, n, stream), "gather_entries")

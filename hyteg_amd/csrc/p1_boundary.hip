@@ -1,0 +1,452 @@
+// C-ABI entry points for the cell-centric multi-cell model: kernels on the boundary shell of a macro-cell
+// (points on its macro-faces/edges/vertices), masked vector kernels, masked dot, and the additive exchange of
+// shared points.  The shell has O(4^L) points, so these kernels are latency- rather than bandwidth-relevant.
+#include "common.hpp"
+
+using namespace hyteg_hip;
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct Slots14x15
+{
+   double w[14][15];
+};
+
+__constant__ int kOffs[15][3] = { { 0, 0, -1 }, { 1, 0, -1 }, { -1, 1, -1 }, { 0, 1, -1 }, { 0, -1, 0 },
+                                  { 1, -1, 0 }, { -1, 0, 0 }, { 0, 0, 0 },   { 1, 0, 0 },  { -1, 1, 0 },
+                                  { 0, 1, 0 },  { 0, -1, 1 }, { 1, -1, 1 },  { -1, 0, 1 }, { 0, 0, 1 } };
+
+// slot of the macro-primitive a point lies on (see p1_transfer.hip / MacroCellIndexing.cpp:36-91), -1 interior
+__device__ inline int shell_slot( int N, int x, int y, int z )
+{
+   const int f0 = ( z == 0 ), f1 = ( y == 0 ), f2 = ( x == 0 ), f3 = ( x + y + z == N - 1 );
+   const int cnt = f0 + f1 + f2 + f3;
+   if ( cnt == 0 )
+      return -1;
+   if ( cnt == 1 )
+      return 6 + ( f0 ? 0 : f1 ? 1 : f2 ? 2 : 3 );
+   if ( cnt == 2 )
+   {
+      if ( f0 )
+         return f1 ? 0 : ( f2 ? 1 : 2 );
+      if ( f1 )
+         return f2 ? 3 : 4;
+      return 5;
+   }
+   if ( f0 && f1 && f2 )
+      return 10;
+   if ( f0 && f1 && f3 )
+      return 11;
+   if ( f0 && f2 && f3 )
+      return 12;
+   return 13;
+}
+
+// Enumerates every shell point exactly once: q in [0, 4 tri(N)) -> (x,y,z,slot); returns false for the
+// duplicates (a point on an edge/vertex is visited through its lowest-numbered face only) and padding.
+__device__ inline bool shell_point( int N, int q, int& x, int& y, int& z, int& slot )
+{
+   const int T = tri( N );
+   if ( q >= 4 * T )
+      return false;
+   const int f = q / T, r = q - f * T;
+   const int j = row_of( N, r );
+   const int i = r - row_start( N, j );
+   switch ( f )
+   {
+   case 0:
+      x = i, y = j, z = 0;
+      break;
+   case 1:
+      x = i, y = 0, z = j;
+      break;
+   case 2:
+      x = 0, y = i, z = j;
+      break;
+   default:
+      x = i, y = j, z = N - 1 - i - j;
+      break;
+   }
+   const int lowest = ( z == 0 ) ? 0 : ( y == 0 ) ? 1 : ( x == 0 ) ? 2 : 3;
+   if ( lowest != f )
+      return false;
+   slot = shell_slot( N, x, y, z );
+   return true;
+}
+
+__global__ __launch_bounds__( kThreads ) void p1_apply_shell_kernel( double* __restrict__ dst,
+                                                                      const double* __restrict__ src,
+                                                                      int              N,
+                                                                      unsigned         mask,
+                                                                      int              update,
+                                                                      const Slots14x15 S )
+{
+   const int q = blockIdx.x * kThreads + threadIdx.x;
+   int       x, y, z, slot;
+   if ( !shell_point( N, q, x, y, z, slot ) || !( ( mask >> slot ) & 1u ) )
+      return;
+   double acc = 0.0;
+#pragma unroll
+   for ( int k = 0; k < 15; ++k )
+   {
+      const int nx = x + kOffs[k][0], ny = y + kOffs[k][1], nz = z + kOffs[k][2];
+      if ( nx < 0 || ny < 0 || nz < 0 || nx + ny + nz > N - 1 )
+         continue;
+      acc = fma( S.w[slot][k], src[cell_index( N, nx, ny, nz )], acc );
+   }
+   const int i = cell_index( N, x, y, z );
+   dst[i]      = update == HYTEG_HIP_ADD ? acc + dst[i] : acc;
+}
+
+struct VecArgsM
+{
+   double*       dst;
+   const double* src[HYTEG_HIP_MAX_SRCS];
+   double        c[HYTEG_HIP_MAX_SRCS];
+   int           N;
+   int           nsrc;
+   unsigned      mask;
+   int           op; // 0 assign, 1 add, 2 mult, 3 set constant (c[0])
+};
+
+__global__ __launch_bounds__( kThreads ) void p1_vector_shell_kernel( const VecArgsM A )
+{
+   const int q = blockIdx.x * kThreads + threadIdx.x;
+   int       x, y, z, slot;
+   if ( !shell_point( A.N, q, x, y, z, slot ) || !( ( A.mask >> slot ) & 1u ) )
+      return;
+   const int i = cell_index( A.N, x, y, z );
+   double    tmp;
+   if ( A.op == 3 )
+      tmp = A.c[0];
+   else if ( A.op == 2 )
+   {
+      tmp = A.src[0][i];
+      for ( int k = 1; k < A.nsrc; ++k )
+         tmp *= A.src[k][i];
+   }
+   else
+   {
+      tmp = A.c[0] * A.src[0][i];
+      for ( int k = 1; k < A.nsrc; ++k )
+         tmp += A.c[k] * A.src[k][i];
+      if ( A.op == 1 )
+         tmp = A.dst[i] + tmp;
+   }
+   A.dst[i] = tmp;
+}
+
+__global__ __launch_bounds__( kThreads ) void p1_set_inner_kernel( double* dst, double value, const Tile* tiles, int ntiles, int N )
+{
+   const int t = blockIdx.x;
+   if ( t >= ntiles )
+      return;
+   const Tile tl = tiles[t];
+   const int  W = N - tl.z, s0 = slice_start( N, tl.z );
+   for ( int e = threadIdx.x; e < tl.cnt; e += kThreads )
+   {
+      const int i = tl.a + e, j = i - s0;
+      const int y = row_of( W, j ), x = j - row_start( W, y );
+      if ( x >= 1 && x <= W - y - 2 )
+         dst[i] = value;
+   }
+}
+
+__device__ inline double wave_sum( double v )
+{
+#pragma unroll
+   for ( int off = 32; off > 0; off >>= 1 )
+      v += __shfl_down( v, off, 64 );
+   return v;
+}
+
+// partial sums of a.b over the masked shell points; fixed point -> workgroup assignment (deterministic)
+__global__ __launch_bounds__( kThreads ) void p1_dot_shell_kernel( const double* __restrict__ a,
+                                                                    const double* __restrict__ b,
+                                                                    int      N,
+                                                                    unsigned mask,
+                                                                    int      npoints,
+                                                                    double*  partial )
+{
+   __shared__ double sh[kThreads / 64];
+   double            acc = 0.0;
+   for ( int q = blockIdx.x * kThreads + threadIdx.x; q < npoints; q += gridDim.x * kThreads )
+   {
+      int x, y, z, slot;
+      if ( shell_point( N, q, x, y, z, slot ) && ( ( mask >> slot ) & 1u ) )
+      {
+         const int i = cell_index( N, x, y, z );
+         acc         = fma( a[i], b[i], acc );
+      }
+   }
+   acc = wave_sum( acc );
+   if ( ( threadIdx.x & 63 ) == 0 )
+      sh[threadIdx.x >> 6] = acc;
+   __syncthreads();
+   if ( threadIdx.x == 0 )
+   {
+      double r = 0.0;
+      for ( int k = 0; k < kThreads / 64; ++k )
+         r += sh[k];
+      partial[blockIdx.x] = r;
+   }
+}
+
+__global__ __launch_bounds__( kThreads ) void zero_partials_kernel( double* p, int n )
+{
+   const int k = blockIdx.x * kThreads + threadIdx.x;
+   if ( k < n )
+      p[k] = 0.0;
+}
+
+__global__ __launch_bounds__( kThreads ) void sum_partials_kernel( const double* partial, int n, double* result )
+{
+   __shared__ double sh[kThreads / 64];
+   double            acc = 0.0;
+   for ( int k = threadIdx.x; k < n; k += kThreads )
+      acc += partial[k];
+   acc = wave_sum( acc );
+   if ( ( threadIdx.x & 63 ) == 0 )
+      sh[threadIdx.x >> 6] = acc;
+   __syncthreads();
+   if ( threadIdx.x == 0 )
+   {
+      double r = 0.0;
+      for ( int k = 0; k < kThreads / 64; ++k )
+         r += sh[k];
+      *result = r;
+   }
+}
+
+template < bool SUM >
+__global__ __launch_bounds__( kThreads ) void sum_shared_kernel( double* const* __restrict__ bases,
+                                                                  const int* __restrict__ group_ptr,
+                                                                  const int* __restrict__ entry_buf,
+                                                                  const int* __restrict__ entry_off,
+                                                                  int ngroups,
+                                                                  int n_writable )
+{
+   const int g = blockIdx.x * kThreads + threadIdx.x;
+   if ( g >= ngroups )
+      return;
+   const int lo = group_ptr[g], hi = group_ptr[g + 1];
+   double    s = 0.0;
+   for ( int e = lo; e < ( SUM ? hi : lo + 1 ); ++e )
+      s = ( e == lo ) ? bases[entry_buf[e]][entry_off[e]] : s + bases[entry_buf[e]][entry_off[e]];
+   for ( int e = lo; e < hi; ++e )
+      if ( entry_buf[e] < n_writable )
+         bases[entry_buf[e]][entry_off[e]] = s;
+}
+
+__global__ __launch_bounds__( kThreads ) void gather_entries_kernel( double* __restrict__ out,
+                                                                      double* const* __restrict__ bases,
+                                                                      const int* __restrict__ entry_buf,
+                                                                      const int* __restrict__ entry_off,
+                                                                      int n )
+{
+   const int k = blockIdx.x * kThreads + threadIdx.x;
+   if ( k < n )
+      out[k] = bases[entry_buf[k]][entry_off[k]];
+}
+
+inline bool shell_level_ok( int level ) { return level >= 0 && level <= HYTEG_HIP_MAX_LEVEL; }
+inline int  shell_blocks( int N ) { return ( 4 * tri( N ) + kThreads - 1 ) / kThreads; }
+
+} // namespace
+
+// implemented in p1_vector.hip / p1_transfer.hip
+namespace hyteg_hip {
+int launch_vec_inner( int op, double* dst, int nsrc, const double* const* srcs, const double* scalars, int level, hipStream_t stream );
+int launch_dot_inner_partial( const double* a, const double* b, int level, double* partial, int* nblocks, hipStream_t stream );
+} // namespace hyteg_hip
+
+extern "C" {
+
+HYTEG_HIP_API int hyteg_hip_p1_apply_cell_boundary( double*            dst,
+                                                    const double*      src,
+                                                    int                level,
+                                                    const double*      w_slots,
+                                                    unsigned           mask,
+                                                    int                update,
+                                                    hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( dst && src && w_slots, "p1_apply_cell_boundary: null pointer" );
+   HH_REQUIRE( shell_level_ok( level ), "p1_apply_cell_boundary: level out of range [0,11]" );
+   HH_REQUIRE( dst != src, "p1_apply_cell_boundary: src and dst must not alias" );
+   HH_REQUIRE( update == HYTEG_HIP_REPLACE || update == HYTEG_HIP_ADD, "p1_apply_cell_boundary: bad update type" );
+   if ( ( mask & HYTEG_HIP_MASK_SHELL ) == 0 )
+      return HYTEG_HIP_OK;
+   Slots14x15 S;
+   for ( int s = 0; s < 14; ++s )
+      for ( int k = 0; k < 15; ++k )
+         S.w[s][k] = w_slots[15 * s + k];
+   const int N = ( 1 << level ) + 1;
+   hipLaunchKernelGGL( p1_apply_shell_kernel, dim3( shell_blocks( N ) ), dim3( kThreads ), 0, as_stream( stream ), dst, src, N,
+                       mask & HYTEG_HIP_MASK_SHELL, update, S );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_p1_vector_cell_masked( int                  op,
+                                                   double*              dst,
+                                                   int                  nsrc,
+                                                   const double* const* srcs,
+                                                   const double*        scalars,
+                                                   int                  level,
+                                                   unsigned             mask,
+                                                   hyteg_hip_stream_t   stream )
+{
+   HH_REQUIRE( dst && srcs, "p1_vector_cell_masked: null pointer" );
+   HH_REQUIRE( op >= 0 && op <= 2, "p1_vector_cell_masked: op must be 0 (assign), 1 (add) or 2 (mult)" );
+   HH_REQUIRE( shell_level_ok( level ), "p1_vector_cell_masked: level out of range [0,11]" );
+   HH_REQUIRE( nsrc >= 1 && nsrc <= HYTEG_HIP_MAX_SRCS, "p1_vector_cell_masked: nsrc must be 1..HYTEG_HIP_MAX_SRCS" );
+   HH_REQUIRE( op == 2 || scalars != nullptr, "p1_vector_cell_masked: null scalars" );
+   for ( int k = 0; k < nsrc; ++k )
+      HH_REQUIRE( srcs[k] != nullptr, "p1_vector_cell_masked: null source pointer" );
+   if ( ( mask & HYTEG_HIP_MASK_INNER ) && level >= HYTEG_HIP_MIN_LEVEL )
+   {
+      int rc = launch_vec_inner( op, dst, nsrc, srcs, scalars, level, as_stream( stream ) );
+      if ( rc != HYTEG_HIP_OK )
+         return rc;
+   }
+   if ( mask & HYTEG_HIP_MASK_SHELL )
+   {
+      VecArgsM A{};
+      A.dst = dst;
+      for ( int k = 0; k < nsrc; ++k )
+      {
+         A.src[k] = srcs[k];
+         A.c[k]   = scalars ? scalars[k] : 1.0;
+      }
+      A.N    = ( 1 << level ) + 1;
+      A.nsrc = nsrc;
+      A.mask = mask & HYTEG_HIP_MASK_SHELL;
+      A.op   = op;
+      hipLaunchKernelGGL( p1_vector_shell_kernel, dim3( shell_blocks( A.N ) ), dim3( kThreads ), 0, as_stream( stream ), A );
+      HH_CHECK_HIP( hipGetLastError() );
+   }
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int
+    hyteg_hip_p1_set_cell_masked( double* dst, double value, int level, unsigned mask, hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( dst, "p1_set_cell_masked: null pointer" );
+   HH_REQUIRE( shell_level_ok( level ), "p1_set_cell_masked: level out of range [0,11]" );
+   const int N = ( 1 << level ) + 1;
+   if ( ( mask & HYTEG_HIP_MASK_INNER ) && level >= HYTEG_HIP_MIN_LEVEL )
+   {
+      TileTable tt;
+      int       rc = get_tiles( level, TILES_INNER, 1024, &tt );
+      if ( rc != HYTEG_HIP_OK )
+         return rc;
+      if ( tt.count > 0 )
+         hipLaunchKernelGGL( p1_set_inner_kernel, dim3( tt.count ), dim3( kThreads ), 0, as_stream( stream ), dst, value, tt.dev,
+                             tt.count, N );
+   }
+   if ( mask & HYTEG_HIP_MASK_SHELL )
+   {
+      VecArgsM A{};
+      A.dst  = dst;
+      A.c[0] = value;
+      A.N    = N;
+      A.nsrc = 0;
+      A.mask = mask & HYTEG_HIP_MASK_SHELL;
+      A.op   = 3;
+      hipLaunchKernelGGL( p1_vector_shell_kernel, dim3( shell_blocks( N ) ), dim3( kThreads ), 0, as_stream( stream ), A );
+   }
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_p1_dot_cell_masked( const double*      a,
+                                                const double*      b,
+                                                int                level,
+                                                unsigned           mask,
+                                                double*            result_dev,
+                                                void*              workspace_dev,
+                                                hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( a && b && result_dev && workspace_dev, "p1_dot_cell_masked: null pointer" );
+   HH_REQUIRE( shell_level_ok( level ), "p1_dot_cell_masked: level out of range [0,11]" );
+   double*   partial = static_cast< double* >( workspace_dev ); // [0,1024): interior, [1024,1024+256): shell
+   const int N       = ( 1 << level ) + 1;
+   int       n_inner = 0;
+   if ( ( mask & HYTEG_HIP_MASK_INNER ) && level >= HYTEG_HIP_MIN_LEVEL )
+   {
+      int rc = launch_dot_inner_partial( a, b, level, partial, &n_inner, as_stream( stream ) );
+      if ( rc != HYTEG_HIP_OK )
+         return rc;
+   }
+   int n_shell = 0;
+   if ( mask & HYTEG_HIP_MASK_SHELL )
+   {
+      const int npoints = 4 * tri( N );
+      n_shell           = ( npoints + kThreads - 1 ) / kThreads;
+      n_shell           = n_shell > 256 ? 256 : n_shell;
+      hipLaunchKernelGGL( p1_dot_shell_kernel, dim3( n_shell ), dim3( kThreads ), 0, as_stream( stream ), a, b, N,
+                          mask & HYTEG_HIP_MASK_SHELL, npoints, partial + n_inner );
+   }
+   if ( n_inner + n_shell == 0 )
+   {
+      hipLaunchKernelGGL( zero_partials_kernel, dim3( 1 ), dim3( kThreads ), 0, as_stream( stream ), result_dev, 1 );
+   }
+   else
+      hipLaunchKernelGGL( sum_partials_kernel, dim3( 1 ), dim3( kThreads ), 0, as_stream( stream ), partial, n_inner + n_shell,
+                          result_dev );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_sum_shared( double* const*     bases,
+                                        const int*         group_ptr,
+                                        const int*         entry_buf,
+                                        const int*         entry_off,
+                                        int                ngroups,
+                                        int                n_writable,
+                                        hyteg_hip_stream_t stream )
+{
+   if ( ngroups <= 0 )
+      return HYTEG_HIP_OK;
+   HH_REQUIRE( bases && group_ptr && entry_buf && entry_off, "sum_shared: null pointer" );
+   hipLaunchKernelGGL( sum_shared_kernel< true >, dim3( ( ngroups + kThreads - 1 ) / kThreads ), dim3( kThreads ), 0,
+                       as_stream( stream ), bases, group_ptr, entry_buf, entry_off, ngroups, n_writable );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_copy_shared( double* const*     bases,
+                                         const int*         group_ptr,
+                                         const int*         entry_buf,
+                                         const int*         entry_off,
+                                         int                ngroups,
+                                         int                n_writable,
+                                         hyteg_hip_stream_t stream )
+{
+   if ( ngroups <= 0 )
+      return HYTEG_HIP_OK;
+   HH_REQUIRE( bases && group_ptr && entry_buf && entry_off, "copy_shared: null pointer" );
+   hipLaunchKernelGGL( sum_shared_kernel< false >, dim3( ( ngroups + kThreads - 1 ) / kThreads ), dim3( kThreads ), 0,
+                       as_stream( stream ), bases, group_ptr, entry_buf, entry_off, ngroups, n_writable );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_gather_entries( double*            out,
+                                            double* const*     bases,
+                                            const int*         entry_buf,
+                                            const int*         entry_off,
+                                            int                n,
+                                            hyteg_hip_stream_t stream )
+{
+   if ( n <= 0 )
+      return HYTEG_HIP_OK;
+   HH_REQUIRE( out && bases && entry_buf && entry_off, "gather_entries: null pointer" );
+   hipLaunchKernelGGL( gather_entries_kernel, dim3( ( n + kThreads - 1 ) / kThreads ), dim3( kThreads ), 0, as_stream( stream ), out,
+                       bases, entry_buf, entry_off, n );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+}

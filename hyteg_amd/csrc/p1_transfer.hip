@@ -51,6 +51,7 @@ __global__ __launch_bounds__( kThreads ) void p1_restrict_kernel( double* __rest
                                                                    const Tile* tiles,
                                                                    int         ntiles,
                                                                    int         Nc,
+                                                                   unsigned    mask,
                                                                    const Nnc14 s )
 {
    const int t = blockIdx.x;
@@ -67,6 +68,11 @@ __global__ __launch_bounds__( kThreads ) void p1_restrict_kernel( double* __rest
       const int j = i - s0;
       const int y = row_of( Wc, j );
       const int x = j - row_start( Wc, y );
+      {
+         const int cs = prim_slot( Nc, x, y, z );
+         if ( !( ( mask >> ( cs < 0 ? 14 : cs ) ) & 1u ) )
+            continue;
+      }
       double    acc   = 0.0;
       bool      first = true;
 #pragma unroll
@@ -99,6 +105,7 @@ __global__ __launch_bounds__( kThreads ) void p1_prolongate_kernel( const double
                                                                      const Tile* tiles,
                                                                      int         ntiles,
                                                                      int         Nf,
+                                                                     unsigned    mask,
                                                                      const Nnc14 s )
 {
    const int t = blockIdx.x;
@@ -116,6 +123,8 @@ __global__ __launch_bounds__( kThreads ) void p1_prolongate_kernel( const double
       const int    y    = row_of( Wf, j );
       const int    x    = j - row_start( Wf, y );
       const int    slot = prim_slot( Nf, x, y, z );
+      if ( !( ( mask >> ( slot < 0 ? 14 : slot ) ) & 1u ) )
+         continue;
       const double sc   = slot < 0 ? 1.0 : s.inv[slot];
       const int    code = ( x & 1 ) | ( ( y & 1 ) << 1 ) | ( ( z & 1 ) << 2 );
       // Replace zeroes everything first; Add zeroes only the boundary shell (P1toP1LinearProlongation.cpp:214-238)
@@ -147,6 +156,16 @@ HYTEG_HIP_API int hyteg_hip_p1_restrict_cell( double*            coarse,
                                               const double*      nnc,
                                               hyteg_hip_stream_t stream )
 {
+   return hyteg_hip_p1_restrict_cell_masked( coarse, fine, coarse_level, nnc, HYTEG_HIP_MASK_ALL, stream );
+}
+
+HYTEG_HIP_API int hyteg_hip_p1_restrict_cell_masked( double*            coarse,
+                                                     const double*      fine,
+                                                     int                coarse_level,
+                                                     const double*      nnc,
+                                                     unsigned           mask,
+                                                     hyteg_hip_stream_t stream )
+{
    HH_REQUIRE( coarse && fine && nnc, "p1_restrict_cell: null pointer" );
    HH_REQUIRE( coarse_level >= 0 && coarse_level + 1 <= HYTEG_HIP_MAX_LEVEL, "p1_restrict_cell: level out of range" );
    Nnc14 s;
@@ -169,10 +188,14 @@ HYTEG_HIP_API int hyteg_hip_p1_restrict_cell( double*            coarse,
                        tt.dev,
                        tt.count,
                        ( 1 << coarse_level ) + 1,
+                       mask,
                        s );
    HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;
 }
+
+static int prolongate_impl( const double* coarse, double* fine, int coarse_level, const double* nnc, int update, unsigned mask,
+                            hyteg_hip_stream_t stream );
 
 HYTEG_HIP_API int hyteg_hip_p1_prolongate_cell( const double*      coarse,
                                                 double*            fine,
@@ -180,6 +203,22 @@ HYTEG_HIP_API int hyteg_hip_p1_prolongate_cell( const double*      coarse,
                                                 const double*      nnc,
                                                 int                update,
                                                 hyteg_hip_stream_t stream )
+{
+   return prolongate_impl( coarse, fine, coarse_level, nnc, update, HYTEG_HIP_MASK_ALL, stream );
+}
+
+HYTEG_HIP_API int hyteg_hip_p1_prolongate_cell_masked( const double*      coarse,
+                                                       double*            fine,
+                                                       int                coarse_level,
+                                                       const double*      nnc,
+                                                       unsigned           mask,
+                                                       hyteg_hip_stream_t stream )
+{
+   return prolongate_impl( coarse, fine, coarse_level, nnc, HYTEG_HIP_REPLACE, mask, stream );
+}
+
+static int prolongate_impl( const double* coarse, double* fine, int coarse_level, const double* nnc, int update, unsigned mask,
+                            hyteg_hip_stream_t stream )
 {
    HH_REQUIRE( coarse && fine && nnc, "p1_prolongate_cell: null pointer" );
    HH_REQUIRE( coarse_level >= 0 && coarse_level + 1 <= HYTEG_HIP_MAX_LEVEL, "p1_prolongate_cell: level out of range" );
@@ -206,6 +245,7 @@ HYTEG_HIP_API int hyteg_hip_p1_prolongate_cell( const double*      coarse,
                           tt.dev,
                           tt.count,
                           Nf,
+                          mask,
                           s );
    else
       hipLaunchKernelGGL( ( p1_prolongate_kernel< HYTEG_HIP_ADD > ),
@@ -218,6 +258,7 @@ HYTEG_HIP_API int hyteg_hip_p1_prolongate_cell( const double*      coarse,
                           tt.dev,
                           tt.count,
                           Nf,
+                          mask,
                           s );
    HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;

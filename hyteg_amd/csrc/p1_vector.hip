@@ -175,6 +175,30 @@ __global__ __launch_bounds__( kThreads ) void p1_dot_final_kernel( const double*
 
 } // namespace
 
+namespace hyteg_hip {
+int launch_vec_inner( int op, double* dst, int nsrc, const double* const* srcs, const double* scalars, int level, hipStream_t stream )
+{
+   if ( op == 0 )
+      return launch_vec< OP_ASSIGN >( dst, nsrc, srcs, scalars, level, stream );
+   if ( op == 1 )
+      return launch_vec< OP_ADD >( dst, nsrc, srcs, scalars, level, stream );
+   return launch_vec< OP_MULT >( dst, nsrc, srcs, nullptr, level, stream );
+}
+
+int launch_dot_inner_partial( const double* a, const double* b, int level, double* partial, int* nblocks, hipStream_t stream )
+{
+   TileTable tt;
+   int       rc = get_tiles( level, TILES_INNER, kTile, &tt );
+   if ( rc != HYTEG_HIP_OK )
+      return rc;
+   *nblocks = tt.count < kDotBlocks ? tt.count : kDotBlocks;
+   if ( *nblocks > 0 )
+      hipLaunchKernelGGL( p1_dot_partial_kernel, dim3( *nblocks ), dim3( kThreads ), 0, stream, a, b, tt.dev, tt.count,
+                          ( 1 << level ) + 1, partial );
+   return HYTEG_HIP_OK;
+}
+} // namespace hyteg_hip
+
 extern "C" {
 
 #define VEC_COMMON_CHECKS( name )                                                                          \
@@ -215,7 +239,7 @@ HYTEG_HIP_API int
    return launch_vec< OP_MULT >( dst, nsrc, srcs, nullptr, level, as_stream( stream ) );
 }
 
-HYTEG_HIP_API size_t hyteg_hip_dot_workspace_bytes( void ) { return kDotBlocks * sizeof( double ); }
+HYTEG_HIP_API size_t hyteg_hip_dot_workspace_bytes( void ) { return ( kDotBlocks + 256 ) * sizeof( double ); }
 
 HYTEG_HIP_API int hyteg_hip_p1_dot_cell( const double*      a,
                                          const double*      b,

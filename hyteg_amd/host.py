@@ -1,0 +1,321 @@
+"""ctypes binding of libhyteg_host.so (include/hyteg_host.h): the C facade of the C++ host layer
+(hyteg_amd/host/hyteg_host.hpp) that mirrors HyTeG's PrimitiveStorage / P1Function / P1ConstantLaplaceOperator /
+grid transfer / solver classes.  Used by the tests, bench.py and the torch.distributed driver; plumbing only."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+_LIB_PATH = _PKG / "lib" / "libhyteg_host.so"
+
+Inner, DirichletBoundary, NeumannBoundary, FreeslipBoundary, All, Boundary = 1, 2, 4, 8, 15, 14
+Replace, Add = 0, 1
+JACOBI, GAUSS_SEIDEL, SOR = 0, 1, 2
+
+_vp, _i, _d, _u = C.c_void_p, C.c_int, C.c_double, C.c_uint
+_ip, _dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+EXCHANGE_CB = C.CFUNCTYPE(None, _vp, _i, _i)
+ALLREDUCE_CB = C.CFUNCTYPE(None, _vp, _dp, _i)
+
+SIGNATURES = {
+    "hyteg_host_last_error": (C.c_char_p, []),
+    "hyteg_host_storage_from_gmsh": (_i, [C.c_char_p, _i, _i, C.POINTER(_vp)]),
+    "hyteg_host_storage_from_arrays": (_i, [_i, _dp, _i, _ip, _i, _i, C.POINTER(_vp)]),
+    "hyteg_host_storage_destroy": (_i, [_vp]),
+    "hyteg_host_storage_counts": (_i, [_vp, _ip]),
+    "hyteg_host_storage_local_cell": (_i, [_vp, _i, _ip, _dp, _dp]),
+    "hyteg_host_storage_mask": (_i, [_vp, _i, _i, _i, C.POINTER(_u)]),
+    "hyteg_host_storage_set_boundary_type": (_i, [_vp, _i]),
+    "hyteg_host_storage_set_stream": (_i, [_vp, _vp]),
+    "hyteg_host_storage_set_hooks": (_i, [_vp, EXCHANGE_CB, ALLREDUCE_CB, _vp]),
+    "hyteg_host_plan_sizes": (_i, [_vp, _i, _i, _ip]),
+    "hyteg_host_plan_export": (_i, [_vp, _i, _i, _ip, _ip, _ip, _ip, _ip, _ip, _ip, _ip]),
+    "hyteg_host_plan_register_buffers": (_i, [_vp, _i, _i, _vp, _vp]),
+    "hyteg_host_function_create": (_i, [_vp, C.c_char_p, _i, _i, C.POINTER(_vp)]),
+    "hyteg_host_function_destroy": (_i, [_vp]),
+    "hyteg_host_function_cell_pointer": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "hyteg_host_function_upload_cell": (_i, [_vp, _i, _i, _dp]),
+    "hyteg_host_function_download_cell": (_i, [_vp, _i, _i, _dp]),
+    "hyteg_host_function_interpolate_constant": (_i, [_vp, _d, _i, _i]),
+    "hyteg_host_function_assign": (_i, [_vp, _i, _dp, C.POINTER(_vp), _i, _i]),
+    "hyteg_host_function_add": (_i, [_vp, _i, _dp, C.POINTER(_vp), _i, _i]),
+    "hyteg_host_function_mult_elementwise": (_i, [_vp, _i, C.POINTER(_vp), _i, _i]),
+    "hyteg_host_function_dot": (_i, [_vp, _vp, _i, _i, _i, _dp]),
+    "hyteg_host_function_sum_shared": (_i, [_vp, _i, _i]),
+    "hyteg_host_function_sync_shared": (_i, [_vp, _i, _i]),
+    "hyteg_host_operator_create": (_i, [_vp, _i, _i, _i, C.POINTER(_vp)]),
+    "hyteg_host_operator_destroy": (_i, [_vp]),
+    "hyteg_host_operator_stencils": (_i, [_vp, _i, _i, _dp, _dp]),
+    "hyteg_host_operator_apply": (_i, [_vp, _vp, _vp, _i, _i, _i]),
+    "hyteg_host_operator_smooth_jac": (_i, [_vp, _vp, _vp, _vp, _d, _i, _i]),
+    "hyteg_host_operator_smooth_sor": (_i, [_vp, _vp, _vp, _d, _i, _i, _i]),
+    "hyteg_host_operator_compute_inverse_diagonal": (_i, [_vp]),
+    "hyteg_host_operator_inverse_diagonal": (_i, [_vp, C.POINTER(_vp)]),
+    "hyteg_host_restrict": (_i, [_vp, _i, _i]),
+    "hyteg_host_prolongate": (_i, [_vp, _i, _i]),
+    "hyteg_host_prolongate_and_add": (_i, [_vp, _i, _i]),
+    "hyteg_host_gmg_create": (_i, [_vp, _i, _i, _i, _d, _i, _i, _i, _i, _d, C.POINTER(_vp)]),
+    "hyteg_host_cg_create": (_i, [_vp, _i, _i, _i, _d, C.POINTER(_vp)]),
+    "hyteg_host_solver_solve": (_i, [_vp, _vp, _vp, _vp, _i]),
+    "hyteg_host_solver_destroy": (_i, [_vp]),
+}
+
+
+class HytegHostError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not _LIB_PATH.exists():
+            raise HytegHostError(f"{_LIB_PATH} not found: run __graft_entry__.build()")
+        # libhyteg_host.so depends on libhyteg_hip.so next to it (rpath $ORIGIN)
+        l = C.CDLL(str(_LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(l, name)
+            f.restype, f.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def _ck(rc, what):
+    if rc != 0:
+        raise HytegHostError(f"{what}: {lib().hyteg_host_last_error().decode(errors='replace')}")
+
+
+def cell_size(level: int) -> int:
+    n = (1 << level) + 1
+    return n * (n + 1) * (n + 2) // 6
+
+
+class Storage:
+    """hyteg::PrimitiveStorage"""
+
+    def __init__(self, handle):
+        self.h = handle
+        self._hooks = None
+        c = (C.c_int * 6)()
+        _ck(lib().hyteg_host_storage_counts(self.h, c), "storage_counts")
+        self.n_cells, self.n_faces, self.n_edges, self.n_vertices, self.n_local_cells, self.n_ranks = list(c)
+
+    @classmethod
+    def from_gmsh(cls, path, rank=0, nranks=1):
+        h = _vp()
+        _ck(lib().hyteg_host_storage_from_gmsh(str(path).encode(), rank, nranks, C.byref(h)), "storage_from_gmsh")
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, vertices, cells, rank=0, nranks=1):
+        v = np.ascontiguousarray(vertices, dtype=np.float64).reshape(-1, 3)
+        c = np.ascontiguousarray(cells, dtype=np.int32).reshape(-1, 4)
+        h = _vp()
+        _ck(lib().hyteg_host_storage_from_arrays(len(v), v.ctypes.data_as(_dp), len(c), c.ctypes.data_as(_ip), rank, nranks,
+                                                 C.byref(h)), "storage_from_arrays")
+        return cls(h)
+
+    @classmethod
+    def single_tet(cls, coords):
+        return cls.from_arrays(coords, [[0, 1, 2, 3]])
+
+    def local_cell(self, i):
+        gid = C.c_int()
+        co = np.empty(12)
+        nnc = np.empty(14)
+        _ck(lib().hyteg_host_storage_local_cell(self.h, i, C.byref(gid), co.ctypes.data_as(_dp), nnc.ctypes.data_as(_dp)),
+            "storage_local_cell")
+        return gid.value, co.reshape(4, 3), nnc
+
+    def mask(self, i, flag, owned=False):
+        m = _u()
+        _ck(lib().hyteg_host_storage_mask(self.h, i, flag, int(owned), C.byref(m)), "storage_mask")
+        return m.value
+
+    def set_boundary_type(self, t):
+        _ck(lib().hyteg_host_storage_set_boundary_type(self.h, t), "set_boundary_type")
+
+    def set_stream(self, stream):
+        _ck(lib().hyteg_host_storage_set_stream(self.h, stream), "set_stream")
+
+    def set_hooks(self, exchange, allreduce_sum):
+        ex = EXCHANGE_CB(lambda user, level, cls: exchange(level, cls))
+        ar = ALLREDUCE_CB(lambda user, values, n: allreduce_sum(values, n))
+        self._hooks = (ex, ar)  # keep alive
+        _ck(lib().hyteg_host_storage_set_hooks(self.h, ex, ar, None), "set_hooks")
+
+    def plan(self, level, cls):
+        s = (C.c_int * 5)()
+        _ck(lib().hyteg_host_plan_sizes(self.h, level, cls, s), "plan_sizes")
+        ng, ne, npeer, ts, tr = list(s)
+        a = lambda n: np.zeros(max(n, 1), dtype=np.int32)  # noqa: E731
+        gp, eb, eo, peers, sc, rc, sb, so = a(ng + 1), a(ne), a(ne), a(npeer), a(npeer), a(npeer), a(ts), a(ts)
+        p = lambda x: x.ctypes.data_as(_ip)  # noqa: E731
+        _ck(lib().hyteg_host_plan_export(self.h, level, cls, p(gp), p(eb), p(eo), p(peers), p(sc), p(rc), p(sb), p(so)),
+            "plan_export")
+        return dict(ngroups=ng, group_ptr=gp[:ng + 1], entry_buf=eb[:ne], entry_off=eo[:ne], peers=peers[:npeer],
+                    send_count=sc[:npeer], recv_count=rc[:npeer], send_buf=sb[:ts], send_off=so[:ts], total_send=ts,
+                    total_recv=tr)
+
+    def register_comm_buffers(self, level, cls, send_ptr, recv_ptr):
+        _ck(lib().hyteg_host_plan_register_buffers(self.h, level, cls, send_ptr, recv_ptr), "plan_register_buffers")
+
+    def close(self):
+        if self.h:
+            lib().hyteg_host_storage_destroy(self.h)
+            self.h = None
+
+
+class P1Function:
+    """hyteg::P1Function<double>"""
+
+    def __init__(self, storage: Storage, name: str, min_level: int, max_level: int, _borrowed=None):
+        self.storage, self.min_level, self.max_level = storage, min_level, max_level
+        self._borrowed = _borrowed is not None
+        if _borrowed is not None:
+            self.h = _borrowed
+        else:
+            h = _vp()
+            _ck(lib().hyteg_host_function_create(storage.h, name.encode(), min_level, max_level, C.byref(h)), "function_create")
+            self.h = h
+
+    def cell_pointer(self, c, level):
+        p = _vp()
+        _ck(lib().hyteg_host_function_cell_pointer(self.h, c, level, C.byref(p)), "cell_pointer")
+        return p.value
+
+    def upload_cell(self, c, level, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        assert a.size == cell_size(level)
+        _ck(lib().hyteg_host_function_upload_cell(self.h, c, level, a.ctypes.data_as(_dp)), "upload_cell")
+
+    def download_cell(self, c, level):
+        a = np.empty(cell_size(level))
+        _ck(lib().hyteg_host_function_download_cell(self.h, c, level, a.ctypes.data_as(_dp)), "download_cell")
+        return a
+
+    def interpolate(self, value, level, flag=All):
+        _ck(lib().hyteg_host_function_interpolate_constant(self.h, float(value), level, flag), "interpolate")
+
+    def _vec(self, fn, scalars, funcs, level, flag):
+        n = len(funcs)
+        hs = (_vp * n)(*[f.h for f in funcs])
+        if scalars is None:
+            _ck(fn(self.h, n, hs, level, flag), "vector op")
+        else:
+            sc = (C.c_double * n)(*[float(s) for s in scalars])
+            _ck(fn(self.h, n, sc, hs, level, flag), "vector op")
+
+    def assign(self, scalars, funcs, level, flag=All):
+        self._vec(lib().hyteg_host_function_assign, scalars, funcs, level, flag)
+
+    def add(self, scalars, funcs, level, flag=All):
+        self._vec(lib().hyteg_host_function_add, scalars, funcs, level, flag)
+
+    def mult_elementwise(self, funcs, level, flag=All):
+        self._vec(lib().hyteg_host_function_mult_elementwise, None, funcs, level, flag)
+
+    def dot(self, other, level, flag=All, global_=True):
+        r = C.c_double()
+        _ck(lib().hyteg_host_function_dot(self.h, other.h, level, flag, int(global_), C.byref(r)), "dot")
+        return r.value
+
+    def sum_shared(self, level, flag=All):
+        _ck(lib().hyteg_host_function_sum_shared(self.h, level, flag), "sum_shared")
+
+    def sync_shared(self, level, flag=All):
+        _ck(lib().hyteg_host_function_sync_shared(self.h, level, flag), "sync_shared")
+
+    def close(self):
+        if self.h and not self._borrowed:
+            lib().hyteg_host_function_destroy(self.h)
+        self.h = None
+
+
+class P1ConstantOperator:
+    """hyteg::P1ConstantLaplaceOperator (form=0) / P1ConstantMassOperator (form=1)"""
+
+    def __init__(self, storage: Storage, min_level: int, max_level: int, form: int = 0):
+        self.storage = storage
+        h = _vp()
+        _ck(lib().hyteg_host_operator_create(storage.h, min_level, max_level, form, C.byref(h)), "operator_create")
+        self.h = h
+
+    def stencils(self, global_cell, level):
+        inner, slots = np.empty(15), np.empty(210)
+        _ck(lib().hyteg_host_operator_stencils(self.h, global_cell, level, inner.ctypes.data_as(_dp), slots.ctypes.data_as(_dp)),
+            "operator_stencils")
+        return inner, slots.reshape(14, 15)
+
+    def apply(self, src, dst, level, flag, update=Replace):
+        _ck(lib().hyteg_host_operator_apply(self.h, src.h, dst.h, level, flag, update), "apply")
+
+    def smooth_jac(self, dst, rhs, src, relax, level, flag):
+        _ck(lib().hyteg_host_operator_smooth_jac(self.h, dst.h, rhs.h, src.h, float(relax), level, flag), "smooth_jac")
+
+    def smooth_sor(self, dst, rhs, relax, level, flag, backwards=False):
+        _ck(lib().hyteg_host_operator_smooth_sor(self.h, dst.h, rhs.h, float(relax), level, flag, int(backwards)), "smooth_sor")
+
+    def smooth_gs(self, dst, rhs, level, flag):
+        self.smooth_sor(dst, rhs, 1.0, level, flag)
+
+    def compute_inverse_diagonal(self):
+        _ck(lib().hyteg_host_operator_compute_inverse_diagonal(self.h), "computeInverseDiagonalOperatorValues")
+
+    def inverse_diagonal(self, min_level, max_level):
+        h = _vp()
+        _ck(lib().hyteg_host_operator_inverse_diagonal(self.h, C.byref(h)), "getInverseDiagonalValues")
+        return P1Function(self.storage, "invdiag", min_level, max_level, _borrowed=h)
+
+    def close(self):
+        if self.h:
+            lib().hyteg_host_operator_destroy(self.h)
+            self.h = None
+
+
+def restrict(f: P1Function, source_level, flag):
+    _ck(lib().hyteg_host_restrict(f.h, source_level, flag), "restrict")
+
+
+def prolongate(f: P1Function, source_level, flag):
+    _ck(lib().hyteg_host_prolongate(f.h, source_level, flag), "prolongate")
+
+
+def prolongate_and_add(f: P1Function, source_level, flag):
+    _ck(lib().hyteg_host_prolongate_and_add(f.h, source_level, flag), "prolongateAndAdd")
+
+
+class Solver:
+    def __init__(self, handle):
+        self.h = handle
+
+    @classmethod
+    def gmg(cls, storage, min_level, max_level, smoother=JACOBI, relax=2.0 / 3.0, pre=3, post=3, wcycle=False, cg_max_iter=1000,
+            cg_tol=1e-14):
+        h = _vp()
+        _ck(lib().hyteg_host_gmg_create(storage.h, min_level, max_level, smoother, float(relax), pre, post, int(wcycle),
+                                        cg_max_iter, float(cg_tol), C.byref(h)), "gmg_create")
+        return cls(h)
+
+    @classmethod
+    def cg(cls, storage, min_level, max_level, max_iter=1000, tol=1e-14):
+        h = _vp()
+        _ck(lib().hyteg_host_cg_create(storage.h, min_level, max_level, max_iter, float(tol), C.byref(h)), "cg_create")
+        return cls(h)
+
+    def solve(self, laplace: P1ConstantOperator, x: P1Function, b: P1Function, level: int):
+        _ck(lib().hyteg_host_solver_solve(self.h, laplace.h, x.h, b.h, level), "solve")
+
+    def close(self):
+        if self.h:
+            lib().hyteg_host_solver_destroy(self.h)
+            self.h = None

@@ -1,0 +1,330 @@
+// C facade of the C++ host layer (include/hyteg_host.h).  Exceptions become return codes.
+#include "hyteg_host.hpp"
+
+#include "../../include/hyteg_host.h"
+
+using namespace hyteg;
+
+namespace {
+thread_local std::string g_err;
+
+struct StorageH
+{
+   std::shared_ptr< PrimitiveStorage > p;
+};
+struct FunctionH
+{
+   std::shared_ptr< P1Function< double > > p;
+};
+struct OperatorH
+{
+   int                                          form;
+   std::shared_ptr< P1ConstantLaplaceOperator > laplace;
+   std::shared_ptr< P1ConstantMassOperator >    mass;
+   FunctionH                                    invDiag; // borrowed view
+};
+struct SolverH
+{
+   std::shared_ptr< Solver< P1ConstantLaplaceOperator > > p;
+};
+
+template < typename F >
+int guarded( F&& fn )
+{
+   try
+   {
+      fn();
+      return 0;
+   } catch ( const std::exception& e )
+   {
+      g_err = e.what();
+      return 1;
+   } catch ( ... )
+   {
+      g_err = "unknown error";
+      return 1;
+   }
+}
+PrimitiveStorage&      S( hh_storage_t s ) { return *static_cast< StorageH* >( s )->p; }
+P1Function< double >&  F( hh_function_t f ) { return *static_cast< FunctionH* >( f )->p; }
+std::vector< std::reference_wrapper< const P1Function< double > > > refs( int n, const hh_function_t* fs )
+{
+   std::vector< std::reference_wrapper< const P1Function< double > > > r;
+   for ( int i = 0; i < n; ++i )
+      r.push_back( std::cref( F( fs[i] ) ) );
+   return r;
+}
+} // namespace
+
+extern "C" {
+
+HYTEG_HOST_API const char* hyteg_host_last_error( void ) { return g_err.c_str(); }
+
+HYTEG_HOST_API int hyteg_host_storage_from_gmsh( const char* path, int rank, int nranks, hh_storage_t* out )
+{
+   return guarded( [&] { *out = new StorageH{ std::make_shared< PrimitiveStorage >( MeshInfo::fromGmshFile( path ), rank, nranks ) }; } );
+}
+HYTEG_HOST_API int hyteg_host_storage_from_arrays( int nv, const double* xyz, int nc, const int* cells, int rank, int nranks, hh_storage_t* out )
+{
+   return guarded( [&] { *out = new StorageH{ std::make_shared< PrimitiveStorage >( MeshInfo::fromArrays( nv, xyz, nc, cells ), rank, nranks ) }; } );
+}
+HYTEG_HOST_API int hyteg_host_storage_destroy( hh_storage_t s )
+{
+   return guarded( [&] { delete static_cast< StorageH* >( s ); } );
+}
+HYTEG_HOST_API int hyteg_host_storage_counts( hh_storage_t s, int* c )
+{
+   return guarded( [&] {
+      auto& st = S( s );
+      c[0]     = (int) st.getCells().size();
+      c[1]     = (int) st.getFaces().size();
+      c[2]     = (int) st.getEdges().size();
+      c[3]     = (int) st.getVertices().size();
+      c[4]     = (int) st.getNumberOfLocalCells();
+      c[5]     = st.numRanks();
+   } );
+}
+HYTEG_HOST_API int hyteg_host_storage_local_cell( hh_storage_t s, int li, int* gid, double* coords12, double* nnc14 )
+{
+   return guarded( [&] {
+      const MacroCell& c = S( s ).getLocalCell( (uint_t) li );
+      if ( gid )
+         *gid = c.id;
+      if ( coords12 )
+         for ( int v = 0; v < 4; ++v )
+            for ( int r = 0; r < 3; ++r )
+               coords12[3 * v + r] = c.coords[v][r];
+      if ( nnc14 )
+      {
+         auto n = S( s ).numNeighborCells( c );
+         std::copy( n.begin(), n.end(), nnc14 );
+      }
+   } );
+}
+HYTEG_HOST_API int hyteg_host_storage_mask( hh_storage_t s, int li, int flag, int owned, unsigned* mask )
+{
+   return guarded( [&] {
+      const MacroCell& c = S( s ).getLocalCell( (uint_t) li );
+      *mask              = owned ? S( s ).ownedMaskFor( c, DoFType( flag ) ) : S( s ).maskFor( c, DoFType( flag ) );
+   } );
+}
+HYTEG_HOST_API int hyteg_host_storage_set_boundary_type( hh_storage_t s, int t )
+{
+   return guarded( [&] { S( s ).setBoundaryType( DoFType( t ) ); } );
+}
+HYTEG_HOST_API int hyteg_host_storage_set_stream( hh_storage_t s, void* stream )
+{
+   return guarded( [&] { S( s ).setStream( stream ); } );
+}
+HYTEG_HOST_API int hyteg_host_storage_set_hooks( hh_storage_t s, void ( *ex )( void*, int, int ), void ( *ar )( void*, double*, int ), void* user )
+{
+   return guarded( [&] {
+      CommHooks h;
+      h.exchange     = ex;
+      h.allreduceSum = ar;
+      h.user         = user;
+      S( s ).setCommHooks( h );
+   } );
+}
+HYTEG_HOST_API int hyteg_host_plan_sizes( hh_storage_t s, int level, int cls, int* sizes )
+{
+   return guarded( [&] {
+      const auto& P = S( s ).exchangePlan( level, cls );
+      sizes[0]      = P.ngroups();
+      sizes[1]      = (int) P.entryBuf.size();
+      sizes[2]      = (int) P.peers.size();
+      sizes[3]      = P.totalSend();
+      sizes[4]      = P.totalRecv();
+   } );
+}
+HYTEG_HOST_API int hyteg_host_plan_export( hh_storage_t s, int level, int cls, int* gp, int* eb, int* eo, int* peers, int* sc, int* rc, int* sb, int* so )
+{
+   return guarded( [&] {
+      const auto& P = S( s ).exchangePlan( level, cls );
+      std::copy( P.groupPtr.begin(), P.groupPtr.end(), gp );
+      std::copy( P.entryBuf.begin(), P.entryBuf.end(), eb );
+      std::copy( P.entryOff.begin(), P.entryOff.end(), eo );
+      std::copy( P.peers.begin(), P.peers.end(), peers );
+      std::copy( P.sendCount.begin(), P.sendCount.end(), sc );
+      std::copy( P.recvCount.begin(), P.recvCount.end(), rc );
+      std::copy( P.sendBuf.begin(), P.sendBuf.end(), sb );
+      std::copy( P.sendOff.begin(), P.sendOff.end(), so );
+   } );
+}
+HYTEG_HOST_API int hyteg_host_plan_register_buffers( hh_storage_t s, int level, int cls, double* send, double* recv )
+{
+   return guarded( [&] { S( s ).registerCommBuffers( level, cls, send, recv ); } );
+}
+
+HYTEG_HOST_API int hyteg_host_function_create( hh_storage_t s, const char* name, int minL, int maxL, hh_function_t* out )
+{
+   return guarded( [&] {
+      *out = new FunctionH{ std::make_shared< P1Function< double > >( name, static_cast< StorageH* >( s )->p, (uint_t) minL, (uint_t) maxL ) };
+   } );
+}
+HYTEG_HOST_API int hyteg_host_function_destroy( hh_function_t f )
+{
+   return guarded( [&] { delete static_cast< FunctionH* >( f ); } );
+}
+HYTEG_HOST_API int hyteg_host_function_cell_pointer( hh_function_t f, int c, int level, double** p )
+{
+   return guarded( [&] { *p = F( f ).getCellPointer( (uint_t) c, (uint_t) level ); } );
+}
+HYTEG_HOST_API int hyteg_host_function_upload_cell( hh_function_t f, int c, int level, const double* host )
+{
+   return guarded( [&] { F( f ).copyCellFromHost( (uint_t) c, (uint_t) level, host ); } );
+}
+HYTEG_HOST_API int hyteg_host_function_download_cell( hh_function_t f, int c, int level, double* host )
+{
+   return guarded( [&] { F( f ).copyCellToHost( (uint_t) c, (uint_t) level, host ); } );
+}
+HYTEG_HOST_API int hyteg_host_function_interpolate_constant( hh_function_t f, double v, int level, int flag )
+{
+   return guarded( [&] { F( f ).interpolate( v, (uint_t) level, DoFType( flag ) ); } );
+}
+HYTEG_HOST_API int hyteg_host_function_assign( hh_function_t dst, int n, const double* sc, const hh_function_t* srcs, int level, int flag )
+{
+   return guarded( [&] { F( dst ).assign( std::vector< double >( sc, sc + n ), refs( n, srcs ), (uint_t) level, DoFType( flag ) ); } );
+}
+HYTEG_HOST_API int hyteg_host_function_add( hh_function_t dst, int n, const double* sc, const hh_function_t* srcs, int level, int flag )
+{
+   return guarded( [&] { F( dst ).add( std::vector< double >( sc, sc + n ), refs( n, srcs ), (uint_t) level, DoFType( flag ) ); } );
+}
+HYTEG_HOST_API int hyteg_host_function_mult_elementwise( hh_function_t dst, int n, const hh_function_t* srcs, int level, int flag )
+{
+   return guarded( [&] { F( dst ).multElementwise( refs( n, srcs ), (uint_t) level, DoFType( flag ) ); } );
+}
+HYTEG_HOST_API int hyteg_host_function_dot( hh_function_t a, hh_function_t b, int level, int flag, int global, double* result )
+{
+   return guarded( [&] {
+      *result = global ? F( a ).dotGlobal( F( b ), (uint_t) level, DoFType( flag ) ) : F( a ).dotLocal( F( b ), (uint_t) level, DoFType( flag ) );
+   } );
+}
+HYTEG_HOST_API int hyteg_host_function_sum_shared( hh_function_t f, int level, int flag )
+{
+   return guarded( [&] { F( f ).sumSharedCopies( (uint_t) level, DoFType( flag ) ); } );
+}
+HYTEG_HOST_API int hyteg_host_function_sync_shared( hh_function_t f, int level, int flag )
+{
+   return guarded( [&] { F( f ).syncSharedCopies( (uint_t) level, DoFType( flag ) ); } );
+}
+
+HYTEG_HOST_API int hyteg_host_operator_create( hh_storage_t s, int minL, int maxL, int form, hh_operator_t* out )
+{
+   return guarded( [&] {
+      auto* h = new OperatorH{};
+      h->form = form;
+      if ( form == 0 )
+         h->laplace = std::make_shared< P1ConstantLaplaceOperator >( static_cast< StorageH* >( s )->p, (uint_t) minL, (uint_t) maxL );
+      else
+         h->mass = std::make_shared< P1ConstantMassOperator >( static_cast< StorageH* >( s )->p, (uint_t) minL, (uint_t) maxL );
+      *out = h;
+   } );
+}
+HYTEG_HOST_API int hyteg_host_operator_destroy( hh_operator_t op )
+{
+   return guarded( [&] { delete static_cast< OperatorH* >( op ); } );
+}
+#define WITH_OP( op, expr )                        \
+   do                                              \
+   {                                               \
+      auto* _h = static_cast< OperatorH* >( op );  \
+      if ( _h->form == 0 )                         \
+      {                                            \
+         auto& A = *_h->laplace;                   \
+         expr;                                     \
+      }                                            \
+      else                                         \
+      {                                            \
+         auto& A = *_h->mass;                      \
+         expr;                                     \
+      }                                            \
+   } while ( 0 )
+HYTEG_HOST_API int hyteg_host_operator_stencils( hh_operator_t op, int gc, int level, double* inner15, double* slots210 )
+{
+   return guarded( [&] {
+      WITH_OP( op, {
+         const auto& st = A.getCellStencils( gc, (uint_t) level );
+         std::copy( st.inner, st.inner + 15, inner15 );
+         std::copy( &st.slots[0][0], &st.slots[0][0] + 210, slots210 );
+      } );
+   } );
+}
+HYTEG_HOST_API int hyteg_host_operator_apply( hh_operator_t op, hh_function_t src, hh_function_t dst, int level, int flag, int update )
+{
+   return guarded( [&] { WITH_OP( op, A.apply( F( src ), F( dst ), (uint_t) level, DoFType( flag ), update ? Add : Replace ) ); } );
+}
+HYTEG_HOST_API int hyteg_host_operator_smooth_jac( hh_operator_t op, hh_function_t dst, hh_function_t rhs, hh_function_t src, double relax, int level, int flag )
+{
+   return guarded( [&] { WITH_OP( op, A.smooth_jac( F( dst ), F( rhs ), F( src ), relax, (uint_t) level, DoFType( flag ) ) ); } );
+}
+HYTEG_HOST_API int hyteg_host_operator_smooth_sor( hh_operator_t op, hh_function_t dst, hh_function_t rhs, double relax, int level, int flag, int backwards )
+{
+   return guarded( [&] { WITH_OP( op, A.smooth_sor( F( dst ), F( rhs ), relax, (uint_t) level, DoFType( flag ), backwards != 0 ) ); } );
+}
+HYTEG_HOST_API int hyteg_host_operator_compute_inverse_diagonal( hh_operator_t op )
+{
+   return guarded( [&] { WITH_OP( op, A.computeInverseDiagonalOperatorValues() ); } );
+}
+HYTEG_HOST_API int hyteg_host_operator_inverse_diagonal( hh_operator_t op, hh_function_t* out )
+{
+   return guarded( [&] {
+      auto* h = static_cast< OperatorH* >( op );
+      WITH_OP( op, h->invDiag.p = A.getInverseDiagonalValues() );
+      *out = &h->invDiag;
+   } );
+}
+
+HYTEG_HOST_API int hyteg_host_restrict( hh_function_t f, int sourceLevel, int flag )
+{
+   return guarded( [&] { P1toP1LinearRestriction().restrict( F( f ), (uint_t) sourceLevel, DoFType( flag ) ); } );
+}
+HYTEG_HOST_API int hyteg_host_prolongate( hh_function_t f, int sourceLevel, int flag )
+{
+   return guarded( [&] { P1toP1LinearProlongation().prolongate( F( f ), (uint_t) sourceLevel, DoFType( flag ) ); } );
+}
+HYTEG_HOST_API int hyteg_host_prolongate_and_add( hh_function_t f, int sourceLevel, int flag )
+{
+   return guarded( [&] { P1toP1LinearProlongation().prolongateAndAdd( F( f ), (uint_t) sourceLevel, DoFType( flag ) ); } );
+}
+
+HYTEG_HOST_API int hyteg_host_gmg_create( hh_storage_t s, int minL, int maxL, int smoother, double relax, int pre, int post, int wcycle,
+                                          int cgMaxIter, double cgTol, hh_solver_t* out )
+{
+   return guarded( [&] {
+      using Op     = P1ConstantLaplaceOperator;
+      auto storage = static_cast< StorageH* >( s )->p;
+      std::shared_ptr< Solver< Op > > sm;
+      if ( smoother == 0 )
+         sm = std::make_shared< WeightedJacobiSmoother< Op > >( storage, (uint_t) minL, (uint_t) maxL, relax );
+      else if ( smoother == 1 )
+         sm = std::make_shared< GaussSeidelSmoother< Op > >();
+      else
+         sm = std::make_shared< SORSmoother< Op > >( relax );
+      auto coarse = std::make_shared< CGSolver< Op > >( storage, (uint_t) minL, (uint_t) minL, (uint_t) cgMaxIter, cgTol, cgTol );
+      *out        = new SolverH{ std::make_shared< GeometricMultigridSolver< Op > >(
+          storage, sm, coarse, std::make_shared< P1toP1LinearRestriction >(), std::make_shared< P1toP1LinearProlongation >(), (uint_t) minL,
+          (uint_t) maxL, (uint_t) pre, (uint_t) post, 0, wcycle ? CycleType::WCYCLE : CycleType::VCYCLE ) };
+   } );
+}
+HYTEG_HOST_API int hyteg_host_cg_create( hh_storage_t s, int minL, int maxL, int maxIter, double tol, hh_solver_t* out )
+{
+   return guarded( [&] {
+      *out = new SolverH{ std::make_shared< CGSolver< P1ConstantLaplaceOperator > >( static_cast< StorageH* >( s )->p, (uint_t) minL, (uint_t) maxL,
+                                                                                     (uint_t) maxIter, tol, tol ) };
+   } );
+}
+HYTEG_HOST_API int hyteg_host_solver_solve( hh_solver_t solver, hh_operator_t laplace, hh_function_t x, hh_function_t b, int level )
+{
+   return guarded( [&] {
+      auto* h = static_cast< OperatorH* >( laplace );
+      if ( h->form != 0 )
+         throw std::runtime_error( "solver_solve: the solvers are instantiated for the Laplace operator" );
+      static_cast< SolverH* >( solver )->p->solve( *h->laplace, F( x ), F( b ), (uint_t) level );
+   } );
+}
+HYTEG_HOST_API int hyteg_host_solver_destroy( hh_solver_t solver )
+{
+   return guarded( [&] { delete static_cast< SolverH* >( solver ); } );
+}
+}

@@ -208,6 +208,100 @@ HYTEG_HIP_API int hyteg_hip_p1_prolongate_cell( const double*      coarse,
                                                 int                update,
                                                 hyteg_hip_stream_t stream );
 
+/* ---- cell-centric multi-cell support -------------------------------------------------------------------
+ * On meshes with several macro-cells this library keeps the DoFs of macro-faces/edges/vertices in the boundary
+ * entries of every adjacent cell array (HyTeG's cell arrays hold the same copies after communicate<Face,Cell>,
+ * src/hyteg/p1functionspace/VertexDoFPackInfo.hpp:410-478).  Points are addressed by a 15-bit mask:
+ * bit k (k = 0..13) selects the points on the macro-primitive in slot k of { edge0..5, face0..3, vertex0..3 }
+ * (the cell-local numbering of src/hyteg/indexing/MacroCellIndexing.cpp:36-91), bit 14 the cell interior.
+ * A host layer derives the mask from the DoFType flag and the primitives' boundary conditions, which is the
+ * test `testFlag( bc.getBoundaryType( prim.getMeshBoundaryFlag() ), flag )` of P1Operator.hpp:213-303. */
+#define HYTEG_HIP_SLOT_INNER 14
+#define HYTEG_HIP_MASK_INNER ( 1u << 14 )
+#define HYTEG_HIP_MASK_SHELL 0x3FFFu
+#define HYTEG_HIP_MASK_ALL 0x7FFFu
+
+/* a9: apply on the points of the cell boundary with this cell's PARTIAL stencils
+ * (what P1Elements3D::calculateStencilInMacroCell gives for a micro-vertex on that face/edge/vertex,
+ *  src/hyteg/p1functionspace/P1Elements.hpp:215-380; the reference stores them per neighbour cell in
+ *  faceStencil3D / edgeStencil3D, src/constant_stencil_operator/P1ConstantOperator.cpp:239-357).
+ * w_slots: host, 14 x 15 weights (slot-major, stencil order as above; weights of neighbours outside the cell
+ * are ignored).  dst_i (=|+=) sum over the neighbours inside the cell.  Summing the results of all cells that
+ * share a point gives the reference's value of apply() on that macro-face/edge/vertex DoF. */
+HYTEG_HIP_API int hyteg_hip_p1_apply_cell_boundary( double*            dst,
+                                                    const double*      src,
+                                                    int                level,
+                                                    const double*      w_slots /* host, 14*15 */,
+                                                    unsigned           mask,
+                                                    int                update,
+                                                    hyteg_hip_stream_t stream );
+
+/* a6 with a point mask: op 0 = assign, 1 = add, 2 = multElementwise (VertexDoFFunction.cpp:1130-1221,
+ * 1408-1484, 1487-1563 loop over vertices, edges, faces and cells with the same flag test). */
+HYTEG_HIP_API int hyteg_hip_p1_vector_cell_masked( int                  op,
+                                                   double*              dst,
+                                                   int                  nsrc,
+                                                   const double* const* srcs,
+                                                   const double*        scalars /* host, nsrc; ignored for op 2 */,
+                                                   int                  level,
+                                                   unsigned             mask,
+                                                   hyteg_hip_stream_t   stream );
+/* dst = value on the masked points (VertexDoFFunction::interpolate( constant, level, flag )) */
+HYTEG_HIP_API int
+    hyteg_hip_p1_set_cell_masked( double* dst, double value, int level, unsigned mask, hyteg_hip_stream_t stream );
+/* dot over the masked points (dotLocal sums vertices + edges + faces + cells, VertexDoFFunction.cpp:1720-1793;
+ * the host passes, per cell, the mask of the primitives that cell "owns" so that every DoF counts once). */
+HYTEG_HIP_API int hyteg_hip_p1_dot_cell_masked( const double*      a,
+                                                const double*      b,
+                                                int                level,
+                                                unsigned           mask,
+                                                double*            result_dev,
+                                                void*              workspace_dev,
+                                                hyteg_hip_stream_t stream );
+/* grid transfer writing only the masked coarse / fine points (interior bit must be set) */
+HYTEG_HIP_API int hyteg_hip_p1_restrict_cell_masked( double*            coarse,
+                                                     const double*      fine,
+                                                     int                coarse_level,
+                                                     const double*      nnc /* host, 14 */,
+                                                     unsigned           mask,
+                                                     hyteg_hip_stream_t stream );
+HYTEG_HIP_API int hyteg_hip_p1_prolongate_cell_masked( const double*      coarse,
+                                                       double*            fine,
+                                                       int                coarse_level,
+                                                       const double*      nnc /* host, 14 */,
+                                                       unsigned           mask,
+                                                       hyteg_hip_stream_t stream );
+
+/* a10: additive exchange of shared points (the reduce-into-owner of VertexDoFAdditivePackInfo.hpp:676-745,
+ * followed by the copy back into every adjacent cell).  A group is one physical DoF; its entries are the
+ * places that hold a partial value of it: (buffer index into `bases`, element offset).
+ *   out[e] = init + sum_{e in group} bases[buf_e][off_e]   in entry order (fixed, so every rank gets the same bits),
+ * written back to every entry whose buffer index is < n_writable (local cell arrays; receive buffers follow).
+ * All arrays are device memory except the scalars. */
+HYTEG_HIP_API int hyteg_hip_sum_shared( double* const*     bases /* device table of device pointers */,
+                                        const int*         group_ptr /* device, ngroups+1 */,
+                                        const int*         entry_buf /* device, nentries */,
+                                        const int*         entry_off /* device, nentries */,
+                                        int                ngroups,
+                                        int                n_writable,
+                                        hyteg_hip_stream_t stream );
+/* same groups, but every writable entry := the value of the group's FIRST entry (owner copy wins); used after
+ * host-side interpolation, where the copies of a shared DoF may differ in the last bit */
+HYTEG_HIP_API int hyteg_hip_copy_shared( double* const*     bases,
+                                         const int*         group_ptr,
+                                         const int*         entry_buf,
+                                         const int*         entry_off,
+                                         int                ngroups,
+                                         int                n_writable,
+                                         hyteg_hip_stream_t stream );
+/* pack: out[k] = bases[buf[k]][off[k]]  (send buffer for one peer) */
+HYTEG_HIP_API int hyteg_hip_gather_entries( double*            out,
+                                            double* const*     bases,
+                                            const int*         entry_buf,
+                                            const int*         entry_off,
+                                            int                n,
+                                            hyteg_hip_stream_t stream );
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,92 @@
+/*
+ * hyteg_host.h -- C facade over the C++ host layer (hyteg_amd/host/hyteg_host.hpp) for non-C++ callers
+ * (the pytest suite, bench.py and the torch.distributed driver use it through ctypes).  The C++ classes
+ * carry the reference's names (PrimitiveStorage, P1Function, P1ConstantLaplaceOperator, P1toP1Linear*,
+ * GeometricMultigridSolver ...); this header only flattens them to handles.  Library: libhyteg_host.so,
+ * which itself calls nothing but libhyteg_hip.so (include/hyteg_hip.h).
+ *
+ * All functions return 0 on success, non-zero on failure (hyteg_host_last_error() has the message); the
+ * reference would WALBERLA_ABORT.  Handles are opaque pointers.  DoFType flags and UpdateType are the integer
+ * values of src/hyteg/types/types.hpp:29-44 (Inner = 1, DirichletBoundary = 2, NeumannBoundary = 4, All = 15).
+ */
+#ifndef HYTEG_HOST_H
+#define HYTEG_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined( HYTEG_HOST_BUILDING )
+#define HYTEG_HOST_API __attribute__( ( visibility( "default" ) ) )
+#else
+#define HYTEG_HOST_API
+#endif
+
+typedef void* hh_storage_t;
+typedef void* hh_function_t;
+typedef void* hh_operator_t;
+typedef void* hh_solver_t;
+
+HYTEG_HOST_API const char* hyteg_host_last_error( void );
+
+/* ---- PrimitiveStorage ---- */
+HYTEG_HOST_API int hyteg_host_storage_from_gmsh( const char* path, int rank, int nranks, hh_storage_t* out );
+HYTEG_HOST_API int hyteg_host_storage_from_arrays( int nvertices, const double* xyz, int ncells, const int* cells, int rank, int nranks, hh_storage_t* out );
+HYTEG_HOST_API int hyteg_host_storage_destroy( hh_storage_t s );
+/* counts[0..5] = global cells, faces, edges, vertices, local cells, ranks */
+HYTEG_HOST_API int hyteg_host_storage_counts( hh_storage_t s, int* counts );
+HYTEG_HOST_API int hyteg_host_storage_local_cell( hh_storage_t s, int local_index, int* global_id, double* coords12, double* nnc14 );
+HYTEG_HOST_API int hyteg_host_storage_mask( hh_storage_t s, int local_index, int flag, int owned, unsigned* mask );
+HYTEG_HOST_API int hyteg_host_storage_set_boundary_type( hh_storage_t s, int dof_type );
+HYTEG_HOST_API int hyteg_host_storage_set_stream( hh_storage_t s, void* stream );
+/* multi-rank hooks: exchange( user, level, cls ), allreduce_sum( user, values, n ) */
+HYTEG_HOST_API int hyteg_host_storage_set_hooks( hh_storage_t s, void ( *exchange )( void*, int, int ), void ( *allreduce_sum )( void*, double*, int ), void* user );
+/* exchange plan of (level, cls) -- host data, works without a GPU.
+ * sizes[0..4] = ngroups, nentries, npeers, total_send, total_recv */
+HYTEG_HOST_API int hyteg_host_plan_sizes( hh_storage_t s, int level, int cls, int* sizes );
+HYTEG_HOST_API int hyteg_host_plan_export( hh_storage_t s, int level, int cls, int* group_ptr, int* entry_buf, int* entry_off,
+                                           int* peers, int* send_count, int* recv_count, int* send_buf, int* send_off );
+HYTEG_HOST_API int hyteg_host_plan_register_buffers( hh_storage_t s, int level, int cls, double* send_dev, double* recv_dev );
+
+/* ---- P1Function<double> ---- */
+HYTEG_HOST_API int hyteg_host_function_create( hh_storage_t s, const char* name, int min_level, int max_level, hh_function_t* out );
+HYTEG_HOST_API int hyteg_host_function_destroy( hh_function_t f );
+HYTEG_HOST_API int hyteg_host_function_cell_pointer( hh_function_t f, int local_cell, int level, double** dev_ptr );
+HYTEG_HOST_API int hyteg_host_function_upload_cell( hh_function_t f, int local_cell, int level, const double* host );
+HYTEG_HOST_API int hyteg_host_function_download_cell( hh_function_t f, int local_cell, int level, double* host );
+HYTEG_HOST_API int hyteg_host_function_interpolate_constant( hh_function_t f, double value, int level, int flag );
+HYTEG_HOST_API int hyteg_host_function_assign( hh_function_t dst, int n, const double* scalars, const hh_function_t* srcs, int level, int flag );
+HYTEG_HOST_API int hyteg_host_function_add( hh_function_t dst, int n, const double* scalars, const hh_function_t* srcs, int level, int flag );
+HYTEG_HOST_API int hyteg_host_function_mult_elementwise( hh_function_t dst, int n, const hh_function_t* srcs, int level, int flag );
+HYTEG_HOST_API int hyteg_host_function_dot( hh_function_t a, hh_function_t b, int level, int flag, int global, double* result );
+HYTEG_HOST_API int hyteg_host_function_sum_shared( hh_function_t f, int level, int flag );
+HYTEG_HOST_API int hyteg_host_function_sync_shared( hh_function_t f, int level, int flag );
+
+/* ---- P1ConstantOperator (form 0: Laplace, 1: mass) ---- */
+HYTEG_HOST_API int hyteg_host_operator_create( hh_storage_t s, int min_level, int max_level, int form, hh_operator_t* out );
+HYTEG_HOST_API int hyteg_host_operator_destroy( hh_operator_t op );
+/* inner[15], slots[14*15] of a GLOBAL cell id */
+HYTEG_HOST_API int hyteg_host_operator_stencils( hh_operator_t op, int global_cell, int level, double* inner15, double* slots210 );
+HYTEG_HOST_API int hyteg_host_operator_apply( hh_operator_t op, hh_function_t src, hh_function_t dst, int level, int flag, int update );
+HYTEG_HOST_API int hyteg_host_operator_smooth_jac( hh_operator_t op, hh_function_t dst, hh_function_t rhs, hh_function_t src, double relax, int level, int flag );
+HYTEG_HOST_API int hyteg_host_operator_smooth_sor( hh_operator_t op, hh_function_t dst, hh_function_t rhs, double relax, int level, int flag, int backwards );
+HYTEG_HOST_API int hyteg_host_operator_compute_inverse_diagonal( hh_operator_t op );
+HYTEG_HOST_API int hyteg_host_operator_inverse_diagonal( hh_operator_t op, hh_function_t* out /* borrowed */ );
+
+/* ---- grid transfer ---- */
+HYTEG_HOST_API int hyteg_host_restrict( hh_function_t f, int source_level, int flag );
+HYTEG_HOST_API int hyteg_host_prolongate( hh_function_t f, int source_level, int flag );
+HYTEG_HOST_API int hyteg_host_prolongate_and_add( hh_function_t f, int source_level, int flag );
+
+/* ---- solvers on the Laplace operator ----
+ * smoother: 0 = weighted Jacobi (relax), 1 = Gauss-Seidel, 2 = SOR (relax).  Coarse grid: CG. */
+HYTEG_HOST_API int hyteg_host_gmg_create( hh_storage_t s, int min_level, int max_level, int smoother, double relax, int pre, int post,
+                                          int wcycle, int cg_max_iter, double cg_tol, hh_solver_t* out );
+HYTEG_HOST_API int hyteg_host_cg_create( hh_storage_t s, int min_level, int max_level, int max_iter, double tol, hh_solver_t* out );
+HYTEG_HOST_API int hyteg_host_solver_solve( hh_solver_t solver, hh_operator_t laplace, hh_function_t x, hh_function_t b, int level );
+HYTEG_HOST_API int hyteg_host_solver_destroy( hh_solver_t solver );
+
+#ifdef __cplusplus
+}
+#endif
+#endif

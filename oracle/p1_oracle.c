@@ -539,3 +539,151 @@ HO_API void ho_coordinate_from_index( double* out, const double* cc, int level, 
       out[r] = cc[r] + xs * (double) x + ys * (double) y + zs * (double) z;
    }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * a9 (cell-centric form): per-cell PARTIAL stencils on the cell boundary and the apply that uses them.
+ * src/hyteg/p1functionspace/P1Elements.hpp:215-301 (getNeighboringElements: a micro-vertex on a cell
+ * face keeps the 12 micro-tets of allCellsAtFace[f] (:145-205), on a cell edge the intersection of two
+ * such lists, on a cell vertex a single micro-tet) and :303-380 (calculateStencilInMacroCell).
+ * Those lists are exactly the micro-tets of the 24 whose four vertices stay inside the cell, i.e. whose
+ * directions d satisfy, for every cell face the point lies on:
+ *    face 0 (z=0): dz >= 0,  face 1 (y=0): dy >= 0,  face 2 (x=0): dx >= 0,  face 3 (x+y+z=n): dx+dy+dz <= 0.
+ * The reference keeps these weights per neighbour cell in faceStencil3D / edgeStencil3D
+ * (src/constant_stencil_operator/P1ConstantOperator.cpp:239-357) and sums the per-cell results.
+ * Slots: { edge0..5, face0..3, vertex0..3 } (ho_prim_slot).  w_slots: 14 x 15, stencil order as w[15].
+ * ------------------------------------------------------------------------------------------- */
+static const int SLOT_FACES[14][4] = {
+    /* edges  */ { 1, 1, 0, 0 }, { 1, 0, 1, 0 }, { 1, 0, 0, 1 }, { 0, 1, 1, 0 }, { 0, 1, 0, 1 }, { 0, 0, 1, 1 },
+    /* faces  */ { 1, 0, 0, 0 }, { 0, 1, 0, 0 }, { 0, 0, 1, 0 }, { 0, 0, 0, 1 },
+    /* verts  */ { 1, 1, 1, 0 }, { 1, 1, 0, 1 }, { 1, 0, 1, 1 }, { 0, 1, 1, 1 } };
+
+static int dir_allowed( int slot, const int* d )
+{
+   const int* f = SLOT_FACES[slot];
+   if ( f[0] && d[2] < 0 ) return 0;
+   if ( f[1] && d[1] < 0 ) return 0;
+   if ( f[2] && d[0] < 0 ) return 0;
+   if ( f[3] && d[0] + d[1] + d[2] > 0 ) return 0;
+   return 1;
+}
+
+HO_API void ho_assemble_cell_slot_stencils( double* w_slots, const double* cc, int level, int form )
+{
+   const double step = 1.0 / (double) ( (int64_t) 1 << level );
+   double       xs[3], ys[3], zs[3];
+   for ( int r = 0; r < 3; ++r )
+   {
+      xs[r] = ( cc[3 + r] - cc[r] ) * step;
+      ys[r] = ( cc[6 + r] - cc[r] ) * step;
+      zs[r] = ( cc[9 + r] - cc[r] ) * step;
+   }
+   double rows[24][4];
+   for ( int t = 0; t < 24; ++t )
+   {
+      double coords[12], A[16];
+      for ( int v = 0; v < 4; ++v )
+      {
+         const int* o = OFFS[MICRO_TETS[t][v]];
+         for ( int r = 0; r < 3; ++r )
+            coords[3 * v + r] = cc[r] + xs[r] * (double) ( 1 + o[0] ) + ys[r] * (double) ( 1 + o[1] ) + zs[r] * (double) ( 1 + o[2] );
+      }
+      if ( form == 0 )
+         ho_p1_tet_diffusion( A, coords );
+      else
+         ho_p1_tet_mass( A, coords );
+      for ( int v = 0; v < 4; ++v )
+         rows[t][v] = A[v];
+   }
+   for ( int s = 0; s < 14; ++s )
+   {
+      double* w = w_slots + 15 * s;
+      for ( int k = 0; k < 15; ++k )
+         w[k] = 0.0;
+      for ( int t = 0; t < 24; ++t )
+      {
+         int ok = 1;
+         for ( int v = 1; v < 4; ++v )
+            ok = ok && dir_allowed( s, OFFS[MICRO_TETS[t][v]] );
+         if ( !ok )
+            continue;
+         for ( int v = 0; v < 4; ++v )
+            w[MICRO_TETS[t][v]] += rows[t][v];
+      }
+   }
+}
+
+/* mask bit k (0..13): points on slot k; bit 14: interior */
+static inline int point_selected( unsigned mask, int slot ) { return ( mask >> ( slot < 0 ? 14 : slot ) ) & 1u; }
+
+HO_API void ho_apply_cell_boundary( double* dst, const double* src, int level, const double* w_slots, unsigned mask, int update )
+{
+   const int64_t N = ho_width( level );
+   for ( int64_t z = 0; z < N; ++z )
+      for ( int64_t y = 0; y < N - z; ++y )
+         for ( int64_t x = 0; x < N - z - y; ++x )
+         {
+            const int slot = prim_slot( N, x, y, z );
+            if ( slot < 0 || !point_selected( mask, slot ) )
+               continue;
+            const double* w   = w_slots + 15 * slot;
+            double        acc = 0.0;
+            for ( int k = 0; k < 15; ++k )
+            {
+               const int64_t nx = x + OFFS[k][0], ny = y + OFFS[k][1], nz = z + OFFS[k][2];
+               if ( !inside( N, nx, ny, nz ) )
+                  continue;
+               acc = acc + w[k] * src[cell_index_w( N, nx, ny, nz )];
+            }
+            const int64_t i = cell_index_w( N, x, y, z );
+            dst[i]          = update ? acc + dst[i] : acc;
+         }
+}
+
+/* masked vector kernels: op 0 assign, 1 add, 2 mult, 3 set constant scalars[0]
+ * (VertexDoFFunction.cpp:1130-1221, 1408-1484, 1487-1563, interpolate( constant ) :380-392) */
+HO_API void ho_vector_cell_masked( int op, double* dst, int nsrc, const double* const* srcs, const double* scalars, int level,
+                                   unsigned mask )
+{
+   const int64_t N = ho_width( level );
+   for ( int64_t z = 0; z < N; ++z )
+      for ( int64_t y = 0; y < N - z; ++y )
+         for ( int64_t x = 0; x < N - z - y; ++x )
+         {
+            if ( !point_selected( mask, prim_slot( N, x, y, z ) ) )
+               continue;
+            const int64_t i = cell_index_w( N, x, y, z );
+            double        tmp;
+            if ( op == 3 )
+               tmp = scalars[0];
+            else if ( op == 2 )
+            {
+               tmp = srcs[0][i];
+               for ( int k = 1; k < nsrc; ++k )
+                  tmp = tmp * srcs[k][i];
+            }
+            else
+            {
+               tmp = scalars[0] * srcs[0][i];
+               for ( int k = 1; k < nsrc; ++k )
+                  tmp = tmp + scalars[k] * srcs[k][i];
+               if ( op == 1 )
+                  tmp = dst[i] + tmp;
+            }
+            dst[i] = tmp;
+         }
+}
+
+HO_API double ho_dot_cell_masked( const double* a, const double* b, int level, unsigned mask )
+{
+   const int64_t N  = ho_width( level );
+   double        sp = 0;
+   for ( int64_t z = 0; z < N; ++z )
+      for ( int64_t y = 0; y < N - z; ++y )
+         for ( int64_t x = 0; x < N - z - y; ++x )
+            if ( point_selected( mask, prim_slot( N, x, y, z ) ) )
+            {
+               const int64_t i = cell_index_w( N, x, y, z );
+               sp              = sp + a[i] * b[i];
+            }
+   return sp;
+}

@@ -65,6 +65,10 @@ def _bind(lib):
         "ho_p1_tet_mass": (None, [_P, _P]),
         "ho_assemble_cell_stencil": (None, [_P, _P, i, i]),
         "ho_coordinate_from_index": (None, [_P, _P, i, i, i, i]),
+        "ho_assemble_cell_slot_stencils": (None, [_P, _P, i, i]),
+        "ho_apply_cell_boundary": (None, [_P, _P, i, _P, C.c_uint, i]),
+        "ho_vector_cell_masked": (None, [i, _P, i, C.POINTER(_P), _P, i, C.c_uint]),
+        "ho_dot_cell_masked": (d, [_P, _P, i, C.c_uint]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)
@@ -247,6 +251,38 @@ def assemble_cell_stencil(cell_vertex_coords, level, form=0):
     w = np.empty(15)
     lib().ho_assemble_cell_stencil(_p(w), _p(c), level, form)
     return w
+
+
+MASK_INNER, MASK_SHELL, MASK_ALL = 1 << 14, 0x3FFF, 0x7FFF
+
+
+def assemble_cell_slot_stencils(cell_vertex_coords, level, form=0):
+    """(14,15) partial stencils of this cell for points on its edges 0-5, faces 0-3, vertices 0-3."""
+    c = np.ascontiguousarray(cell_vertex_coords, dtype=np.float64).reshape(12)
+    w = np.empty(14 * 15)
+    lib().ho_assemble_cell_slot_stencils(_p(w), _p(c), level, form)
+    return w.reshape(14, 15)
+
+
+def apply_cell_boundary(dst, src, level, w_slots, mask=MASK_SHELL, update=REPLACE):
+    ws = np.ascontiguousarray(w_slots, dtype=np.float64).reshape(14 * 15)
+    lib().ho_apply_cell_boundary(_p(dst), _p(src), level, _p(ws), mask, update)
+    return dst
+
+
+def vector_cell_masked(op, dst, scalars, srcs, level, mask):
+    s = np.ascontiguousarray(scalars if scalars is not None else [1.0] * max(1, len(srcs)), dtype=np.float64)
+    lib().ho_vector_cell_masked(op, _p(dst), len(srcs), _pp(srcs) if srcs else None, _p(s), level, mask)
+    return dst
+
+
+def dot_cell_masked(a, b, level, mask): return float(lib().ho_dot_cell_masked(_p(a), _p(b), level, mask))
+
+
+def slot_of_points(level):
+    """per array entry: slot 0..13 of the macro-primitive it lies on, 14 for interior points"""
+    c = cell_coords(level)
+    return np.array([14 if prim_slot(level, *map(int, p)) < 0 else prim_slot(level, *map(int, p)) for p in c])
 
 
 def coordinate_from_index(cell_vertex_coords, level, x, y, z):

@@ -1,0 +1,417 @@
+"""GPU tests of the cell-centric multi-cell kernels (C-ABI) and of the C++ host layer (through its C facade),
+checked against the CPU oracle and against the properties the reference's own multi-cell tests assert."""
+import numpy as np
+import pytest
+
+from conftest import OCT_TET, REF_TET, SKEW_TET
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-13
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    from hyteg_amd import capi, host
+    from oracle import p1_oracle as po
+
+    assert torch.cuda.is_available()
+    capi.lib()
+    host.lib()
+    return torch, capi, host, po
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda")
+
+
+def _rel(a, b):
+    nb = np.linalg.norm(b)
+    return np.linalg.norm(a - b) / (nb if nb > 0 else 1.0)
+
+
+MASKS = [0x3FFF, 0x7FFF, 1 << 14, 0x0240 | (1 << 10), 0x003F, 0x3C00, 0]
+
+
+# ---- C-ABI: shell kernels --------------------------------------------------------------------------------
+@pytest.mark.parametrize("level", [0, 1, 2, 3, 5])
+@pytest.mark.parametrize("tet", [REF_TET, SKEW_TET])
+def test_apply_cell_boundary_partial_stencils(env, level, tet):
+    torch, capi, host, po = env
+    rng = np.random.default_rng(level)
+    n = po.cell_size(level)
+    ws = po.assemble_cell_slot_stencils(tet, level)
+    src_h, d0 = rng.random(n), rng.random(n)
+    src = _dev(torch, src_h)
+    for mask in MASKS:
+        for update in (0, 1):
+            dst = _dev(torch, d0)
+            capi.p1_apply_cell_boundary(dst.data_ptr(), src.data_ptr(), level, ws, mask, update)
+            torch.cuda.synchronize()
+            ref = d0.copy()
+            po.apply_cell_boundary(ref, src_h, level, ws, mask, update)
+            got = dst.cpu().numpy()
+            sel = ((mask & 0x3FFF) >> po.slot_of_points(level)) & 1
+            assert np.array_equal(got[sel == 0], d0[sel == 0])
+            assert _rel(got, ref) < TOL
+
+
+def test_partial_stencils_of_two_mirror_cells_add_up_to_the_interior_stencil(env):
+    """Glue a cell and its mirror image across face 0 (z = 0): the two face-0 shares of the stencil must add up to
+    the full 15-point stencil of the uniform refinement (row sum 0, symmetric) -- the consistency the reference relies
+    on when it sums faceStencil3D over the two neighbour cells (P1ConstantOperator.cpp:264-329)."""
+    torch, capi, host, po = env
+    level = 3
+    a = np.array(REF_TET)
+    b = a.copy()
+    b[3] = [0.0, 0.0, -1.0]  # mirrored apex
+    wa = po.assemble_cell_slot_stencils(a, level)[6]   # face 0 of cell a
+    wb = po.assemble_cell_slot_stencils(b, level)[6]
+    full = po.assemble_cell_stencil(a, level)
+    names = po.STENCIL_NAMES
+    # in-plane weights (dz = 0) add up; out-of-plane weights come from one cell each
+    for k, (nme, off) in enumerate(zip(names, po.STENCIL_OFFSETS)):
+        if off[2] == 0:
+            assert abs(wa[k] + wb[k] - full[k]) < 1e-13, nme
+    assert abs(wa.sum() + wb.sum()) < 1e-13
+
+
+@pytest.mark.parametrize("level", [0, 1, 3, 5])
+def test_masked_vector_set_and_dot(env, level):
+    torch, capi, host, po = env
+    rng = np.random.default_rng(10 + level)
+    n = po.cell_size(level)
+    hs = [rng.random(n) for _ in range(3)]
+    ds = [_dev(torch, h) for h in hs]
+    d0 = rng.random(n)
+    res = torch.zeros(1, dtype=torch.float64, device="cuda")
+    ws = torch.zeros(capi.dot_workspace_bytes() // 8, dtype=torch.float64, device="cuda")
+    for mask in MASKS:
+        sel = ((mask >> po.slot_of_points(level)) & 1).astype(bool)
+        for op, scal in ((0, [2.0, -1.5, 0.25]), (1, [2.0, -1.5, 0.25]), (2, None)):
+            dst = _dev(torch, d0)
+            capi.p1_vector_cell_masked(op, dst.data_ptr(), scal, [d.data_ptr() for d in ds], level, mask)
+            torch.cuda.synchronize()
+            ref = d0.copy()
+            po.vector_cell_masked(op, ref, scal, hs, level, mask)
+            got = dst.cpu().numpy()
+            assert np.array_equal(got[~sel], d0[~sel]) and _rel(got, ref) < TOL
+        dst = _dev(torch, d0)
+        capi.p1_set_cell_masked(dst.data_ptr(), 3.25, level, mask)
+        torch.cuda.synchronize()
+        got = dst.cpu().numpy()
+        assert np.all(got[sel] == 3.25) and np.array_equal(got[~sel], d0[~sel])
+        capi.p1_dot_cell_masked(ds[0].data_ptr(), ds[1].data_ptr(), level, mask, res.data_ptr(), ws.data_ptr())
+        torch.cuda.synchronize()
+        ref = po.dot_cell_masked(hs[0], hs[1], level, mask)
+        assert abs(float(res[0]) - ref) <= 1e-13 * max(1.0, abs(ref))
+
+
+@pytest.mark.parametrize("coarse_level", [0, 2, 4])
+def test_masked_grid_transfer(env, coarse_level):
+    torch, capi, host, po = env
+    rng = np.random.default_rng(coarse_level)
+    nnc = [3, 4, 5, 6, 7, 8, 2, 1, 2, 2, 9, 10, 11, 12]
+    fine_h, coarse_h = rng.random(po.cell_size(coarse_level + 1)), rng.random(po.cell_size(coarse_level))
+    fine, coarse = _dev(torch, fine_h), _dev(torch, coarse_h)
+    for mask in (0x7FFF, (1 << 14) | 0x03C0, 0x3FFF):
+        out = _dev(torch, coarse_h)
+        capi.p1_restrict_cell_masked(out.data_ptr(), fine.data_ptr(), coarse_level, nnc, mask)
+        torch.cuda.synchronize()
+        full = np.zeros_like(coarse_h)
+        po.restrict_cell(full, fine_h, coarse_level, np.array(nnc, dtype=float))
+        sel = ((mask >> po.slot_of_points(coarse_level)) & 1).astype(bool)
+        ref = np.where(sel, full, coarse_h)
+        assert _rel(out.cpu().numpy(), ref) < TOL
+        outf = _dev(torch, fine_h)
+        capi.p1_prolongate_cell_masked(coarse.data_ptr(), outf.data_ptr(), coarse_level, nnc, mask)
+        torch.cuda.synchronize()
+        fullf = np.zeros_like(fine_h)
+        po.prolongate_cell(coarse_h, fullf, coarse_level, np.array(nnc, dtype=float))
+        self_f = ((mask >> po.slot_of_points(coarse_level + 1)) & 1).astype(bool)
+        reff = np.where(self_f, fullf, fine_h)
+        assert _rel(outf.cpu().numpy(), reff) < TOL
+
+
+def test_sum_and_copy_shared_kernels(env):
+    torch, capi, host, po = env
+    a = torch.arange(10, dtype=torch.float64, device="cuda")
+    b = torch.arange(10, dtype=torch.float64, device="cuda") * 10
+    r = torch.tensor([100.0, 200.0], dtype=torch.float64, device="cuda")  # "receive buffer", not writable
+    bases = torch.tensor([a.data_ptr(), b.data_ptr(), r.data_ptr()], dtype=torch.int64, device="cuda")
+    gp = torch.tensor([0, 2, 5], dtype=torch.int32, device="cuda")
+    eb = torch.tensor([0, 1, 0, 1, 2], dtype=torch.int32, device="cuda")
+    eo = torch.tensor([3, 4, 7, 7, 1], dtype=torch.int32, device="cuda")
+    capi.sum_shared(bases.data_ptr(), gp.data_ptr(), eb.data_ptr(), eo.data_ptr(), 2, 2)
+    torch.cuda.synchronize()
+    assert float(a[3]) == 43.0 and float(b[4]) == 43.0
+    assert float(a[7]) == 277.0 and float(b[7]) == 277.0 and float(r[1]) == 200.0
+    capi.lib().hyteg_hip_copy_shared(bases.data_ptr(), gp.data_ptr(), eb.data_ptr(), eo.data_ptr(), 2, 2, 0)
+    out = torch.zeros(5, dtype=torch.float64, device="cuda")
+    capi.gather_entries(out.data_ptr(), bases.data_ptr(), eb.data_ptr(), eo.data_ptr(), 5)
+    torch.cuda.synchronize()
+    assert out.cpu().tolist() == [43.0, 43.0, 277.0, 277.0, 200.0]
+
+
+# ---- host layer ---------------------------------------------------------------------------------------------
+def _storage(host, mesh):
+    from hostutil import MESHES
+
+    return host.Storage.from_gmsh(MESHES / f"{mesh}.msh")
+
+
+@pytest.mark.parametrize("mesh", ["tet_1el", "pyramid_2el", "pyramid_4el", "pyramid_tilted_4el", "regular_octahedron_8el"])
+@pytest.mark.parametrize("level", [2, 3])
+def test_laplace_annihilates_constants_and_linears_on_multi_cell_meshes(env, mesh, level):
+    """tests/hyteg/P1/P1LaplaceOperator3DTest.cpp:40-141: the same meshes, levels, functions and limit (2.8e-13);
+    the error norm is taken over ALL inner DoFs, i.e. including those on shared macro-faces/edges/vertices."""
+    torch, capi, host, po = env
+    from hostutil import MultiCellOracle, upload
+
+    st = _storage(host, mesh)
+    mo = MultiCellOracle(st)
+    A = host.P1ConstantOperator(st, level, level)
+    u, r, one = (host.P1Function(st, nm, level, level) for nm in ("u", "r", "one"))
+    one.interpolate(1.0, level, host.All)
+    npts = one.dot(one, level, host.Inner)
+    fns = [lambda x, y, z: 0 * x, lambda x, y, z: 0 * x + 1.0, lambda x, y, z: 42 * x, lambda x, y, z: 42 * x + y + 1337 * z]
+    for fn in fns:
+        upload(u, mo.interpolate(fn, level), level)
+        r.interpolate(0.0, level, host.All)
+        A.apply(u, r, level, host.Inner)
+        err = np.sqrt(r.dot(r, level, host.Inner) / npts)
+        assert err < 2.8e-13
+    for o in (u, r, one, A, st):
+        o.close()
+
+
+@pytest.mark.parametrize("mesh", ["regular_octahedron_8el", "pyramid_tilted_4el", "cube_6el"])
+@pytest.mark.parametrize("flag", ["Inner", "All"])
+def test_apply_matches_the_multi_cell_oracle(env, mesh, flag):
+    torch, capi, host, po = env
+    from hostutil import MultiCellOracle, download, upload
+
+    level = 3
+    st = _storage(host, mesh)
+    mo = MultiCellOracle(st)
+    fl = getattr(host, flag)
+    A = host.P1ConstantOperator(st, level, level)
+    src, dst = host.P1Function(st, "src", level, level), host.P1Function(st, "dst", level, level)
+    rng = np.random.default_rng(3)
+    # consistent random data: random per physical point (identical in all copies)
+    src_h = mo.interpolate(lambda x, y, z: np.sin(37.0 * x + 11.0 * y * y + 5.0 * z) + x * y, level)
+    dst0 = [rng.random(po.cell_size(level)) for _ in src_h]
+    mo.sync(dst0, level, host.All)
+    upload(src, src_h, level)
+    upload(dst, dst0, level)
+    A.apply(src, dst, level, fl)
+    got = download(dst, level)
+    ref = mo.apply(src_h, [d.copy() for d in dst0], level, fl)
+    for g, r_, d0, i in zip(got, ref, dst0, range(len(got))):
+        sel = ((st.mask(i, fl) >> po.slot_of_points(level)) & 1).astype(bool)
+        assert np.array_equal(g[~sel], d0[~sel])
+        assert _rel(g, r_) < 1e-12
+    # Add mode: dst += A src on the selected points
+    upload(dst, dst0, level)
+    A.apply(src, dst, level, fl, host.Add)
+    got2 = download(dst, level)
+    for g2, r_, d0, i in zip(got2, ref, dst0, range(len(got2))):
+        sel = ((st.mask(i, fl) >> po.slot_of_points(level)) & 1).astype(bool)
+        assert np.array_equal(g2[~sel], d0[~sel])
+        assert _rel(g2[sel], (r_ + d0)[sel]) < 1e-12
+    # dot over every DoF exactly once
+    d = src.dot(src, level, fl)
+    assert abs(d - mo.dot(src_h, src_h, level, fl)) < 1e-12 * d
+    for o in (src, dst, A, st):
+        o.close()
+
+
+def test_operator_stencils_match_the_oracle_assembly(env):
+    torch, capi, host, po = env
+    st = _storage(host, "regular_octahedron_8el")
+    A = host.P1ConstantOperator(st, 2, 4)
+    M = host.P1ConstantOperator(st, 2, 3, form=1)
+    for i in range(st.n_local_cells):
+        gid, co, nnc = st.local_cell(i)
+        for level in (2, 4):
+            inner, slots = A.stencils(gid, level)
+            assert np.allclose(inner, po.assemble_cell_stencil(co, level), rtol=0, atol=1e-15)
+            assert np.allclose(slots, po.assemble_cell_slot_stencils(co, level), rtol=0, atol=1e-15)
+        inner, slots = M.stencils(gid, 3)
+        assert np.allclose(inner, po.assemble_cell_stencil(co, 3, 1), rtol=0, atol=1e-18)
+    for o in (A, M, st):
+        o.close()
+
+
+@pytest.mark.parametrize("mesh", ["tet_1el", "regular_octahedron_8el"])
+def test_jacobi_sweeps_match_the_reference_composition(env, mesh):
+    """smooth_jac == apply ; rhs - . ; invDiag .* ; src + relax * .  (P1Operator.hpp:429-447) on all inner DoFs;
+    as in tests/hyteg/convergence/P1JacobiConvergenceTest.cpp the residual must decrease sweep by sweep."""
+    torch, capi, host, po = env
+    from hostutil import MultiCellOracle, download, upload
+
+    level = 3
+    st = _storage(host, mesh)
+    mo = MultiCellOracle(st)
+    A = host.P1ConstantOperator(st, level, level)
+    A.compute_inverse_diagonal()
+    invd = A.inverse_diagonal(level, level)
+    x, y, b, t = (host.P1Function(st, n, level, level) for n in ("x", "y", "b", "t"))
+    x_h = mo.interpolate(lambda X, Y, Z: np.cos(9 * X) * np.sin(7 * Y + Z), level)
+    upload(x, x_h, level)
+    b.interpolate(0.0, level, host.All)
+    relax = 2.0 / 3.0
+    # reference composition with the library's own vector kernels
+    A.apply(x, t, level, host.Inner)
+    t.assign([1.0, -1.0], [b, t], level, host.Inner)
+    t.mult_elementwise([invd, t], level, host.Inner)
+    t.assign([1.0, relax], [x, t], level, host.Inner)
+    y.assign([1.0], [x], level, host.All)
+    A.smooth_jac(y, b, x, relax, level, host.Inner)
+    # compare only inner DoFs (t holds garbage elsewhere)
+    for i, (g, r_) in enumerate(zip(download(y, level), download(t, level))):
+        sel = ((st.mask(i, host.Inner) >> po.slot_of_points(level)) & 1).astype(bool)
+        assert _rel(g[sel], r_[sel]) < 1e-12
+    # inverse diagonal: interior = 1/w_c, shared = 1/sum of shares
+    gid, co, nnc = st.local_cell(0)
+    inner, slots = A.stencils(gid, level)
+    iv = invd.download_cell(0, level)
+    assert np.allclose(iv[po.slot_of_points(level) == 14], 1.0 / inner[7], rtol=1e-15)
+    # residual decreases monotonically under damped Jacobi
+    def resnorm(f):
+        A.apply(f, t, level, host.Inner)
+        t.assign([1.0, -1.0], [b, t], level, host.Inner)
+        return np.sqrt(t.dot(t, level, host.Inner))
+    last = resnorm(x)
+    cur, nxt = x, y
+    for _ in range(5):
+        A.smooth_jac(nxt, b, cur, relax, level, host.Inner)
+        cur, nxt = nxt, cur
+        r = resnorm(cur)
+        assert r < last
+        last = r
+    for o in (x, y, b, t, A, st):
+        o.close()
+
+
+@pytest.mark.parametrize("mesh", ["tet_1el", "regular_octahedron_8el", "cube_6el"])
+@pytest.mark.parametrize("lower", [1, 2, 3])
+def test_prolongation_reproduces_linears_across_macro_cells(env, mesh, lower):
+    """tests/hyteg/vertexdofspace/VertexDoFLinearProlongation3DTest.cpp:46-137: u(l+1) - interpolate(l+1) on
+    Inner | NeumannBoundary DoFs, squared error < 1e-15 (scaled by the magnitude of the data)."""
+    torch, capi, host, po = env
+    from hostutil import MultiCellOracle, download, upload
+
+    st = _storage(host, mesh)
+    mo = MultiCellOracle(st)
+    u = host.P1Function(st, "u", lower, lower + 1)
+    flag = host.Inner | host.NeumannBoundary
+    for fn in (lambda x, y, z: 0 * x + 42.0, lambda x, y, z: 42 * x + y):
+        upload(u, mo.interpolate(fn, lower), lower)
+        u.interpolate(123.0, lower + 1, host.All)
+        host.prolongate(u, lower, flag)
+        exact = mo.interpolate(fn, lower + 1)
+        for i, (g, e) in enumerate(zip(download(u, lower + 1), exact)):
+            sel = ((st.mask(i, flag) >> po.slot_of_points(lower + 1)) & 1).astype(bool)
+            assert float(((g - e)[sel] ** 2).sum()) < 1e-15 * max(1.0, float((e ** 2).max()))
+            assert np.all(g[~sel] == 123.0)
+    for o in (u, st):
+        o.close()
+
+
+@pytest.mark.parametrize("mesh", ["regular_octahedron_8el", "pyramid_4el"])
+def test_restriction_is_the_transpose_of_prolongation_on_the_whole_mesh(env, mesh):
+    """<R f, c> == <f, P c> over all DoFs counted once: checks the 1/numNeighborCells scaling together with the
+    additive exchange (P1toP1LinearRestriction.cpp:193-243, 343-345)."""
+    torch, capi, host, po = env
+    from hostutil import MultiCellOracle, upload
+
+    st = _storage(host, mesh)
+    st.set_boundary_type(host.NeumannBoundary)  # every DoF participates
+    mo = MultiCellOracle(st)
+    mo.boundary_type = host.NeumannBoundary
+    lc = 2
+    f = host.P1Function(st, "f", lc, lc + 1)
+    f0 = host.P1Function(st, "f0", lc, lc + 1)
+    c = host.P1Function(st, "c", lc, lc + 1)
+    upload(f, mo.interpolate(lambda x, y, z: np.sin(3 * x + y) + z * z, lc + 1), lc + 1)
+    f0.assign([1.0], [f], lc + 1, host.All)
+    upload(c, mo.interpolate(lambda x, y, z: np.cos(2 * x - y + 4 * z), lc), lc)
+    host.restrict(f, lc + 1, host.All)                 # f(lc) = R f(lc+1)
+    lhs = f.dot(c, lc, host.All)
+    host.prolongate(c, lc, host.All)                   # c(lc+1) = P c(lc)
+    rhs = f0.dot(c, lc + 1, host.All)
+    assert abs(lhs - rhs) < 1e-11 * abs(rhs)
+    for o in (f, f0, c, st):
+        o.close()
+
+
+def _vcycle_residuals(host, st, min_level, max_level, smoother, relax, ncycles, seed=0):
+    from hostutil import MultiCellOracle, upload
+
+    mo = MultiCellOracle(st)
+    A = host.P1ConstantOperator(st, min_level, max_level)
+    A.compute_inverse_diagonal()
+    x, b, r = (host.P1Function(st, n, min_level, max_level) for n in ("x", "b", "r"))
+    upload(x, mo.interpolate(lambda X, Y, Z: np.sin(11 * X) * np.cos(5 * Y) + Z * X, max_level), max_level)
+    x.interpolate(0.0, max_level, host.DirichletBoundary)
+    b.interpolate(0.0, max_level, host.All)
+    gmg = host.Solver.gmg(st, min_level, max_level, smoother=smoother, relax=relax, pre=3, post=3)
+    flag = host.Inner | host.NeumannBoundary
+
+    def res2():
+        A.apply(x, r, max_level, flag)
+        r.assign([1.0, -1.0], [b, r], max_level, flag)
+        return r.dot(r, max_level, flag)
+
+    out = [res2()]
+    for _ in range(ncycles):
+        gmg.solve(A, x, b, max_level)
+        out.append(res2())
+    for o in (gmg, x, b, r, A):
+        o.close()
+    return out
+
+
+def test_gmg_v33_gauss_seidel_single_macro_cell(env):
+    """tests/hyteg/convergence/P1GMG3DConvergenceTest.cpp:114-146: V(3,3) with Gauss-Seidel, squared residual
+    ratio < 3.2e-2 per cycle (here on one macro-tet, levels 2..5, exact lexicographic GS through the hyperplane kernel)."""
+    torch, capi, host, po = env
+    st = _storage(host, "tet_1el")
+    res = _vcycle_residuals(host, st, 2, 5, host.GAUSS_SEIDEL, 1.0, 4)
+    for k in range(1, len(res)):
+        assert res[k] / res[k - 1] < 3.2e-2
+    st.close()
+
+
+def test_gmg_v33_jacobi_eight_macro_cells(env):
+    """Same V(3,3) cycle on regular_octahedron_8el (the mesh of P1GMG3DConvergenceTest.cpp:52) with the weighted-Jacobi
+    smoother (SOR on shared macro-faces/edges/vertices is not implemented yet).  Damped Jacobi smooths less than
+    Gauss-Seidel, so the bound is the looser 0.15 per cycle in the squared residual (measured: ~0.05)."""
+    torch, capi, host, po = env
+    st = _storage(host, "regular_octahedron_8el")
+    res = _vcycle_residuals(host, st, 2, 4, host.JACOBI, 2.0 / 3.0, 4)
+    for k in range(1, len(res)):
+        assert res[k] / res[k - 1] < 0.15
+    st.close()
+
+
+def test_cg_solves_the_coarse_problem(env):
+    torch, capi, host, po = env
+    from hostutil import MultiCellOracle, upload
+
+    st = _storage(host, "regular_octahedron_8el")
+    level = 2
+    mo = MultiCellOracle(st)
+    A = host.P1ConstantOperator(st, level, level)
+    x, b, r, xe = (host.P1Function(st, n, level, level) for n in ("x", "b", "r", "xe"))
+    upload(xe, mo.interpolate(lambda X, Y, Z: X * (1 - X) * Y + Z, level), level)
+    xe.interpolate(0.0, level, host.DirichletBoundary)
+    A.apply(xe, b, level, host.Inner)
+    cg = host.Solver.cg(st, level, level, 200, 1e-14)
+    cg.solve(A, x, b, level)
+    r.assign([1.0, -1.0], [x, xe], level, host.Inner)
+    assert np.sqrt(r.dot(r, level, host.Inner)) < 1e-10 * np.sqrt(xe.dot(xe, level, host.Inner))
+    for o in (cg, x, b, r, xe, A, st):
+        o.close()
