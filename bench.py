@@ -3,11 +3,13 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--level L] [--no-cpu-baseline]
 
-A "step" is ONE P1ConstantLaplaceOperator::apply(src, dst, level, Inner, Replace) over the rank's macro-cell
-(one kernel launch through the C-ABI).  Inputs are resident in HBM before the timed region; a ring of
-buffer pairs larger than the 256 MiB Infinity Cache is cycled so that every launch streams from HBM.
-For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank owns one macro-cell
-(weak scaling); rank 0 prints ONE JSON line with the whole-job aggregate.
+A "step" is ONE P1ConstantLaplaceOperator::apply(src, dst, level, Inner, Replace) through the C++ host layer
+(hyteg_amd/host, the mirror of HyTeG's operator API), which calls the HIP kernels through the C-ABI.  Inputs are
+resident in HBM before the timed region; a ring of function pairs larger than the 256 MiB Infinity Cache is cycled
+so that every apply streams from HBM.  For N > 1 (launched by torch.distributed.run, one rank per GPU) the mesh has
+N macro-cells, one per GPU (weak scaling); the shares of the macro-face/edge/vertex DoFs the cells have in common
+are exchanged over RCCL inside every apply, overlapped with the interior kernel.  Rank 0 prints ONE JSON line with
+the whole-job aggregate.
 
 value      = (interior DoFs per cell) * (cells) * K / (max over ranks of the timed region)
 roofline   = algorithmic bytes per launch (16 B per DoF-update) / average launch duration
@@ -30,16 +32,6 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 MALL_BYTES = 256 * 1024 * 1024
 REF_TET = ((0.0, 0.0, 0.0), (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0))
-
-
-def laplace_stencil(level: int):
-    """15 Laplace weights of the unit reference tet at `level`.  The level-2 weights are exact rationals
-    (multiples of h/3 with h = 1/4); HyTeG's weights scale by 1/2 per level
-    (tests/hyteg/vertexdofspace/VertexDoFStencilAssemblyTest.cpp:85).  Order: include/hyteg_hip.h."""
-    h = 0.25
-    t = h / 3.0
-    lvl2 = [-4 * t, t, t, -t, -2 * t, -t, -4 * t, 20 * t, -4 * t, -t, -2 * t, -t, t, t, -4 * t]
-    return [v * 0.5 ** (level - 2) for v in lvl2]
 
 
 def cpu_baseline(level: int, w, budget_s: float = 12.0):
@@ -81,6 +73,9 @@ def cpu_baseline(level: int, w, budget_s: float = 12.0):
     }
 
 
+MESH_FOR_WORLD = {1: "tet_1el", 2: "pyramid_2el", 4: "pyramid_4el", 8: "regular_octahedron_8el"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,9 +85,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    import numpy as np
     import torch
 
-    from hyteg_amd import capi
+    from hyteg_amd import capi, host
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -101,6 +97,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if world not in MESH_FOR_WORLD:
+        raise SystemExit(f"bench.py supports 1, 2, 4 or 8 GPUs (one macro-cell per GPU), not {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
     torch.cuda.set_device(local_rank)
@@ -113,25 +111,42 @@ def main():
 
     level = args.level
     capi.lib()
+    host.lib()
     capi.prepare_level(level)
     n = capi.cell_size(level)
-    inner = capi.cell_inner_size(level)
-    w = laplace_stencil(level)
 
-    # ring of buffer pairs > Infinity Cache so that each launch reads and writes HBM
-    pair_bytes = 2 * n * 8
-    nbuf = max(2, -(-int(1.5 * MALL_BYTES) // pair_bytes))
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(42 + rank)
-    srcs = [torch.rand(n, dtype=torch.float64, device="cuda", generator=gen) for _ in range(nbuf)]
-    dsts = [torch.zeros(n, dtype=torch.float64, device="cuda") for _ in range(nbuf)]
-    sp = [t.data_ptr() for t in srcs]
-    dp = [t.data_ptr() for t in dsts]
+    # one level-`level` macro-cell per GPU: meshes of 1, 2, 4, 8 tetrahedra from the reference's test data; the cells of
+    # a rank-r process are those with (cell id % world) == r (HyTeG's round-robin default)
+    mesh = ROOT / "tests" / "golden" / "meshes" / f"{MESH_FOR_WORLD[world]}.msh"
+    storage = host.Storage.from_gmsh(mesh, rank, world)
     stream = torch.cuda.current_stream()
-    sh = stream.cuda_stream
+    storage.set_stream(stream.cuda_stream)
+    ctx = None
+    if world > 1:
+        from hyteg_amd.distributed import DistributedContext
+
+        ctx = DistributedContext(storage, [level], torch.device("cuda", local_rank))
+    laplace = host.P1ConstantOperator(storage, level, level)  # assembles the cell / face / edge / vertex stencils
+
+    # ring of function pairs > Infinity Cache so that each apply reads and writes HBM
+    pair_bytes = 2 * n * 8 * storage.n_local_cells
+    nbuf = max(2, -(-int(1.5 * MALL_BYTES) // pair_bytes))
+    rng = np.random.default_rng(42 + rank)
+    srcs = [host.P1Function(storage, f"src{k}", level, level) for k in range(nbuf)]
+    dsts = [host.P1Function(storage, f"dst{k}", level, level) for k in range(nbuf)]
+    for f in srcs:
+        for c in range(storage.n_local_cells):
+            f.upload_cell(c, level, rng.random(n))
+        f.sync_shared(level, host.All)  # copies of a shared DoF hold one value
+    one = host.P1Function(storage, "one", level, level)
+    one.interpolate(1.0, level, host.All)
+    inner_dofs = int(round(one.dot(one, level, host.Inner)))  # global number of DoFs an apply(..., Inner) updates
+    one.close()
 
     def step(k):
-        capi.p1_apply_cell(dp[k % nbuf], sp[k % nbuf], level, w, capi.REPLACE, sh)
+        # P1ConstantLaplaceOperator::apply( src, dst, level, Inner, Replace ): boundary shares -> halo exchange started
+        # -> interior stencil kernel (overlaps the exchange) -> reduction of the shares
+        laplace.apply(srcs[k % nbuf], dsts[k % nbuf], level, host.Inner, host.Replace)
 
     for k in range(args.warmup):
         step(k)
@@ -150,7 +165,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream
+    dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels are launched on
 
     if dist is not None:
         tmax = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device="cuda")
@@ -158,19 +173,21 @@ def main():
         elapsed, dev_ms = float(tmax[0]), float(tmax[1])
 
     if rank == 0:
+        w = laplace.stencils(0, level)[0]
         launch_us = dev_ms * 1e3 / args.steps
-        algo_bytes = 16 * inner  # 8 B compulsory src read + 8 B dst write per DoF-update
+        cell_inner = capi.cell_inner_size(level)
+        algo_bytes = 16 * cell_inner  # 8 B compulsory src read + 8 B dst write per DoF-update, one cell
         achieved = algo_bytes / (launch_us * 1e-6) / 1e9
         traffic = None
         tfile = ROOT / "profiles" / "pmc_traffic.json"
         if tfile.exists():
             try:
-                traffic = json.loads(tfile.read_text()).get("p1_apply_tiled_kernel_bytes_per_launch")
+                traffic = json.loads(tfile.read_text()).get("p1_apply_zmarch_kernel_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
             "metric": "DoF-updates/s, P1 Laplace apply() level 8",
-            "value": inner * world * args.steps / elapsed,
+            "value": inner_dofs * args.steps / elapsed,
             "unit": "DoF-updates/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -182,28 +199,32 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"P1ConstantLaplaceOperator::apply(Replace), one level-{level} macro-cell per GPU "
-                            f"(unit reference tet, {n} entries, {inner} DoF-updates per apply), "
-                            f"{nbuf} rotating buffer pairs ({nbuf * pair_bytes / 2**20:.0f} MiB > 256 MiB Infinity Cache)",
+                "workload": f"P1ConstantLaplaceOperator::apply(src, dst, level {level}, Inner, Replace) through the host layer, "
+                            f"one level-{level} macro-cell per GPU ({MESH_FOR_WORLD[world]}.msh, {n} entries per cell array, "
+                            f"{inner_dofs} inner DoF-updates per apply over all GPUs), "
+                            f"{nbuf} rotating function pairs ({nbuf * pair_bytes / 2**20:.0f} MiB per GPU > 256 MiB Infinity Cache)",
                 "level": level,
                 "macro_cells": world,
-                "halo_exchange": False if world > 1 else None,
+                "halo_exchange": ("RCCL all_to_all of shared face/edge/vertex shares, overlapped with the interior kernel"
+                                  if world > 1 else None),
                 "device": capi.device_name(),
             },
             "roofline": {
                 "bound": "hbm",
                 "kernel": "p1_apply_zmarch_kernel<REPLACE,4,4>",
-                "achieved": achieved,
+                "achieved": achieved if world == 1 else None,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
+                "frac": achieved / HBM_PEAK_GBS if world == 1 else None,
                 "traffic": traffic,
                 "launch_us": launch_us,
                 "algorithmic_bytes_per_launch": algo_bytes,
+                "note": "achieved = algorithmic bytes of one cell's interior kernel / time per apply on the launch stream"
+                        " (N=1: one kernel per apply)",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(level, w)
+            out["cpu_baseline"] = cpu_baseline(level, list(w))
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

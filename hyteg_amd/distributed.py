@@ -1,0 +1,84 @@
+"""torch.distributed plumbing for storages partitioned over several ranks (one process per GPU).
+
+The C++ host layer (hyteg_amd/host/hyteg_host.hpp) packs the partial values of shared macro-face/edge/vertex DoFs
+into one send buffer per (level, boundary class), calls the `exchange` hook, and then reduces local and received
+values in a fixed order.  This module owns the buffers (torch tensors, so that the RCCL / gloo backends can move
+them) and implements the two hooks:
+
+  exchange(level, cls):   dist.all_to_all_single over the registered send/recv tensors, split per peer rank
+                          (neighbour exchange: ranks that share no primitive exchange 0 elements);
+  allreduce_sum(v, n):    dist.all_reduce(SUM) of n doubles  (walberla::mpi::allReduceInplace in
+                          src/hyteg/p1functionspace/VertexDoFFunction.cpp:1717).
+
+Backend "nccl" is RCCL over xGMI on ROCm; backend "gloo" with CPU tensors is used by the CPU tests, which emulate the
+pack / reduce kernels with numpy on the exported plan (tests/test_distributed_gloo.py)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import host
+
+
+class DistributedContext:
+    def __init__(self, storage: host.Storage, levels, device: torch.device | str):
+        self.storage = storage
+        self.device = torch.device(device)
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.buffers = {}
+        self.plans = {}
+        for level in levels:
+            for cls in (0, 1):
+                p = storage.plan(level, cls)
+                self.plans[(level, cls)] = p
+                if len(p["peers"]) == 0:
+                    continue
+                send = torch.zeros(max(1, p["total_send"]), dtype=torch.float64, device=self.device)
+                recv = torch.zeros(max(1, p["total_recv"]), dtype=torch.float64, device=self.device)
+                in_splits = [0] * self.world
+                out_splits = [0] * self.world
+                for k, peer in enumerate(p["peers"]):
+                    in_splits[int(peer)] = int(p["send_count"][k])
+                    out_splits[int(peer)] = int(p["recv_count"][k])
+                self.buffers[(level, cls)] = (send, recv, in_splits, out_splits)
+                if self.device.type == "cuda":
+                    storage.register_comm_buffers(level, cls, send.data_ptr(), recv.data_ptr())
+        self._scalar = torch.zeros(8, dtype=torch.float64, device=self.device)
+        self._pending = {}
+        storage.set_hooks(self.exchange_begin, self.exchange_end, self.allreduce_sum)
+
+    def send_tensor(self, level, cls):
+        return self.buffers[(level, cls)][0]
+
+    def recv_tensor(self, level, cls):
+        return self.buffers[(level, cls)][1]
+
+    # ---- hooks ----
+    def exchange_begin(self, level: int, cls: int) -> None:
+        """start the neighbour all-to-all; the pack kernel ran on torch's current stream (= the storage's stream) and
+        the collective orders itself after it.  Returns immediately: kernels launched next overlap the transfer."""
+        if (level, cls) not in self.buffers:
+            return
+        send, recv, in_splits, out_splits = self.buffers[(level, cls)]
+        n_in, n_out = sum(in_splits), sum(out_splits)
+        self._pending[(level, cls)] = dist.all_to_all_single(recv[:n_out], send[:n_in], out_splits, in_splits, async_op=True)
+
+    def exchange_end(self, level: int, cls: int) -> None:
+        work = self._pending.pop((level, cls), None)
+        if work is not None:
+            work.wait()  # makes the current stream wait for the collective (no host sync on the nccl backend)
+
+    def exchange(self, level: int, cls: int) -> None:
+        self.exchange_begin(level, cls)
+        self.exchange_end(level, cls)
+
+    def allreduce_sum(self, values, n: int) -> None:
+        arr = np.ctypeslib.as_array(values, shape=(n,))
+        t = self._scalar[:n] if n <= self._scalar.numel() else torch.zeros(n, dtype=torch.float64, device=self.device)
+        t.copy_(torch.from_numpy(arr.copy()))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        arr[:] = t.cpu().numpy()

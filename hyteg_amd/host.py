@@ -30,7 +30,7 @@ SIGNATURES = {
     "hyteg_host_storage_mask": (_i, [_vp, _i, _i, _i, C.POINTER(_u)]),
     "hyteg_host_storage_set_boundary_type": (_i, [_vp, _i]),
     "hyteg_host_storage_set_stream": (_i, [_vp, _vp]),
-    "hyteg_host_storage_set_hooks": (_i, [_vp, EXCHANGE_CB, ALLREDUCE_CB, _vp]),
+    "hyteg_host_storage_set_hooks": (_i, [_vp, EXCHANGE_CB, EXCHANGE_CB, ALLREDUCE_CB, _vp]),
     "hyteg_host_plan_sizes": (_i, [_vp, _i, _i, _ip]),
     "hyteg_host_plan_export": (_i, [_vp, _i, _i, _ip, _ip, _ip, _ip, _ip, _ip, _ip, _ip]),
     "hyteg_host_plan_register_buffers": (_i, [_vp, _i, _i, _vp, _vp]),
@@ -147,11 +147,12 @@ class Storage:
     def set_stream(self, stream):
         _ck(lib().hyteg_host_storage_set_stream(self.h, stream), "set_stream")
 
-    def set_hooks(self, exchange, allreduce_sum):
-        ex = EXCHANGE_CB(lambda user, level, cls: exchange(level, cls))
+    def set_hooks(self, exchange_begin, exchange_end, allreduce_sum):
+        exb = EXCHANGE_CB(lambda user, level, cls: exchange_begin(level, cls))
+        exe = EXCHANGE_CB(lambda user, level, cls: exchange_end(level, cls))
         ar = ALLREDUCE_CB(lambda user, values, n: allreduce_sum(values, n))
-        self._hooks = (ex, ar)  # keep alive
-        _ck(lib().hyteg_host_storage_set_hooks(self.h, ex, ar, None), "set_hooks")
+        self._hooks = (exb, exe, ar)  # keep alive
+        _ck(lib().hyteg_host_storage_set_hooks(self.h, exb, exe, ar, None), "set_hooks")
 
     def plan(self, level, cls):
         s = (C.c_int * 5)()

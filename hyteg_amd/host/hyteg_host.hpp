@@ -253,8 +253,10 @@ struct MacroPrimitive
 // callbacks for storages distributed over several ranks (set by the embedding application; see hyteg_amd/host.py)
 struct CommHooks
 {
-   // all-to-all of the packed partial values of one (level, boundary class); buffers were registered before
-   void ( *exchange )( void* user, int level, int cls ) = nullptr;
+   // all-to-all of the packed partial values of one (level, boundary class); buffers were registered before.
+   // Begin may return before the data has arrived (so that interior kernels overlap the transfer); End waits.
+   void ( *exchangeBegin )( void* user, int level, int cls ) = nullptr;
+   void ( *exchangeEnd )( void* user, int level, int cls )   = nullptr;
    // in-place sum over all ranks of n doubles in host memory (walberla::mpi::allReduceInplace, VertexDoFFunction.cpp:1717)
    void ( *allreduceSum )( void* user, double* values, int n ) = nullptr;
    void* user                                                   = nullptr;
@@ -811,9 +813,21 @@ class P1Function
 
    // ---- shared-point exchange (the cell-centric replacement of communicate<> / communicateAdditively<>) ----
    // additive: every copy of a shared DoF := sum of all copies (VertexDoFAdditivePackInfo.hpp:676-745 + copy back)
-   void sumSharedCopies( uint_t level, DoFType flag = All ) const { exchange( level, flag, true ); }
+   void sumSharedCopies( uint_t level, DoFType flag = All ) const
+   {
+      exchangeBegin( level, flag );
+      exchangeEnd( level, flag, true );
+   }
    // every copy := the copy held by the lowest-numbered neighbour cell
-   void syncSharedCopies( uint_t level, DoFType flag = All ) const { exchange( level, flag, false ); }
+   void syncSharedCopies( uint_t level, DoFType flag = All ) const
+   {
+      exchangeBegin( level, flag );
+      exchangeEnd( level, flag, false );
+   }
+   // split form: pack + start the transfer / wait + reduce.  Kernels that do not touch shared points may be
+   // launched in between (the interior apply overlaps the halo exchange).
+   void beginSumSharedCopies( uint_t level, DoFType flag = All ) const { exchangeBegin( level, flag ); }
+   void endSumSharedCopies( uint_t level, DoFType flag = All ) const { exchangeEnd( level, flag, true ); }
 
    void copyCellToHost( uint_t c, uint_t level, double* host ) const
    {
@@ -890,9 +904,26 @@ class P1Function
       return it->second;
    }
 
-   void exchange( uint_t level, DoFType flag, bool additive ) const
+   void exchangeBegin( uint_t level, DoFType flag ) const
    {
       checkLevel( level );
+      if ( storage_->numRanks() == 1 )
+         return;
+      for ( int cls = 0; cls < 2; ++cls )
+      {
+         if ( !testFlag( storage_->boundaryTypeOf( cls == 1 ), flag ) || storage_->exchangePlan( (int) level, cls ).peers.empty() )
+            continue;
+         const auto& plan  = storage_->devicePlan( (int) level, cls );
+         double**    bases = basesFor( level, cls );
+         hipCheck( hyteg_hip_gather_entries( plan.sendBuffer, bases, plan.dSendBuf, plan.dSendOff, plan.totalSend(), storage_->stream() ),
+                   "exchange: pack" );
+         if ( !storage_->hooks().exchangeBegin || !storage_->hooks().exchangeEnd )
+            throw std::runtime_error( "exchange: storage is distributed but no exchange hooks are set" );
+         storage_->hooks().exchangeBegin( storage_->hooks().user, (int) level, cls );
+      }
+   }
+   void exchangeEnd( uint_t level, DoFType flag, bool additive ) const
+   {
       for ( int cls = 0; cls < 2; ++cls )
       {
          if ( !testFlag( storage_->boundaryTypeOf( cls == 1 ), flag ) )
@@ -902,13 +933,7 @@ class P1Function
          const auto& plan  = storage_->devicePlan( (int) level, cls );
          double**    bases = basesFor( level, cls );
          if ( !plan.peers.empty() )
-         {
-            hipCheck( hyteg_hip_gather_entries( plan.sendBuffer, bases, plan.dSendBuf, plan.dSendOff, plan.totalSend(), storage_->stream() ),
-                      "exchange: pack" );
-            if ( !storage_->hooks().exchange )
-               throw std::runtime_error( "exchange: storage is distributed but no exchange hook is set" );
-            storage_->hooks().exchange( storage_->hooks().user, (int) level, cls );
-         }
+            storage_->hooks().exchangeEnd( storage_->hooks().user, (int) level, cls );
          hipCheck( additive ? hyteg_hip_sum_shared( bases, plan.dGroupPtr, plan.dEntryBuf, plan.dEntryOff, plan.ngroups(),
                                                     (int) storage_->getNumberOfLocalCells(), storage_->stream() )
                             : hyteg_hip_copy_shared( bases, plan.dGroupPtr, plan.dEntryBuf, plan.dEntryOff, plan.ngroups(),
@@ -1103,20 +1128,26 @@ class P1ConstantOperator
          tmp.reset( new P1Function< double >( "apply_tmp", storage_, level, level ) );
          shellDst = tmp.get();
       }
+      // 1. this cell's share of the shared macro-face/edge/vertex DoFs (tiny kernels), 2. start the halo exchange,
+      // 3. the interior stencil while the exchange is in flight, 4. reduce the shares
       forCells( [&]( uint_t c, const MacroCell& cell ) {
-         const auto&    S    = getCellStencils( cell.id, level );
-         const unsigned mask = storage_->maskFor( cell, flag );
-         if ( ( mask & HYTEG_HIP_MASK_INNER ) && level >= HYTEG_HIP_MIN_LEVEL )
-            hipCheck( hyteg_hip_p1_apply_cell( dst.getCellPointer( c, level ), src.getCellPointer( c, level ), (int) level, S.inner,
-                                               updateType == Replace ? HYTEG_HIP_REPLACE : HYTEG_HIP_ADD, storage_->stream() ),
-                      "apply: cell" );
+         const auto& S = getCellStencils( cell.id, level );
          hipCheck( hyteg_hip_p1_apply_cell_boundary( shellDst->getCellPointer( c, level ), src.getCellPointer( c, level ), (int) level,
-                                                     &S.slots[0][0], mask,
+                                                     &S.slots[0][0], storage_->maskFor( cell, flag ),
                                                      ( updateType == Add && shellDst == &dst ) ? HYTEG_HIP_ADD : HYTEG_HIP_REPLACE,
                                                      storage_->stream() ),
                    "apply: boundary" );
       } );
-      shellDst->sumSharedCopies( level, flag );
+      shellDst->beginSumSharedCopies( level, flag );
+      forCells( [&]( uint_t c, const MacroCell& cell ) {
+         const unsigned mask = storage_->maskFor( cell, flag );
+         if ( ( mask & HYTEG_HIP_MASK_INNER ) && level >= HYTEG_HIP_MIN_LEVEL )
+            hipCheck( hyteg_hip_p1_apply_cell( dst.getCellPointer( c, level ), src.getCellPointer( c, level ), (int) level,
+                                               getCellStencils( cell.id, level ).inner,
+                                               updateType == Replace ? HYTEG_HIP_REPLACE : HYTEG_HIP_ADD, storage_->stream() ),
+                      "apply: cell" );
+      } );
+      shellDst->endSumSharedCopies( level, flag );
       if ( shellDst != &dst )
       {
          // dst += tmp on the shell points selected by flag

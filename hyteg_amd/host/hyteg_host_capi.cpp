@@ -116,11 +116,13 @@ HYTEG_HOST_API int hyteg_host_storage_set_stream( hh_storage_t s, void* stream )
 {
    return guarded( [&] { S( s ).setStream( stream ); } );
 }
-HYTEG_HOST_API int hyteg_host_storage_set_hooks( hh_storage_t s, void ( *ex )( void*, int, int ), void ( *ar )( void*, double*, int ), void* user )
+HYTEG_HOST_API int hyteg_host_storage_set_hooks( hh_storage_t s, void ( *exb )( void*, int, int ), void ( *exe )( void*, int, int ),
+                                                 void ( *ar )( void*, double*, int ), void* user )
 {
    return guarded( [&] {
       CommHooks h;
-      h.exchange     = ex;
+      h.exchangeBegin = exb;
+      h.exchangeEnd   = exe;
       h.allreduceSum = ar;
       h.user         = user;
       S( s ).setCommHooks( h );

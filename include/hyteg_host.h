@@ -39,8 +39,11 @@ HYTEG_HOST_API int hyteg_host_storage_local_cell( hh_storage_t s, int local_inde
 HYTEG_HOST_API int hyteg_host_storage_mask( hh_storage_t s, int local_index, int flag, int owned, unsigned* mask );
 HYTEG_HOST_API int hyteg_host_storage_set_boundary_type( hh_storage_t s, int dof_type );
 HYTEG_HOST_API int hyteg_host_storage_set_stream( hh_storage_t s, void* stream );
-/* multi-rank hooks: exchange( user, level, cls ), allreduce_sum( user, values, n ) */
-HYTEG_HOST_API int hyteg_host_storage_set_hooks( hh_storage_t s, void ( *exchange )( void*, int, int ), void ( *allreduce_sum )( void*, double*, int ), void* user );
+/* multi-rank hooks: exchange_begin( user, level, cls ) starts the all-to-all of the packed send buffer (may return
+ * before completion), exchange_end( user, level, cls ) waits for it; allreduce_sum( user, values, n ) */
+HYTEG_HOST_API int hyteg_host_storage_set_hooks( hh_storage_t s, void ( *exchange_begin )( void*, int, int ),
+                                                 void ( *exchange_end )( void*, int, int ),
+                                                 void ( *allreduce_sum )( void*, double*, int ), void* user );
 /* exchange plan of (level, cls) -- host data, works without a GPU.
  * sizes[0..4] = ngroups, nentries, npeers, total_send, total_recv */
 HYTEG_HOST_API int hyteg_host_plan_sizes( hh_storage_t s, int level, int cls, int* sizes );
