@@ -218,7 +218,9 @@ int main( int argc, char** argv )
    // copy kernel (same bytes as an apply: read total, write total)
    for ( int grid : { 1024, 2048, 4096 } )
    {
-      if ( !want( "copy" ) )
+      if ( !want( "copy" ) && strstr( filter, "copy" ) != filter )
+         break;
+      if ( strstr( filter, "copy " ) == filter )
          break;
       for ( int r = 0; r < 10; ++r )
          hipLaunchKernelGGL( copy_kernel, dim3( grid ), dim3( 256 ), 0, 0, (double2*) dst[r % nbuf], (const double2*) src[r % nbuf], total / 2 );
@@ -234,10 +236,12 @@ int main( int argc, char** argv )
       report( nm, ms, 0.0 );
    }
 
-   if ( want( "copy" ) )
+   if ( want( "copy" ) || strstr( filter, "copy" ) == filter )
    {
       typedef double __attribute__( ( ext_vector_type( 2 ) ) ) d2;
       auto timeit = [&]( const char* nm, auto&& launch ) {
+         if ( strstr( filter, "copy " ) == filter && strcmp( filter, nm ) != 0 && strstr( nm, filter ) == nullptr )
+            return;
          for ( int r = 0; r < 10; ++r )
             launch( r % nbuf );
          CK( hipEventRecord( e0 ) );

@@ -96,6 +96,16 @@ int get_tiles( int level, TileKind kind, int capacity, TileTable* out )
 
 int get_bricks( int level, int NY, int LZ, BrickTable* out )
 {
+   // hot path: the same (level, shape) is asked for on every launch
+   thread_local int        lastKey[4] = { -1, -1, -1, -1 };
+   thread_local BrickTable lastVal;
+   int                     dev0 = 0;
+   HH_CHECK_HIP( hipGetDevice( &dev0 ) );
+   if ( lastKey[0] == dev0 && lastKey[1] == level && lastKey[2] == NY && lastKey[3] == LZ )
+   {
+      *out = lastVal;
+      return HYTEG_HIP_OK;
+   }
    static std::mutex                                             mtx;
    static std::map< std::tuple< int, int, int, int >, BrickTable > cache;
    int                                                           dev = 0;
@@ -105,7 +115,9 @@ int get_bricks( int level, int NY, int LZ, BrickTable* out )
    auto                          it  = cache.find( key );
    if ( it != cache.end() )
    {
-      *out = it->second;
+      *out       = it->second;
+      lastKey[0] = dev, lastKey[1] = level, lastKey[2] = NY, lastKey[3] = LZ;
+      lastVal    = it->second;
       return HYTEG_HIP_OK;
    }
    std::vector< BrickTask > host;
@@ -121,6 +133,8 @@ int get_bricks( int level, int NY, int LZ, BrickTable* out )
    }
    cache[key] = bt;
    *out       = bt;
+   lastKey[0] = dev, lastKey[1] = level, lastKey[2] = NY, lastKey[3] = LZ;
+   lastVal    = bt;
    return HYTEG_HIP_OK;
 }
 

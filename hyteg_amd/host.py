@@ -50,6 +50,7 @@ SIGNATURES = {
     "hyteg_host_operator_destroy": (_i, [_vp]),
     "hyteg_host_operator_stencils": (_i, [_vp, _i, _i, _dp, _dp]),
     "hyteg_host_operator_apply": (_i, [_vp, _vp, _vp, _i, _i, _i]),
+    "hyteg_host_operator_apply_cycle": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i]),
     "hyteg_host_operator_smooth_jac": (_i, [_vp, _vp, _vp, _vp, _d, _i, _i]),
     "hyteg_host_operator_smooth_sor": (_i, [_vp, _vp, _vp, _d, _i, _i, _i]),
     "hyteg_host_operator_compute_inverse_diagonal": (_i, [_vp]),
@@ -259,6 +260,12 @@ class P1ConstantOperator:
 
     def apply(self, src, dst, level, flag, update=Replace):
         _ck(lib().hyteg_host_operator_apply(self.h, src.h, dst.h, level, flag, update), "apply")
+
+    def apply_cycle(self, srcs, dsts, level, flag, update=Replace, first=0, steps=1):
+        """`steps` applies, step k on pair (first + k) % len(srcs): the loop a C++ application writes around apply()"""
+        n = len(srcs)
+        hs, hd = (_vp * n)(*[f.h for f in srcs]), (_vp * n)(*[f.h for f in dsts])
+        _ck(lib().hyteg_host_operator_apply_cycle(self.h, n, hs, hd, level, flag, update, first, steps), "apply_cycle")
 
     def smooth_jac(self, dst, rhs, src, relax, level, flag):
         _ck(lib().hyteg_host_operator_smooth_jac(self.h, dst.h, rhs.h, src.h, float(relax), level, flag), "smooth_jac")

@@ -256,6 +256,17 @@ HYTEG_HOST_API int hyteg_host_operator_apply( hh_operator_t op, hh_function_t sr
 {
    return guarded( [&] { WITH_OP( op, A.apply( F( src ), F( dst ), (uint_t) level, DoFType( flag ), update ? Add : Replace ) ); } );
 }
+HYTEG_HOST_API int hyteg_host_operator_apply_cycle( hh_operator_t op, int npairs, const hh_function_t* srcs, const hh_function_t* dsts, int level,
+                                                    int flag, int update, int first, int steps )
+{
+   return guarded( [&] {
+      for ( int k = 0; k < steps; ++k )
+      {
+         const int j = ( first + k ) % npairs;
+         WITH_OP( op, A.apply( F( srcs[j] ), F( dsts[j] ), (uint_t) level, DoFType( flag ), update ? Add : Replace ) );
+      }
+   } );
+}
 HYTEG_HOST_API int hyteg_host_operator_smooth_jac( hh_operator_t op, hh_function_t dst, hh_function_t rhs, hh_function_t src, double relax, int level, int flag )
 {
    return guarded( [&] { WITH_OP( op, A.smooth_jac( F( dst ), F( rhs ), F( src ), relax, (uint_t) level, DoFType( flag ) ) ); } );

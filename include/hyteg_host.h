@@ -71,6 +71,11 @@ HYTEG_HOST_API int hyteg_host_operator_destroy( hh_operator_t op );
 /* inner[15], slots[14*15] of a GLOBAL cell id */
 HYTEG_HOST_API int hyteg_host_operator_stencils( hh_operator_t op, int global_cell, int level, double* inner15, double* slots210 );
 HYTEG_HOST_API int hyteg_host_operator_apply( hh_operator_t op, hh_function_t src, hh_function_t dst, int level, int flag, int update );
+/* `steps` consecutive applies cycling over `npairs` (src, dst) function pairs: step k uses pair (first + k) % npairs.
+ * The loop a C++ application would write around Operator::apply (apps/benchmarks/ApplyBenchmark/ApplyBenchmark.cpp:95-101);
+ * lets a non-C++ driver time K applies without paying its own per-call overhead K times. */
+HYTEG_HOST_API int hyteg_host_operator_apply_cycle( hh_operator_t op, int npairs, const hh_function_t* srcs, const hh_function_t* dsts,
+                                                    int level, int flag, int update, int first, int steps );
 HYTEG_HOST_API int hyteg_host_operator_smooth_jac( hh_operator_t op, hh_function_t dst, hh_function_t rhs, hh_function_t src, double relax, int level, int flag );
 HYTEG_HOST_API int hyteg_host_operator_smooth_sor( hh_operator_t op, hh_function_t dst, hh_function_t rhs, double relax, int level, int flag, int backwards );
 HYTEG_HOST_API int hyteg_host_operator_compute_inverse_diagonal( hh_operator_t op );
