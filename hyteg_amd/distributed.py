@@ -47,7 +47,10 @@ class DistributedContext:
                 self.buffers[(level, cls)] = (send, recv, in_splits, out_splits)
                 if self.device.type == "cuda":
                     storage.register_comm_buffers(level, cls, send.data_ptr(), recv.data_ptr())
-        self._scalar = torch.zeros(8, dtype=torch.float64, device=self.device)
+        # gloo cannot move device tensors in all_to_all: stage through pinned host memory (test / fallback transport;
+        # the production transport is RCCL, which works on the device buffers directly)
+        self._stage = dist.get_backend() == "gloo" and self.device.type == "cuda"
+        self._scalar = torch.zeros(8, dtype=torch.float64, device="cpu" if self._stage else self.device)
         self._pending = {}
         storage.set_hooks(self.exchange_begin, self.exchange_end, self.allreduce_sum)
 
@@ -65,11 +68,23 @@ class DistributedContext:
             return
         send, recv, in_splits, out_splits = self.buffers[(level, cls)]
         n_in, n_out = sum(in_splits), sum(out_splits)
-        self._pending[(level, cls)] = dist.all_to_all_single(recv[:n_out], send[:n_in], out_splits, in_splits, async_op=True)
+        if self._stage:
+            host_send = send[:n_in].cpu()  # synchronises with the pack kernel on the current stream
+            host_recv = torch.empty(n_out, dtype=torch.float64)
+            work = dist.all_to_all_single(host_recv, host_send, out_splits, in_splits, async_op=True)
+            self._pending[(level, cls)] = (work, host_recv, recv, n_out)
+        else:
+            self._pending[(level, cls)] = dist.all_to_all_single(recv[:n_out], send[:n_in], out_splits, in_splits, async_op=True)
 
     def exchange_end(self, level: int, cls: int) -> None:
         work = self._pending.pop((level, cls), None)
-        if work is not None:
+        if work is None:
+            return
+        if self._stage:
+            w, host_recv, recv, n_out = work
+            w.wait()
+            recv[:n_out].copy_(host_recv)
+        else:
             work.wait()  # makes the current stream wait for the collective (no host sync on the nccl backend)
 
     def exchange(self, level: int, cls: int) -> None:
@@ -78,7 +93,7 @@ class DistributedContext:
 
     def allreduce_sum(self, values, n: int) -> None:
         arr = np.ctypeslib.as_array(values, shape=(n,))
-        t = self._scalar[:n] if n <= self._scalar.numel() else torch.zeros(n, dtype=torch.float64, device=self.device)
+        t = self._scalar[:n] if n <= self._scalar.numel() else torch.zeros(n, dtype=torch.float64, device=self._scalar.device)
         t.copy_(torch.from_numpy(arr.copy()))
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         arr[:] = t.cpu().numpy()
