@@ -37,8 +37,12 @@ inline bool level_ok( int level ) { return level >= HYTEG_HIP_MIN_LEVEL && level
 __host__ __device__ inline int tri( int w ) { return ( w * ( w + 1 ) ) / 2; }
 __host__ __device__ inline int64_t tet64( int64_t w ) { return ( w * ( w + 1 ) * ( w + 2 ) ) / 6; }
 // start of slice z in a cell array of width N
+// tet(w) in 32-bit arithmetic: (w(w+1)/2)(w+2) = 3 tet(w) stays below 2^32 for w <= 1290 (levels <= 10)
+__host__ __device__ inline unsigned tet32( unsigned w ) { return ( ( w * ( w + 1u ) ) >> 1 ) * ( w + 2u ) / 3u; }
 __host__ __device__ inline int slice_start( int N, int z )
 {
+   if ( N <= 1290 )
+      return (int) ( tet32( (unsigned) N ) - tet32( (unsigned) ( N - z ) ) );
    return (int) ( tet64( N ) - tet64( N - z ) );
 }
 // start of row y inside a slice whose row 0 has length W

@@ -154,6 +154,21 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_k
 
       const int W  = Wqs[q];
       int       io = baseq[q] + ( W - ym ); // (xb, y0, z)
+      // ADD / JACOBI read a second (and third) array at the output points: issue those loads now, ahead of the
+      // slice's arithmetic, instead of one dependent round trip per row right before the store
+      double ex0[NY], ex1[NY];
+      if constexpr ( MODE != APPLY_REPLACE )
+      {
+         int ie = io;
+#pragma unroll
+         for ( int j = 0; j < NY; ++j )
+         {
+            const int off = ie * 8 + lane_off;
+            ex0[j]        = MODE == APPLY_ADD ? zm_load( rd, off ) : zm_load( rr, off );
+            ex1[j]        = ( MODE == APPLY_JACOBI && A.invdiag ) ? zm_load( ri, off ) : invc;
+            ie += W - ( t.y0 + j );
+         }
+      }
 #pragma unroll
       for ( int j = 0; j < NY; ++j )
       {
@@ -189,13 +204,9 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_k
          if ( MODE == APPLY_REPLACE )
             out = acc;
          else if ( MODE == APPLY_ADD )
-            out = acc + zm_load( rd, off );
+            out = acc + ex0[j];
          else
-         {
-            const double rv = zm_load( rr, off );
-            const double iv = A.invdiag ? zm_load( ri, off ) : invc;
-            out             = a0 + A.relax * ( iv * ( rv - acc ) );
-         }
+            out = a0 + A.relax * ( ex1[j] * ( ex0[j] - acc ) );
          if constexpr ( ( ABL & 4 ) != 0 )
          {
             if ( out == 1.2345e-300 )

@@ -7,6 +7,11 @@
 // larger by the same amounts.  Points on one plane never read each other, so all points of a plane can
 // be updated concurrently and planes in increasing t reproduce the sequential sweep bit for bit (up to
 // FMA contraction).  The backward sweep is the same planes in decreasing t.
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <vector>
+
 #include "common.hpp"
 
 using namespace hyteg_hip;
@@ -71,6 +76,203 @@ __global__ __launch_bounds__( kThreads ) void p1_sor_plane_kernel( const SorArgs
    }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Blocked form of the same sweep.  In the skewed coordinates (p,q,r) = (x+y+z, y+z, z) every already-updated
+// neighbour of a point has all three coordinates <= the point's and every not-yet-updated one >=:
+//   W(-1,0,0)  S(-1,-1,0)  SE(0,-1,0)  BC(-1,-1,-1)  BE(0,-1,-1)  BN(0,0,-1)  BNW(-1,0,-1)   and their negatives.
+// So rectangular blocks of B^3 points in (p,q,r), visited in block-wavefront order P+Q+R (one launch per wavefront,
+// all blocks of a wavefront concurrently), with the points inside a block visited in hyperplanes p+q+r by ONE
+// workgroup from LDS, reproduce the sequential (z,y,x) sweep exactly.  Thread (ql,rl) of a workgroup owns the row
+// (q,r) of its block and marches along p (= along x), staggered by ql+rl steps.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kB  = 16;     // block edge
+constexpr int kBH = kB + 2; // with halo
+
+struct SorBlock
+{
+   short P, Q, R, pad;
+};
+
+struct SorBlockArgs
+{
+   double*         u;
+   const double*   rhs;
+   const SorBlock* blocks; // blocks of this wavefront
+   int             N;
+   int             backwards;
+   double          relax, one_minus_relax, invc;
+   Stencil15       st;
+};
+
+__device__ inline int lds_index( int pl, int ql, int rl ) { return ( ( rl + 1 ) * kBH + ( ql + 1 ) ) * kBH + ( pl + 1 ); }
+
+__global__ __launch_bounds__( kB* kB ) void p1_sor_block_kernel( const SorBlockArgs A )
+{
+   __shared__ double lu[kBH * kBH * kBH];
+   __shared__ double lr[kB * kB * kB]; // rhs of the block (a per-thread register row would be runtime-indexed -> scratch)
+   const SorBlock    blk = A.blocks[blockIdx.x];
+   const int         N = A.N, n = N - 1;
+   const int         p0 = blk.P * kB, q0 = blk.Q * kB, r0 = blk.R * kB;
+   double*           u = A.u;
+
+   // stage the block and its halo: rows of constant (q,r) are contiguous in memory (x = p - q)
+   // (constant trip counts + full unrolling: all loads of a thread are in flight together; a rolled loop waits one
+   //  memory round trip per iteration, which made staging 2/3 of the block time)
+   constexpr int kStageU = ( kBH * kBH * kBH + kB * kB - 1 ) / ( kB * kB );
+   double        stage[kStageU];
+#pragma unroll
+   for ( int it = 0; it < kStageU; ++it )
+   {
+      const int idx = it * ( kB * kB ) + threadIdx.x;
+      const int pl = idx % kBH - 1, ql = ( idx / kBH ) % kBH - 1, rl = idx / ( kBH * kBH ) - 1;
+      const int p = p0 + pl, q = q0 + ql, r = r0 + rl;
+      const int x = p - q, y = q - r, z = r;
+      const bool ok = idx < kBH * kBH * kBH && x >= 0 && y >= 0 && z >= 0 && p <= n;
+      stage[it]     = ok ? u[cell_index( N, x, y, z )] : 0.0;
+   }
+#pragma unroll
+   for ( int it = 0; it < kStageU; ++it )
+   {
+      const int idx = it * ( kB * kB ) + threadIdx.x;
+      if ( idx < kBH * kBH * kBH )
+         lu[idx] = stage[it];
+   }
+   const int ql = threadIdx.x % kB, rl = threadIdx.x / kB;
+   const int q = q0 + ql, r = r0 + rl;
+   const int y = q - r, z = r;
+   // interior row? (y >= 1, z >= 1, and at least x = 1 fits: 1 + y + z <= n - 1)
+   const bool row_ok = y >= 1 && z >= 1 && y + z <= n - 2;
+   {
+      double stageR[kB];
+#pragma unroll
+      for ( int it = 0; it < kB; ++it )
+      {
+         const int idx = it * ( kB * kB ) + threadIdx.x;
+         const int pl = idx % kB, qq = ( idx / kB ) % kB, rr = idx / ( kB * kB );
+         const int p = p0 + pl, q2 = q0 + qq, r2 = r0 + rr;
+         const int x2 = p - q2, y2 = q2 - r2, z2 = r2;
+         const bool ok = x2 >= 1 && y2 >= 1 && z2 >= 1 && p <= n - 1;
+         stageR[it]    = ok ? A.rhs[cell_index( N, x2, y2, z2 )] : 0.0;
+      }
+#pragma unroll
+      for ( int it = 0; it < kB; ++it )
+         lr[it * ( kB * kB ) + threadIdx.x] = stageR[it];
+   }
+   __syncthreads();
+
+   const double* w = A.st.w;
+#pragma unroll 1
+   for ( int step = 0; step < 3 * kB - 2; ++step )
+   {
+      const int s  = A.backwards ? ( 3 * kB - 3 - step ) : step;
+      const int pl = s - ql - rl;
+      if ( pl >= 0 && pl < kB )
+      {
+         const int x = p0 + pl - q;
+         if ( row_ok && x >= 1 && x + y + z <= n - 1 )
+         {
+            const int c = lds_index( pl, ql, rl );
+#define LU( dp, dq, dr ) lu[c + ( dp ) + ( dq ) * kBH + ( dr ) * kBH * kBH]
+            // 14 terms -(w_k u_k) in the reference's order (sor_3D_macrocell_P1.cpp:74), rhs last
+            // three partial sums (a 15-deep dependent FMA chain per step is latency on the critical path of the
+            // whole sweep); the order of the UPDATES is the reference's, the order of additions inside one update is not
+            double a0 = -w[3] * LU( 0, 0, -1 );          // BN  ( 0, 1,-1)
+            double a1 = -w[10] * LU( 1, 1, 0 );          // N   ( 0, 1, 0)
+            double a2 = -w[5] * LU( 0, -1, 0 );          // SE  ( 1,-1, 0)
+            a0        = fma( -w[12], LU( 1, 0, 1 ), a0 );   // TSE ( 1,-1, 1)
+            a1        = fma( -w[1], LU( 0, -1, -1 ), a1 );  // BE  ( 1, 0,-1)
+            a2        = fma( -w[8], LU( 1, 0, 0 ), a2 );    // E   ( 1, 0, 0)
+            a0        = fma( -w[6], LU( -1, 0, 0 ), a0 );   // W   (-1, 0, 0)
+            a1        = fma( -w[13], LU( 0, 1, 1 ), a1 );   // TW  (-1, 0, 1)
+            a2        = fma( -w[2], LU( -1, 0, -1 ), a2 );  // BNW (-1, 1,-1)
+            a0        = fma( -w[9], LU( 0, 1, 0 ), a0 );    // NW  (-1, 1, 0)
+            a1        = fma( -w[4], LU( -1, -1, 0 ), a1 );  // S   ( 0,-1, 0)
+            a2        = fma( -w[11], LU( 0, 0, 1 ), a2 );   // TS  ( 0,-1, 1)
+            a0        = fma( -w[0], LU( -1, -1, -1 ), a0 ); // BC  ( 0, 0,-1)
+            a1        = fma( -w[14], LU( 1, 1, 1 ), a1 );   // TC  ( 0, 0, 1)
+            a2        = a2 + lr[( rl * kB + ql ) * kB + pl];
+            const double acc = ( a0 + a1 ) + a2;
+            lu[c]      = A.relax * A.invc * acc + A.one_minus_relax * lu[c];
+#undef LU
+         }
+      }
+      __syncthreads();
+   }
+
+   // write the updated interior points back (coalesced along p = along x)
+#pragma unroll
+   for ( int it = 0; it < kB; ++it )
+   {
+      const int idx = it * ( kB * kB ) + threadIdx.x;
+      const int pl = idx % kB, qq = ( idx / kB ) % kB, rr = idx / ( kB * kB );
+      const int p = p0 + pl, q2 = q0 + qq, r2 = r0 + rr;
+      const int x = p - q2, y2 = q2 - r2, z2 = r2;
+      if ( x >= 1 && y2 >= 1 && z2 >= 1 && p <= n - 1 )
+         u[cell_index( N, x, y2, z2 )] = lu[lds_index( pl, qq, rr )];
+   }
+}
+
+// per level: the non-empty blocks sorted by wavefront, and the wavefront offsets
+struct SorBlockTable
+{
+   const SorBlock*    dev = nullptr;
+   std::vector< int > wavefrontStart; // size nwavefronts + 1
+};
+
+int get_sor_blocks( int level, const SorBlockTable** out )
+{
+   static std::mutex                                   mtx;
+   static std::map< std::pair< int, int >, SorBlockTable > cache;
+   int                                                 dev = 0;
+   HH_CHECK_HIP( hipGetDevice( &dev ) );
+   std::lock_guard< std::mutex > lock( mtx );
+   auto                          key = std::make_pair( dev, level );
+   auto                          it  = cache.find( key );
+   if ( it == cache.end() )
+   {
+      const int n  = 1 << level;
+      const int nb = ( n + kB - 1 ) / kB;
+      std::vector< std::vector< SorBlock > > byT( 3 * nb );
+      for ( int R = 0; R < nb; ++R )
+         for ( int Q = R; Q < nb; ++Q )
+            for ( int P = Q; P < nb; ++P )
+            {
+               // non-empty iff some interior point: r>=1, q>=r+1, p>=q+1, p<=n-1 within the block ranges
+               const int rmin = std::max( 1, R * kB ), rmax = std::min( n - 3, R * kB + kB - 1 );
+               if ( rmin > rmax )
+                  continue;
+               const int qmin = std::max( rmin + 1, Q * kB ), qmax = std::min( n - 2, Q * kB + kB - 1 );
+               if ( qmin > qmax )
+                  continue;
+               const int pmin = std::max( qmin + 1, P * kB ), pmax = std::min( n - 1, P * kB + kB - 1 );
+               if ( pmin > pmax )
+                  continue;
+               byT[P + Q + R].push_back( SorBlock{ (short) P, (short) Q, (short) R, 0 } );
+            }
+      SorBlockTable           tab;
+      std::vector< SorBlock > flat;
+      tab.wavefrontStart.push_back( 0 );
+      for ( auto& v : byT )
+      {
+         if ( v.empty() )
+            continue;
+         flat.insert( flat.end(), v.begin(), v.end() );
+         tab.wavefrontStart.push_back( (int) flat.size() );
+      }
+      if ( !flat.empty() )
+      {
+         void* p = nullptr;
+         HH_CHECK_HIP( hipMalloc( &p, flat.size() * sizeof( SorBlock ) ) );
+         HH_CHECK_HIP( hipMemcpy( p, flat.data(), flat.size() * sizeof( SorBlock ), hipMemcpyHostToDevice ) );
+         tab.dev = static_cast< const SorBlock* >( p );
+      }
+      it = cache.emplace( key, std::move( tab ) ).first;
+   }
+   *out = &it->second;
+   return HYTEG_HIP_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -96,6 +298,33 @@ HYTEG_HIP_API int hyteg_hip_p1_sor_cell( double*            u,
    A.invc            = 1.0 / w[7];
    for ( int k = 0; k < 15; ++k )
       A.st.w[k] = w[k];
+   if ( level >= 5 )
+   {
+      // blocked sweep: one launch per block wavefront
+      const SorBlockTable* tab = nullptr;
+      int                  rc  = get_sor_blocks( level, &tab );
+      if ( rc != HYTEG_HIP_OK )
+         return rc;
+      SorBlockArgs B;
+      B.u               = u;
+      B.rhs             = rhs;
+      B.N               = A.N;
+      B.backwards       = backwards ? 1 : 0;
+      B.relax           = relax;
+      B.one_minus_relax = A.one_minus_relax;
+      B.invc            = A.invc;
+      B.st              = A.st;
+      const int nw      = (int) tab->wavefrontStart.size() - 1;
+      for ( int k = 0; k < nw; ++k )
+      {
+         const int wv = backwards ? nw - 1 - k : k;
+         const int lo = tab->wavefrontStart[wv], hi = tab->wavefrontStart[wv + 1];
+         B.blocks     = tab->dev + lo;
+         hipLaunchKernelGGL( p1_sor_block_kernel, dim3( hi - lo ), dim3( kB * kB ), 0, as_stream( stream ), B );
+      }
+      HH_CHECK_HIP( hipGetLastError() );
+      return HYTEG_HIP_OK;
+   }
    const int n = 1 << level;
    // interior: x,y,z >= 1, x+y+z <= n-1  =>  t from 6 to max over the interior of x+2y+3z = 3(n-1)-3 (x=y=1, z=n-3)
    const int tmin = 6, tmax = 1 + 2 + 3 * ( n - 3 );

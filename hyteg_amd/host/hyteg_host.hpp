@@ -357,6 +357,8 @@ class PrimitiveStorage
          hyteg_hip_free( dotResult_ );
       if ( dotWorkspace_ )
          hyteg_hip_free( dotWorkspace_ );
+      for ( void* p : scratchAll_ )
+         hyteg_hip_free( p );
    }
    PrimitiveStorage( const PrimitiveStorage& )            = delete;
    PrimitiveStorage& operator=( const PrimitiveStorage& ) = delete;
@@ -419,11 +421,29 @@ class PrimitiveStorage
    void              setCommHooks( const CommHooks& h ) { hooks_ = h; }
    const CommHooks&  hooks() const { return hooks_; }
 
+   // pool of scratch device arrays keyed by size, so that operators can use temporaries without hipMalloc/hipFree
+   // in the hot path (the role of hyteg::getTemporaryFunction, src/hyteg/memory/TempFunctionManager.hpp)
+   double* acquireScratch( size_t doubles ) const
+   {
+      auto& freeList = scratchFree_[doubles];
+      if ( !freeList.empty() )
+      {
+         double* p = freeList.back();
+         freeList.pop_back();
+         return p;
+      }
+      void* p = nullptr;
+      hipCheck( hyteg_hip_malloc( &p, doubles * sizeof( double ) ), "scratch: malloc" );
+      scratchAll_.push_back( p );
+      return static_cast< double* >( p );
+   }
+   void releaseScratch( size_t doubles, double* p ) const { scratchFree_[doubles].push_back( p ); }
+
    double* dotResult() const
    {
       if ( !dotResult_ )
       {
-         hipCheck( hyteg_hip_malloc( &dotResult_, sizeof( double ) ), "PrimitiveStorage: malloc" );
+         hipCheck( hyteg_hip_malloc( &dotResult_, sizeof( double ) * std::max< size_t >( 1, localCells_.size() ) ), "PrimitiveStorage: malloc" );
          hipCheck( hyteg_hip_malloc( &dotWorkspace_, hyteg_hip_dot_workspace_bytes() ), "PrimitiveStorage: malloc" );
       }
       return static_cast< double* >( dotResult_ );
@@ -662,6 +682,8 @@ class PrimitiveStorage
    hyteg_hip_stream_t                                      stream_       = nullptr;
    CommHooks                                               hooks_;
    mutable void *                                          dotResult_ = nullptr, *dotWorkspace_ = nullptr;
+   mutable std::map< size_t, std::vector< double* > >      scratchFree_;
+   mutable std::vector< void* >                            scratchAll_;
    mutable std::map< std::pair< int, int >, ExchangePlan > plans_;
 };
 
@@ -677,11 +699,14 @@ class P1Function
  public:
    using valueType = ValueType;
 
-   P1Function( const std::string& name, const std::shared_ptr< PrimitiveStorage >& storage, uint_t minLevel, uint_t maxLevel )
+   // scratch = true: arrays come from (and return to) the storage's scratch pool and are NOT zero-initialised
+   P1Function( const std::string& name, const std::shared_ptr< PrimitiveStorage >& storage, uint_t minLevel, uint_t maxLevel,
+               bool scratch = false )
    : name_( name )
    , storage_( storage )
    , minLevel_( minLevel )
    , maxLevel_( maxLevel )
+   , scratch_( scratch )
    {
       if ( maxLevel > HYTEG_HIP_MAX_LEVEL || minLevel > maxLevel )
          throw std::runtime_error( "P1Function: bad level range" );
@@ -690,18 +715,28 @@ class P1Function
       for ( uint_t c = 0; c < nLocal; ++c )
          for ( uint_t l = minLevel; l <= maxLevel; ++l )
          {
-            void*        p     = nullptr;
-            const size_t bytes = (size_t) layout::cellSize( (int) l ) * sizeof( double );
-            hipCheck( hyteg_hip_malloc( &p, bytes ), "P1Function: malloc" );
-            hipCheck( hyteg_hip_memset_zero( p, bytes, storage->stream() ), "P1Function: memset" );
+            const size_t doubles = (size_t) layout::cellSize( (int) l );
+            if ( scratch )
+            {
+               data_[c].push_back( storage->acquireScratch( doubles ) );
+               continue;
+            }
+            void* p = nullptr;
+            hipCheck( hyteg_hip_malloc( &p, doubles * sizeof( double ) ), "P1Function: malloc" );
+            hipCheck( hyteg_hip_memset_zero( p, doubles * sizeof( double ), storage->stream() ), "P1Function: memset" );
             data_[c].push_back( static_cast< double* >( p ) );
          }
    }
    ~P1Function()
    {
       for ( auto& c : data_ )
-         for ( double* p : c )
-            hyteg_hip_free( p );
+         for ( uint_t l = 0; l < c.size(); ++l )
+         {
+            if ( scratch_ )
+               storage_->releaseScratch( (size_t) layout::cellSize( (int) ( minLevel_ + l ) ), c[l] );
+            else
+               hyteg_hip_free( c[l] );
+         }
       for ( auto& kv : bases_ )
          hyteg_hip_free( kv.second );
    }
@@ -733,7 +768,7 @@ class P1Function
    {
       // evaluated on the host at the micro-vertex coordinates of VertexDoFMacroCell.hpp:70-77, then uploaded
       const int64_t N = layout::width( (int) level ), size = layout::cellSize( (int) level );
-      P1Function    tmp( "interpolate_tmp", storage_, level, level );
+      P1Function    tmp( "interpolate_tmp", storage_, level, level, true );
       std::vector< double > host( (size_t) size );
       forCells( [&]( uint_t c, const MacroCell& cell ) {
          const double step = 1.0 / double( N - 1 );
@@ -787,16 +822,22 @@ class P1Function
    // ---- dot ( VertexDoFFunction.cpp:1710-1793 ) ----
    ValueType dotLocal( const P1Function< ValueType >& rhs, uint_t level, DoFType flag = All ) const
    {
-      double sum = 0.0;
+      // one result slot per local cell, a single download (= one host synchronisation) per dot product; the
+      // workspace is reused cell after cell, which is safe because all launches are ordered on one stream
+      const uint_t nLocal = storage_->getNumberOfLocalCells();
       forCells( [&]( uint_t c, const MacroCell& cell ) {
          hipCheck( hyteg_hip_p1_dot_cell_masked( getCellPointer( c, level ), rhs.getCellPointer( c, level ), (int) level,
-                                                 storage_->ownedMaskFor( cell, flag ), storage_->dotResult(), storage_->dotWorkspace(),
+                                                 storage_->ownedMaskFor( cell, flag ), storage_->dotResult() + c, storage_->dotWorkspace(),
                                                  storage_->stream() ),
                    "dotLocal" );
-         double part = 0.0;
-         hipCheck( hyteg_hip_download( &part, storage_->dotResult(), sizeof( double ), storage_->stream() ), "dotLocal: download" );
-         sum += part;
       } );
+      std::vector< double > parts( nLocal, 0.0 );
+      if ( nLocal > 0 )
+         hipCheck( hyteg_hip_download( parts.data(), storage_->dotResult(), nLocal * sizeof( double ), storage_->stream() ),
+                   "dotLocal: download" );
+      double sum = 0.0;
+      for ( double v : parts )
+         sum += v; // cells in ascending order: deterministic
       return sum;
    }
    ValueType dotGlobal( const P1Function< ValueType >& rhs, uint_t level, DoFType flag = All ) const
@@ -945,6 +986,7 @@ class P1Function
    std::string                                                           name_;
    std::shared_ptr< PrimitiveStorage >                                   storage_;
    uint_t                                                                minLevel_, maxLevel_;
+   bool                                                                  scratch_ = false;
    std::vector< std::vector< double* > >                                 data_;
    mutable std::map< std::pair< uint_t, int >, double** >                bases_;
    mutable std::map< std::pair< uint_t, int >, std::vector< double* > >  basesHost_;
@@ -1125,7 +1167,8 @@ class P1ConstantOperator
       if ( updateType == Add && hasSharedPoints( level, flag ) )
       {
          // partial results of shared DoFs are summed over cells before they are added to dst
-         tmp.reset( new P1Function< double >( "apply_tmp", storage_, level, level ) );
+         tmp.reset( new P1Function< double >( "apply_tmp", storage_, level, level, true ) );
+         tmp->interpolate( 0.0, level, All );
          shellDst = tmp.get();
       }
       // 1. this cell's share of the shared macro-face/edge/vertex DoFs (tiny kernels), 2. start the halo exchange,
@@ -1345,7 +1388,8 @@ class P1toP1LinearProlongation
    {
       // the prolongated correction is formed in a temporary (Replace), summed over cells on shared points, then added
       auto                 storage = function.getStorage();
-      P1Function< double > tmp( "prolongate_tmp", storage, sourceLevel, sourceLevel + 1 );
+      P1Function< double > tmp( "prolongate_tmp", storage, sourceLevel, sourceLevel + 1, true );
+      tmp.interpolate( 0.0, sourceLevel + 1, All );
       tmp.assign( { 1.0 }, { function }, sourceLevel, All );
       run( tmp, tmp, sourceLevel, flag );
       function.add( { 1.0 }, { tmp }, sourceLevel + 1, flag );

@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Per-kernel timings of the whole P1 hot path on one GPU (level 8 by default) with algorithmic GB/s, plus V-cycle
+timings through the host layer.  Not the headline bench (that is bench.py); this is the evidence table for
+DESIGN.md section 3.  Usage: python tools/bench_kernels.py [--level 8] [--reps 200]"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from hyteg_amd import capi, host  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--level", type=int, default=8)
+    ap.add_argument("--reps", type=int, default=200)
+    args = ap.parse_args()
+    L, reps = args.level, args.reps
+    n, inner = capi.cell_size(L), capi.cell_inner_size(L)
+    nc = capi.cell_size(L - 1)
+    stream = torch.cuda.current_stream()
+    sh = stream.cuda_stream
+    nbuf = max(2, int(1.5 * 256 * 2**20) // (3 * n * 8) + 1)
+    A = [torch.rand(n, dtype=torch.float64, device="cuda") for _ in range(nbuf)]
+    B = [torch.rand(n, dtype=torch.float64, device="cuda") for _ in range(nbuf)]
+    Cc = [torch.rand(n, dtype=torch.float64, device="cuda") for _ in range(nbuf)]
+    Co = [torch.rand(nc, dtype=torch.float64, device="cuda") for _ in range(nbuf)]
+    st = host.Storage.from_gmsh(ROOT / "tests/golden/meshes/tet_1el.msh")
+    st.set_stream(sh)
+    op = host.P1ConstantOperator(st, 2, L)
+    w = list(op.stencils(0, L)[0])
+    ones = [1.0] * 14
+    res = torch.zeros(1, dtype=torch.float64, device="cuda")
+    ws = torch.zeros(capi.dot_workspace_bytes() // 8, dtype=torch.float64, device="cuda")
+    rows = []
+
+    def timeit(name, fn, bytes_per_call, updates, r=reps):
+        for k in range(5):
+            fn(k)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for k in range(r):
+            fn(k)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / r
+        rows.append(dict(kernel=name, us=us, GBps=bytes_per_call / us * 1e-3, GDoFps=updates / us * 1e-3,
+                         algorithmic_bytes=bytes_per_call))
+        print(f"{name:44s} {us:10.2f} us  {bytes_per_call / us * 1e-3:8.1f} GB/s  {updates / us * 1e-3:8.1f} GDoF/s", flush=True)
+
+    p = lambda t, k: t[k % nbuf].data_ptr()  # noqa: E731
+    timeit("apply Replace", lambda k: capi.p1_apply_cell(p(B, k), p(A, k), L, w, 0, sh), 16 * inner, inner)
+    timeit("apply Add", lambda k: capi.p1_apply_cell(p(B, k), p(A, k), L, w, 1, sh), 24 * inner, inner)
+    timeit("Jacobi fused (scalar inverse diagonal)", lambda k: capi.p1_jacobi_cell(p(B, k), p(Cc, k), p(A, k), L, w, 0.66, None, sh),
+           24 * inner, inner)
+    timeit("Jacobi fused (inverse-diagonal function)",
+           lambda k: capi.p1_jacobi_cell(p(B, k), p(Cc, k), p(A, k), L, w, 0.66, p(Cc, k + 1), sh), 32 * inner, inner)
+    timeit("assign 1 source", lambda k: capi.p1_assign_cell(p(B, k), [2.0], [p(A, k)], L, sh), 16 * inner, inner)
+    timeit("assign 2 sources", lambda k: capi.p1_assign_cell(p(B, k), [2.0, -1.0], [p(A, k), p(Cc, k)], L, sh), 24 * inner, inner)
+    timeit("add 1 source", lambda k: capi.p1_add_cell(p(B, k), [2.0], [p(A, k)], L, sh), 24 * inner, inner)
+    timeit("multElementwise 2 sources", lambda k: capi.p1_mult_cell(p(B, k), [p(A, k), p(Cc, k)], L, sh), 24 * inner, inner)
+    timeit("dot", lambda k: capi.p1_dot_cell(p(A, k), p(B, k), L, res.data_ptr(), ws.data_ptr(), sh), 16 * inner, inner)
+    timeit("restrict (fine L -> coarse L-1)", lambda k: capi.p1_restrict_cell(p(Co, k), p(A, k), L - 1, ones, sh), 8 * (n + nc), nc)
+    timeit("prolongate Replace (coarse L-1 -> fine L)", lambda k: capi.p1_prolongate_cell(p(Co, k), p(B, k), L - 1, ones, 0, sh),
+           8 * (n + nc), n)
+    timeit("SOR forward sweep (hyperplane-exact)", lambda k: capi.p1_sor_cell(p(B, k), p(A, k), L, w, 1.0, False, sh), 24 * inner, inner,
+           r=max(3, reps // 40))
+    # V-cycles through the host layer
+    for mesh, lo, hi, smoother, name in (("tet_1el", 2, L, host.JACOBI, "Jacobi(2/3)"), ("tet_1el", 2, min(L, 7), host.GAUSS_SEIDEL, "GS"),
+                                          ("regular_octahedron_8el", 2, min(L, 6), host.JACOBI, "Jacobi(2/3)")):
+        s2 = host.Storage.from_gmsh(ROOT / f"tests/golden/meshes/{mesh}.msh")
+        s2.set_stream(sh)
+        A2 = host.P1ConstantOperator(s2, lo, hi)
+        A2.compute_inverse_diagonal()
+        x, b, one = (host.P1Function(s2, nm, lo, hi) for nm in ("x", "b", "one"))
+        one.interpolate(1.0, hi, host.All)
+        dofs = one.dot(one, hi, host.Inner)
+        rng = np.random.default_rng(0)
+        for c in range(s2.n_local_cells):
+            x.upload_cell(c, hi, rng.random(capi.cell_size(hi)))
+        x.sync_shared(hi, host.All)
+        x.interpolate(0.0, hi, host.DirichletBoundary)
+        gmg = host.Solver.gmg(s2, lo, hi, smoother=smoother, relax=2.0 / 3.0, pre=3, post=3, cg_max_iter=50, cg_tol=1e-10)
+        gmg.solve(A2, x, b, hi)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ncyc = 3
+        for _ in range(ncyc):
+            gmg.solve(A2, x, b, hi)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / ncyc
+        rows.append(dict(kernel=f"V(3,3) {name} {mesh} L{lo}-{hi}", ms=ms, inner_dofs=dofs))
+        print(f"V(3,3) {name:12s} {mesh:24s} levels {lo}-{hi}: {ms:9.2f} ms/cycle, {dofs:.0f} inner DoFs "
+              f"({dofs / ms * 1e-6:.2f} GDoF/s per cycle)", flush=True)
+    print(json.dumps({"level": L, "device": capi.device_name(), "rows": rows}))
+
+
+if __name__ == "__main__":
+    main()
