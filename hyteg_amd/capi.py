@@ -52,6 +52,9 @@ SIGNATURES = {
     "hyteg_hip_p1_prolongate_cell_masked": (_i, [_vp, _vp, _i, _dp, C.c_uint, _vp]),
     "hyteg_hip_sum_shared": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "hyteg_hip_copy_shared": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "hyteg_hip_p1_copy_face_to_cell": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "hyteg_hip_p1_copy_cell_to_face": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "hyteg_hip_p1_apply_face3d": (_i, [_vp, _vp, _i, _i, C.POINTER(_i), _dp, _i, _vp]),
     "hyteg_hip_gather_entries": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
 }
 MASK_INNER, MASK_SHELL, MASK_ALL = 1 << 14, 0x3FFF, 0x7FFF
@@ -199,3 +202,20 @@ def sum_shared(bases, group_ptr, entry_buf, entry_off, ngroups, n_writable, stre
 
 def gather_entries(out, bases, entry_buf, entry_off, n, stream=0):
     check(lib().hyteg_hip_gather_entries(out, bases, entry_buf, entry_off, n, stream), "gather_entries")
+
+
+def p1_copy_face_to_cell(cell, face, level, v, stream=0):
+    check(lib().hyteg_hip_p1_copy_face_to_cell(cell, face, level, int(v[0]), int(v[1]), int(v[2]), stream), "p1_copy_face_to_cell")
+
+
+def p1_copy_cell_to_face(face, cell, level, v, neighbor, stream=0):
+    check(lib().hyteg_hip_p1_copy_cell_to_face(face, cell, level, int(v[0]), int(v[1]), int(v[2]), int(neighbor), stream),
+          "p1_copy_cell_to_face")
+
+
+def p1_apply_face3d(dst, src, level, vmaps, ws, update=REPLACE, stream=0):
+    flat_v = [int(x) for row in vmaps for x in row]
+    flat_w = [float(x) for row in ws for x in row]
+    n = len(flat_v) // 3
+    check(lib().hyteg_hip_p1_apply_face3d(dst, src, level, n, (C.c_int * len(flat_v))(*flat_v), (C.c_double * len(flat_w))(*flat_w),
+                                          update, stream), "p1_apply_face3d")

@@ -251,6 +251,88 @@ __global__ __launch_bounds__( kThreads ) void gather_entries_kernel( double* __r
       out[k] = bases[entry_buf[k]][entry_off[k]];
 }
 
+
+// ---- HyTeG macro-face layout: ghost copies and the one-/two-sided face apply (generic in the vertex map) ----
+struct FaceMap
+{
+   int v[3];
+   int v3;
+};
+struct FaceApplyArgs
+{
+   double*       dst;
+   const double* src;
+   int           N;
+   int           ncells;
+   int           update;
+   FaceMap       map[2];
+   double        w[2][15];
+};
+
+__device__ inline void face_to_cell( int n, const FaceMap& m, int fx, int fy, int fz, int& cx, int& cy, int& cz )
+{
+   int bary[4] = { 0, 0, 0, 0 };
+   bary[m.v[0]] = n - fx - fy - fz;
+   bary[m.v[1]] = fx;
+   bary[m.v[2]] = fy;
+   bary[m.v3]   = fz;
+   cx = bary[1], cy = bary[2], cz = bary[3];
+}
+
+// dir 0: face -> cell boundary layer (all tri(N) face DoFs); dir 1: cell layer at distance 1 -> ghost layer
+__global__ __launch_bounds__( kThreads ) void p1_face_cell_copy_kernel( double* dst, const double* src, int N, FaceMap m, int dir, int ghost_offset )
+{
+   const int Wf = dir == 0 ? N : N - 1; // width of the triangle that is iterated
+   const int r  = blockIdx.x * kThreads + threadIdx.x;
+   if ( r >= tri( Wf ) )
+      return;
+   const int y = row_of( Wf, r ), x = r - row_start( Wf, y );
+   int       cx, cy, cz;
+   face_to_cell( N - 1, m, x, y, dir, cx, cy, cz );
+   const int ci = cell_index( N, cx, cy, cz );
+   if ( dir == 0 )
+      dst[ci] = src[r];
+   else
+      dst[ghost_offset + r] = src[ci];
+}
+
+__global__ __launch_bounds__( kThreads ) void p1_apply_face3d_kernel( const FaceApplyArgs A )
+{
+   const int N = A.N, n = N - 1;
+   const int r = blockIdx.x * kThreads + threadIdx.x;
+   if ( r >= tri( N ) )
+      return;
+   const int y = row_of( N, r ), x = r - row_start( N, y );
+   if ( x < 1 || y < 1 || x + y > n - 1 )
+      return; // inner face DoFs only (macroface::Iterator( level, 1 ))
+   double tmp = 0.0;
+   for ( int k = 0; k < A.ncells; ++k )
+   {
+      const FaceMap& m = A.map[k];
+      int            cx, cy, cz;
+      face_to_cell( n, m, x, y, 0, cx, cy, cz );
+#pragma unroll
+      for ( int s = 0; s < 15; ++s )
+      {
+         const int lx = cx + kOffs[s][0], ly = cy + kOffs[s][1], lz = cz + kOffs[s][2];
+         if ( lx < 0 || ly < 0 || lz < 0 || lx + ly + lz > n )
+            continue;
+         const int bary[4] = { n - lx - ly - lz, lx, ly, lz };
+         const int fx = bary[m.v[1]], fy = bary[m.v[2]], fz = bary[m.v3];
+         if ( fz > 1 )
+            continue;
+         const int idx = fz == 0 ? row_start( N, fy ) + fx : tri( N ) + k * tri( N - 1 ) + row_start( N - 1, fy ) + fx;
+         tmp           = fma( A.w[k][s], A.src[idx], tmp );
+      }
+   }
+   A.dst[r] = A.update == HYTEG_HIP_ADD ? A.dst[r] + tmp : tmp;
+}
+
+inline bool vmap_ok( int v0, int v1, int v2 )
+{
+   return v0 >= 0 && v0 < 4 && v1 >= 0 && v1 < 4 && v2 >= 0 && v2 < 4 && v0 != v1 && v0 != v2 && v1 != v2;
+}
+
 inline bool shell_level_ok( int level ) { return level >= 0 && level <= HYTEG_HIP_MAX_LEVEL; }
 inline int  shell_blocks( int N ) { return ( 4 * tri( N ) + kThreads - 1 ) / kThreads; }
 
@@ -446,6 +528,66 @@ HYTEG_HIP_API int hyteg_hip_gather_entries( double*            out,
    HH_REQUIRE( out && bases && entry_buf && entry_off, "gather_entries: null pointer" );
    hipLaunchKernelGGL( gather_entries_kernel, dim3( ( n + kThreads - 1 ) / kThreads ), dim3( kThreads ), 0, as_stream( stream ), out,
                        bases, entry_buf, entry_off, n );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_p1_copy_face_to_cell( double* cell, const double* face, int level, int v0, int v1, int v2, hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( cell && face, "p1_copy_face_to_cell: null pointer" );
+   HH_REQUIRE( shell_level_ok( level ), "p1_copy_face_to_cell: level out of range [0,11]" );
+   HH_REQUIRE( vmap_ok( v0, v1, v2 ), "p1_copy_face_to_cell: v0,v1,v2 must be distinct cell-local vertex ids" );
+   const int N = ( 1 << level ) + 1;
+   FaceMap   m{ { v0, v1, v2 }, 6 - v0 - v1 - v2 };
+   hipLaunchKernelGGL( p1_face_cell_copy_kernel, dim3( ( tri( N ) + kThreads - 1 ) / kThreads ), dim3( kThreads ), 0, as_stream( stream ),
+                       cell, face, N, m, 0, 0 );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_p1_copy_cell_to_face( double* face, const double* cell, int level, int v0, int v1, int v2, int neighbor,
+                                                  hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( cell && face, "p1_copy_cell_to_face: null pointer" );
+   HH_REQUIRE( level >= 1 && level <= HYTEG_HIP_MAX_LEVEL, "p1_copy_cell_to_face: level out of range [1,11]" );
+   HH_REQUIRE( vmap_ok( v0, v1, v2 ), "p1_copy_cell_to_face: v0,v1,v2 must be distinct cell-local vertex ids" );
+   HH_REQUIRE( neighbor == 0 || neighbor == 1, "p1_copy_cell_to_face: neighbor must be 0 or 1" );
+   const int N = ( 1 << level ) + 1;
+   FaceMap   m{ { v0, v1, v2 }, 6 - v0 - v1 - v2 };
+   hipLaunchKernelGGL( p1_face_cell_copy_kernel, dim3( ( tri( N - 1 ) + kThreads - 1 ) / kThreads ), dim3( kThreads ), 0,
+                       as_stream( stream ), face, cell, N, m, 1, tri( N ) + neighbor * tri( N - 1 ) );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_p1_apply_face3d( double*            dst_face,
+                                             const double*      src_face,
+                                             int                level,
+                                             int                ncells,
+                                             const int*         vmaps,
+                                             const double*      w,
+                                             int                update,
+                                             hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( dst_face && src_face && vmaps && w, "p1_apply_face3d: null pointer" );
+   HH_REQUIRE( level >= 1 && level <= HYTEG_HIP_MAX_LEVEL, "p1_apply_face3d: level out of range [1,11]" );
+   HH_REQUIRE( ncells == 1 || ncells == 2, "p1_apply_face3d: a macro-face has 1 or 2 neighbour cells" );
+   HH_REQUIRE( dst_face != src_face, "p1_apply_face3d: src and dst must not alias" );
+   HH_REQUIRE( update == HYTEG_HIP_REPLACE || update == HYTEG_HIP_ADD, "p1_apply_face3d: bad update type" );
+   FaceApplyArgs A{};
+   A.dst    = dst_face;
+   A.src    = src_face;
+   A.N      = ( 1 << level ) + 1;
+   A.ncells = ncells;
+   A.update = update;
+   for ( int k = 0; k < ncells; ++k )
+   {
+      HH_REQUIRE( vmap_ok( vmaps[3 * k], vmaps[3 * k + 1], vmaps[3 * k + 2] ), "p1_apply_face3d: bad vertex map" );
+      A.map[k] = FaceMap{ { vmaps[3 * k], vmaps[3 * k + 1], vmaps[3 * k + 2] }, 6 - vmaps[3 * k] - vmaps[3 * k + 1] - vmaps[3 * k + 2] };
+      for ( int s = 0; s < 15; ++s )
+         A.w[k][s] = w[15 * k + s];
+   }
+   hipLaunchKernelGGL( p1_apply_face3d_kernel, dim3( ( tri( A.N ) + kThreads - 1 ) / kThreads ), dim3( kThreads ), 0, as_stream( stream ), A );
    HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;
 }

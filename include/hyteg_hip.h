@@ -302,6 +302,34 @@ HYTEG_HIP_API int hyteg_hip_gather_entries( double*            out,
                                             int                n,
                                             hyteg_hip_stream_t stream );
 
+/* ---- a9 / a10 in HyTeG's own macro-face layout (drop-in for the face seam) -----------------------------------
+ * Macro-face array of width N = 2^level + 1:  [ tri(N) face DoFs | tri(N-1) ghost layer of neighbour cell 0 |
+ * tri(N-1) ghost layer of neighbour cell 1 ]  (src/hyteg/p1functionspace/VertexDoFMemory.hpp:59-63,
+ * VertexDoFIndexing.cpp:219-226).  v0,v1,v2 = cell.getFaceLocalVertexToCellLocalVertexMaps()[localFaceID], the
+ * arguments of the reference's generated copy kernels.
+ *
+ * copy_face_to_cell replaces vertexdof::comm::generated::communicate_directly_vertexdof_face_to_cell
+ *   (src/hyteg/p1functionspace/generatedKernels/communicate_directly_vertexdof_face_to_cell*.cpp; caller
+ *    VertexDoFPackInfo.hpp:438-478): all tri(N) face DoFs onto the cell's boundary layer.
+ * copy_cell_to_face replaces communicate_directly_vertexdof_cell_to_face (caller VertexDoFPackInfo.hpp:552-615):
+ *   the cell layer at distance 1 from the face into ghost layer `neighbor` (the face's cell_index of that cell).
+ * apply_face3d replaces apply_3D_macroface_one_sided_vertexdof_to_vertexdof_{replace,add} called once per
+ *   neighbour cell (src/constant_stencil_operator/P1ConstantOperator.cpp:239-357; spec P1Operator.hpp:1111-1173):
+ *   dst_i (=|+=) sum over the ncells (1 or 2) neighbour cells of that cell's share of the stencil.
+ *   vmaps: host, ncells x 3; w: host, ncells x 15 weights in the CELL's stencil directions (w[15] order; entries
+ *   for directions that leave the cell are ignored) -- faceStencil3D[cell] of the reference. */
+HYTEG_HIP_API int hyteg_hip_p1_copy_face_to_cell( double* cell, const double* face, int level, int v0, int v1, int v2, hyteg_hip_stream_t stream );
+HYTEG_HIP_API int hyteg_hip_p1_copy_cell_to_face( double* face, const double* cell, int level, int v0, int v1, int v2, int neighbor,
+                                                  hyteg_hip_stream_t stream );
+HYTEG_HIP_API int hyteg_hip_p1_apply_face3d( double*            dst_face,
+                                             const double*      src_face,
+                                             int                level,
+                                             int                ncells,
+                                             const int*         vmaps /* host, ncells*3 */,
+                                             const double*      w /* host, ncells*15 */,
+                                             int                update,
+                                             hyteg_hip_stream_t stream );
+
 #ifdef __cplusplus
 }
 #endif

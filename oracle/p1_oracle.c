@@ -687,3 +687,92 @@ HO_API double ho_dot_cell_masked( const double* a, const double* b, int level, u
             }
    return sp;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * a9 / a10 in HyTeG's own macro-face layout (drop-in seam).
+ * Macro-face array of width N: [ tri(N) face DoFs | tri(N-1) ghost layer of neighbour cell 0 | ... of cell 1 ]
+ * (src/hyteg/p1functionspace/VertexDoFMemory.hpp:59-63, VertexDoFIndexing.cpp:219-226).
+ * A face point (x,y) / ghost point (x,y,1) in the face's basis (v0,v1,v2,v3) -- v0..v2 the cell-local vertices of
+ * the face's vertices 0..2 (Cell::getFaceLocalVertexToCellLocalVertexMaps), v3 the remaining one -- is the cell
+ * point with weights n-x-y-z, x, y, z on cell vertices v0, v1, v2, v3
+ * (indexing::basisConversion, src/hyteg/indexing/DistanceCoordinateSystem.hpp:107-150;
+ *  getIndexInNeighboringMacroCell, src/hyteg/p1functionspace/VertexDoFMacroFace.hpp:53-70).
+ * ------------------------------------------------------------------------------------------- */
+static void face_to_cell_coords( int64_t n, const int* v, int64_t fx, int64_t fy, int64_t fz, int64_t* c )
+{
+   int64_t bary[4] = { 0, 0, 0, 0 };
+   int     v3      = 6 - v[0] - v[1] - v[2];
+   bary[v[0]]      = n - fx - fy - fz;
+   bary[v[1]]      = fx;
+   bary[v[2]]      = fy;
+   bary[v3]        = fz;
+   c[0] = bary[1], c[1] = bary[2], c[2] = bary[3];
+}
+
+/* communicateLocalFaceToCell, src/hyteg/p1functionspace/VertexDoFPackInfo.hpp:438-478 */
+HO_API void ho_copy_face_to_cell( double* cell, const double* face, int level, int v0, int v1, int v2 )
+{
+   const int64_t N = ho_width( level ), n = N - 1;
+   const int     v[3] = { v0, v1, v2 };
+   for ( int64_t y = 0; y < N; ++y )
+      for ( int64_t x = 0; x < N - y; ++x )
+      {
+         int64_t c[3];
+         face_to_cell_coords( n, v, x, y, 0, c );
+         cell[cell_index_w( N, c[0], c[1], c[2] )] = face[ho_face_index_w( N, x, y )];
+      }
+}
+
+/* communicateLocalCellToFace, VertexDoFPackInfo.hpp:552-615: the cell layer at distance 1 from the face */
+HO_API void ho_copy_cell_to_face( double* face, const double* cell, int level, int v0, int v1, int v2, int neighbor )
+{
+   const int64_t N = ho_width( level ), n = N - 1;
+   const int     v[3] = { v0, v1, v2 };
+   double*       ghost = face + ho_face_size_w( N ) + neighbor * ho_face_size_w( N - 1 );
+   for ( int64_t y = 0; y < N - 1; ++y )
+      for ( int64_t x = 0; x < N - 1 - y; ++x )
+      {
+         int64_t c[3];
+         face_to_cell_coords( n, v, x, y, 1, c );
+         ghost[ho_face_index_w( N - 1, x, y )] = cell[cell_index_w( N, c[0], c[1], c[2] )];
+      }
+}
+
+/* P1Operator::apply_face3D, src/hyteg/p1functionspace/P1Operator.hpp:1111-1173: for every inner face DoF and every
+ * neighbour cell, the cell's share of the stencil (weights in the CELL's stencil directions, w15 order) applied to
+ * leaves that are converted back into the face's array (in-plane leaves) or the cell's ghost layer (distance 1).
+ * vmaps: ncells x 3 cell-local vertex ids; w: ncells x 15. */
+HO_API void ho_apply_face3d( double* dst, const double* src, int level, int ncells, const int* vmaps, const double* w, int update )
+{
+   const int64_t N = ho_width( level ), n = N - 1;
+   for ( int64_t y = 1; y < N - 2; ++y )
+      for ( int64_t x = 1; x < N - 1 - y - 0; ++x )
+      {
+         if ( x + y > n - 1 )
+            continue;
+         double tmp = 0.0;
+         for ( int k = 0; k < ncells; ++k )
+         {
+            const int* v  = vmaps + 3 * k;
+            const int  v3 = 6 - v[0] - v[1] - v[2];
+            int64_t    c[3];
+            face_to_cell_coords( n, v, x, y, 0, c );
+            for ( int s = 0; s < 15; ++s )
+            {
+               const double weight = w[15 * k + s];
+               const int64_t lx = c[0] + OFFS[s][0], ly = c[1] + OFFS[s][1], lz = c[2] + OFFS[s][2];
+               if ( !inside( N, lx, ly, lz ) )
+                  continue; /* direction leaves the cell: not part of this cell's share */
+               int64_t bary[4] = { n - lx - ly - lz, lx, ly, lz };
+               const int64_t fx = bary[v[1]], fy = bary[v[2]], fz = bary[v3];
+               if ( fz > 1 )
+                  continue;
+               const int64_t idx = fz == 0 ? ho_face_index_w( N, fx, fy ) :
+                                             ho_face_size_w( N ) + k * ho_face_size_w( N - 1 ) + ho_face_index_w( N - 1, fx, fy );
+               tmp += weight * src[idx];
+            }
+         }
+         const int64_t i = ho_face_index_w( N, x, y );
+         dst[i]          = update ? dst[i] + tmp : tmp;
+      }
+}

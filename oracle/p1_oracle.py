@@ -69,6 +69,9 @@ def _bind(lib):
         "ho_apply_cell_boundary": (None, [_P, _P, i, _P, C.c_uint, i]),
         "ho_vector_cell_masked": (None, [i, _P, i, C.POINTER(_P), _P, i, C.c_uint]),
         "ho_dot_cell_masked": (d, [_P, _P, i, C.c_uint]),
+        "ho_copy_face_to_cell": (None, [_P, _P, i, i, i, i]),
+        "ho_copy_cell_to_face": (None, [_P, _P, i, i, i, i, i]),
+        "ho_apply_face3d": (None, [_P, _P, i, i, C.POINTER(C.c_int), _P, i]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)
@@ -277,6 +280,29 @@ def vector_cell_masked(op, dst, scalars, srcs, level, mask):
 
 
 def dot_cell_masked(a, b, level, mask): return float(lib().ho_dot_cell_masked(_p(a), _p(b), level, mask))
+
+
+def face_array_size(level, ncells):
+    n = width(level)
+    return face_size_w(n) + ncells * face_size_w(n - 1)
+
+
+def copy_face_to_cell(cell, face, level, v):
+    lib().ho_copy_face_to_cell(_p(cell), _p(face), level, *map(int, v))
+    return cell
+
+
+def copy_cell_to_face(face, cell, level, v, neighbor):
+    lib().ho_copy_cell_to_face(_p(face), _p(cell), level, *map(int, v), int(neighbor))
+    return face
+
+
+def apply_face3d(dst, src, level, vmaps, ws, update=REPLACE):
+    vm = np.ascontiguousarray(vmaps, dtype=np.int32).reshape(-1, 3)
+    w = np.ascontiguousarray(ws, dtype=np.float64).reshape(-1, 15)
+    assert len(vm) == len(w)
+    lib().ho_apply_face3d(_p(dst), _p(src), level, len(vm), vm.ctypes.data_as(C.POINTER(C.c_int)), _p(w.reshape(-1)), update)
+    return dst
 
 
 def slot_of_points(level):
