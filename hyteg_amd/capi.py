@@ -54,6 +54,7 @@ SIGNATURES = {
     "hyteg_hip_copy_shared": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "hyteg_hip_p1_copy_face_to_cell": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "hyteg_hip_p1_copy_cell_to_face": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "hyteg_hip_p1_sor_shell_cell": (_i, [_vp, _vp, _vp, _i, C.POINTER(_i), _dp, C.POINTER(_i), _dp, _dp, _d, C.c_uint, _i, _vp]),
     "hyteg_hip_p1_apply_face3d": (_i, [_vp, _vp, _i, _i, C.POINTER(_i), _dp, _i, _vp]),
     "hyteg_hip_gather_entries": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
 }
@@ -211,6 +212,17 @@ def p1_copy_face_to_cell(cell, face, level, v, stream=0):
 def p1_copy_cell_to_face(face, cell, level, v, neighbor, stream=0):
     check(lib().hyteg_hip_p1_copy_cell_to_face(face, cell, level, int(v[0]), int(v[1]), int(v[2]), int(neighbor), stream),
           "p1_copy_cell_to_face")
+
+
+def p1_sor_shell_cell(dst, rhs, rest, level, edge_verts, edge_w, face_verts, face_w, vertex_w, relax, mask, backwards=False, stream=0):
+    ev = [int(v) for row in edge_verts for v in row]
+    fv = [int(v) for row in face_verts for v in row]
+    ew = [float(v) for row in edge_w for v in row]
+    fw = [float(v) for row in face_w for v in row]
+    vw = [float(v) for v in vertex_w]
+    check(lib().hyteg_hip_p1_sor_shell_cell(dst, rhs, rest, level, (C.c_int * 12)(*ev), (C.c_double * 18)(*ew), (C.c_int * 12)(*fv),
+                                            (C.c_double * 28)(*fw), (C.c_double * 4)(*vw), float(relax), mask, 1 if backwards else 0,
+                                            stream), "p1_sor_shell_cell")
 
 
 def p1_apply_face3d(dst, src, level, vmaps, ws, update=REPLACE, stream=0):

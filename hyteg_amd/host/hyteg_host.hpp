@@ -1123,6 +1123,28 @@ CellStencils assemble( const MacroCell& cell, uint_t level )
       }
    return S;
 }
+// Tables of the SOR / Gauss-Seidel sweep over the macro-vertices, -edges and -faces around a cell
+// (hyteg_hip_p1_sor_shell_cell): total weights over all neighbour cells, sweep orientations = the macro-primitives'
+// own orientations (vertex ids ascending, MeshInfo.cpp:37-72), and the cell's partial stencils without the weights
+// that the sweep handles itself (`rest`).
+struct CellSorTables
+{
+   double rest[14][15];
+   int    edgeVerts[6][2];
+   double edgeW[6][3];
+   int    faceVerts[4][3];
+   double faceW[4][7];
+   double vertexW[4];
+};
+inline int offsetIndex( int dx, int dy, int dz )
+{
+   for ( int k = 0; k < 15; ++k )
+      if ( kOffsets[k][0] == dx && kOffsets[k][1] == dy && kOffsets[k][2] == dz )
+         return k;
+   throw std::runtime_error( "offsetIndex: not a stencil direction" );
+}
+static const int kFaceDirs[6][2] = { { -1, 0 }, { 1, 0 }, { 0, -1 }, { 0, 1 }, { 1, -1 }, { -1, 1 } };
+static const int kUnit[4][3]     = { { 0, 0, 0 }, { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } };
 } // namespace stencil
 
 // =====================================================================================================
@@ -1147,6 +1169,7 @@ class P1ConstantOperator
          for ( const auto& cell : storage->getCells() ) // all cells: inverse diagonals need the neighbours' shares
             perCell.push_back( stencil::assemble< Form >( cell, l ) );
          stencils_[l] = perCell;
+         sorTables_[l] = buildSorTables( perCell );
          if ( l >= HYTEG_HIP_MIN_LEVEL )
             hipCheck( hyteg_hip_prepare_level( (int) l ), "P1ConstantOperator: prepare_level" );
       }
@@ -1240,23 +1263,69 @@ class P1ConstantOperator
       } );
    }
 
-   // P1Operator::smooth_sor / smooth_gs, P1Operator.hpp:322-418.  The macro-cell sweep is the reference's
-   // lexicographic one.  Sweeps over shared macro-faces/edges/vertices are not implemented yet (round 2).
+   // P1Operator::smooth_sor / smooth_gs, P1Operator.hpp:322-418: macro-vertices, -edges, -faces, -cells (reversed for
+   // backwards), each class with the values the reference's communication schedule gives it.  Cell-centric form:
+   //  rest  = (stencil sum over the neighbours outside the primitive's closure), summed over cells by ONE exchange,
+   //          taken from the pre-sweep state (forward) -- the reference's ghost layers are not refreshed in between;
+   //  sweep = every cell runs the vertex / edge / face sweeps on its own copies with the total weights (bit-identical
+   //          copies, no further exchange), then the lexicographic macro-cell sweep.
+   // Backwards the reference communicates before every class, so `rest` is rebuilt (and exchanged) per class.
    void smooth_sor( const P1Function< double >& dst, const P1Function< double >& rhs, double relax, uint_t level, DoFType flag,
                     bool backwards = false ) const
    {
-      if ( hasSharedPoints( level, flag ) )
-         throw std::runtime_error( "smooth_sor: SOR on macro-faces/edges/vertices shared by several cells is not implemented; "
-                                   "use smooth_jac on multi-cell meshes" );
-      forCells( [&]( uint_t c, const MacroCell& cell ) {
-         const unsigned mask = storage_->maskFor( cell, flag );
-         if ( mask & HYTEG_HIP_MASK_SHELL )
-            throw std::runtime_error( "smooth_sor: SOR on macro-cell boundary points (non-Dirichlet) is not implemented" );
-         if ( ( mask & HYTEG_HIP_MASK_INNER ) && level >= HYTEG_HIP_MIN_LEVEL )
-            hipCheck( hyteg_hip_p1_sor_cell( dst.getCellPointer( c, level ), rhs.getCellPointer( c, level ), (int) level,
-                                             getCellStencils( cell.id, level ).inner, relax, backwards ? 1 : 0, storage_->stream() ),
-                      "smooth_sor: cell" );
-      } );
+      if ( &dst == &rhs )
+         throw std::runtime_error( "smooth_sor: dst and rhs must differ" );
+      bool anyShell = false;
+      forCells( [&]( uint_t, const MacroCell& cell ) { anyShell = anyShell || ( storage_->maskFor( cell, flag ) & HYTEG_HIP_MASK_SHELL ); } );
+      auto sweepCells = [&]() {
+         forCells( [&]( uint_t c, const MacroCell& cell ) {
+            const unsigned mask = storage_->maskFor( cell, flag );
+            if ( ( mask & HYTEG_HIP_MASK_INNER ) && level >= HYTEG_HIP_MIN_LEVEL )
+               hipCheck( hyteg_hip_p1_sor_cell( dst.getCellPointer( c, level ), rhs.getCellPointer( c, level ), (int) level,
+                                                getCellStencils( cell.id, level ).inner, relax, backwards ? 1 : 0, storage_->stream() ),
+                         "smooth_sor: cell" );
+         } );
+      };
+      if ( !anyShell && storage_->numRanks() == 1 )
+      {
+         sweepCells();
+         return;
+      }
+      auto& restSlot = sorRest_[level];
+      if ( !restSlot )
+         restSlot.reset( new P1Function< double >( "sor_rest", storage_, level, level ) );
+      P1Function< double >& rest = *restSlot;
+      auto                 sweepShell = [&]( unsigned bits ) {
+         forCells( [&]( uint_t c, const MacroCell& cell ) {
+            const auto&    T    = sorTables_.at( level ).at( cell.id );
+            const unsigned mask = storage_->maskFor( cell, flag ) & bits;
+            hipCheck( hyteg_hip_p1_apply_cell_boundary( rest.getCellPointer( c, level ), dst.getCellPointer( c, level ), (int) level,
+                                                        &T.rest[0][0], mask, HYTEG_HIP_REPLACE, storage_->stream() ),
+                      "smooth_sor: rest" );
+         } );
+         rest.sumSharedCopies( level, flag );
+         forCells( [&]( uint_t c, const MacroCell& cell ) {
+            const auto&    T    = sorTables_.at( level ).at( cell.id );
+            const unsigned mask = storage_->maskFor( cell, flag ) & bits;
+            hipCheck( hyteg_hip_p1_sor_shell_cell( dst.getCellPointer( c, level ), rhs.getCellPointer( c, level ),
+                                                   rest.getCellPointer( c, level ), (int) level, &T.edgeVerts[0][0], &T.edgeW[0][0],
+                                                   &T.faceVerts[0][0], &T.faceW[0][0], T.vertexW, relax, mask, backwards ? 1 : 0,
+                                                   storage_->stream() ),
+                      "smooth_sor: shell" );
+         } );
+      };
+      if ( !backwards )
+      {
+         sweepShell( HYTEG_HIP_MASK_SHELL );
+         sweepCells();
+      }
+      else
+      {
+         sweepCells();
+         sweepShell( 0xFu << 6 );  // macro-faces
+         sweepShell( 0x3Fu );      // macro-edges
+         sweepShell( 0xFu << 10 ); // macro-vertices
+      }
    }
    void smooth_gs( const P1Function< double >& dst, const P1Function< double >& rhs, uint_t level, DoFType flag ) const
    {
@@ -1337,6 +1406,68 @@ class P1ConstantOperator
       for ( uint_t c = 0; c < storage_->getNumberOfLocalCells(); ++c )
          fn( c, storage_->getLocalCell( c ) );
    }
+   // total weights and sweep orientations of every macro-primitive, handed to each adjacent cell in its local numbering
+   std::vector< stencil::CellSorTables > buildSorTables( const std::vector< stencil::CellStencils >& S ) const
+   {
+      using namespace stencil;
+      const auto&                   cells = storage_->getCells();
+      std::vector< CellSorTables >  T( cells.size() );
+      std::vector< std::array< double, 3 > > edgeTot( storage_->getEdges().size(), std::array< double, 3 >{} );
+      std::vector< std::array< double, 7 > > faceTot( storage_->getFaces().size(), std::array< double, 7 >{} );
+      std::vector< double >                  vertTot( storage_->getVertices().size(), 0.0 );
+      for ( const auto& c : cells )
+      {
+         CellSorTables& t = T[c.id];
+         for ( int s = 0; s < 14; ++s )
+            for ( int k = 0; k < 15; ++k )
+               t.rest[s][k] = k == C ? 0.0 : S[c.id].slots[s][k];
+         for ( int k = 0; k < 4; ++k )
+            vertTot[c.v[k]] += S[c.id].slots[10 + k][C];
+         for ( int e = 0; e < 6; ++e )
+         {
+            int lo = kCellEdgeVerts[e][0], hi = kCellEdgeVerts[e][1];
+            if ( c.v[lo] > c.v[hi] )
+               std::swap( lo, hi );
+            const int kp = offsetIndex( kUnit[hi][0] - kUnit[lo][0], kUnit[hi][1] - kUnit[lo][1], kUnit[hi][2] - kUnit[lo][2] );
+            const int km = offsetIndex( kUnit[lo][0] - kUnit[hi][0], kUnit[lo][1] - kUnit[hi][1], kUnit[lo][2] - kUnit[hi][2] );
+            t.edgeVerts[e][0] = lo, t.edgeVerts[e][1] = hi;
+            auto& tot = edgeTot[c.edges[e]];
+            tot[0] += S[c.id].slots[e][C], tot[1] += S[c.id].slots[e][km], tot[2] += S[c.id].slots[e][kp];
+            t.rest[e][km] = t.rest[e][kp] = 0.0;
+         }
+         for ( int f = 0; f < 4; ++f )
+         {
+            int l[3] = { kCellFaceVerts[f][0], kCellFaceVerts[f][1], kCellFaceVerts[f][2] };
+            std::sort( l, l + 3, [&]( int a, int b ) { return c.v[a] < c.v[b]; } );
+            auto& tot = faceTot[c.faces[f]];
+            tot[0] += S[c.id].slots[6 + f][C];
+            for ( int d = 0; d < 6; ++d )
+            {
+               int o[3];
+               for ( int r = 0; r < 3; ++r )
+                  o[r] = kFaceDirs[d][0] * ( kUnit[l[1]][r] - kUnit[l[0]][r] ) + kFaceDirs[d][1] * ( kUnit[l[2]][r] - kUnit[l[0]][r] );
+               const int k = offsetIndex( o[0], o[1], o[2] );
+               tot[1 + d] += S[c.id].slots[6 + f][k];
+               t.rest[6 + f][k] = 0.0;
+            }
+            for ( int r = 0; r < 3; ++r )
+               t.faceVerts[f][r] = l[r];
+         }
+      }
+      for ( const auto& c : cells )
+      {
+         CellSorTables& t = T[c.id];
+         for ( int k = 0; k < 4; ++k )
+            t.vertexW[k] = vertTot[c.v[k]];
+         for ( int e = 0; e < 6; ++e )
+            for ( int k = 0; k < 3; ++k )
+               t.edgeW[e][k] = edgeTot[c.edges[e]][k];
+         for ( int f = 0; f < 4; ++f )
+            for ( int k = 0; k < 7; ++k )
+               t.faceW[f][k] = faceTot[c.faces[f]][k];
+      }
+      return T;
+   }
    bool hasSharedPoints( uint_t level, DoFType flag ) const
    {
       for ( int cls = 0; cls < 2; ++cls )
@@ -1348,6 +1479,8 @@ class P1ConstantOperator
    std::shared_ptr< PrimitiveStorage >                        storage_;
    uint_t                                                     minLevel_, maxLevel_;
    std::map< uint_t, std::vector< stencil::CellStencils > >   stencils_;
+   std::map< uint_t, std::vector< stencil::CellSorTables > >  sorTables_;
+   mutable std::map< uint_t, std::unique_ptr< P1Function< double > > > sorRest_;
    std::shared_ptr< P1Function< double > >                    inverseDiagonalValues_;
 };
 

@@ -272,6 +272,36 @@ HYTEG_HIP_API int hyteg_hip_p1_prolongate_cell_masked( const double*      coarse
                                                        unsigned           mask,
                                                        hyteg_hip_stream_t stream );
 
+/* a3 on the macro-cell boundary: SOR / Gauss-Seidel on the macro-vertices, macro-edges and macro-faces around one cell
+ * (vertexdof::macrovertex::smooth_sor, VertexDoFMacroVertex.hpp:231-251; P1Operator::smooth_sor_edge,
+ * P1Operator.hpp:1352-1421; P1Operator::smooth_sor_face3D / the generated sor_3D_macroface_P1, :1424-1503), in the order
+ * of P1Operator::smooth_sor (:348-418): vertices, edges, faces -- faces, edges, vertices if `backwards`.
+ * The reference sweeps each macro-primitive in its own memory with ghost layers; here the sweep runs in the cell's
+ * array on the points selected by `mask` (bits 0..13), with
+ *   rest       : for every selected point the stencil sum over all neighbours that are NOT on the same macro-primitive
+ *                (nor on its lower-dimensional boundary), already summed over all neighbour cells -- the ghost-layer
+ *                part of the reference's sum.  Overwritten on macro-face points (scratch).
+ *   edge_verts : [6][2] cell-local vertex numbers (a, b): edge e is swept from a to b (the macro-edge's orientation)
+ *   edge_w     : [6][3] total weights: centre, neighbour towards a, neighbour towards b
+ *   face_verts : [4][3] cell-local numbers of the macro-face's vertices 0, 1, 2 (rows y along 0->2, x along 0->1)
+ *   face_w     : [4][7] total weights: centre, then (-1,0) (1,0) (0,-1) (0,1) (1,-1) (-1,1) in face coordinates
+ *   vertex_w   : [4]    total centre weights
+ * (host arrays).  Every cell around a shared primitive runs the same sweep on its own copy, so the copies stay
+ * bit-identical without an exchange.  Levels 0..11. */
+HYTEG_HIP_API int hyteg_hip_p1_sor_shell_cell( double*            dst,
+                                               const double*      rhs,
+                                               double*            rest,
+                                               int                level,
+                                               const int*         edge_verts,
+                                               const double*      edge_w,
+                                               const int*         face_verts,
+                                               const double*      face_w,
+                                               const double*      vertex_w,
+                                               double             relax,
+                                               unsigned           mask,
+                                               int                backwards,
+                                               hyteg_hip_stream_t stream );
+
 /* a10: additive exchange of shared points (the reduce-into-owner of VertexDoFAdditivePackInfo.hpp:676-745,
  * followed by the copy back into every adjacent cell).  A group is one physical DoF; its entries are the
  * places that hold a partial value of it: (buffer index into `bases`, element offset).

@@ -776,3 +776,115 @@ HO_API void ho_apply_face3d( double* dst, const double* src, int level, int ncel
          dst[i]          = update ? dst[i] + tmp : tmp;
       }
 }
+
+/* ---- SOR / Gauss-Seidel on the macro-vertices, -edges and -faces around one cell, cell-centric restatement ----
+ * vertexdof::macrovertex::smooth_sor (src/hyteg/p1functionspace/VertexDoFMacroVertex.hpp:231-251),
+ * P1Operator::smooth_sor_edge (src/hyteg/p1functionspace/P1Operator.hpp:1352-1421) and
+ * P1Operator::smooth_sor_face3D (:1424-1503), called in this order by smooth_sor (:348-418; backwards: reversed).
+ * A macro-primitive is swept in its own memory there: its own points (and the lower-dimensional primitives on its
+ * boundary) carry current values, the ghost layers carry what the last communication delivered.  In the cell-centric
+ * storage the ghost-layer part of the sum, taken over ALL neighbour cells, is the input `rest`; the weights of the
+ * primitive's own points are the totals over all neighbour cells:
+ *   vertex_w[k]            centre weight of cell-local vertex k
+ *   edge_verts[e] = (a,b)  the edge runs from cell-local vertex a to b (the macro-edge's own orientation),
+ *   edge_w[e]     = centre, weight towards a, weight towards b
+ *   face_verts[f] = cell-local numbers of the macro-face's vertices 0, 1, 2 (x runs 0->1, y runs 0->2),
+ *   face_w[f]     = centre, then the in-plane neighbours (-1,0) (1,0) (0,-1) (0,1) (1,-1) (-1,1) in face coordinates.
+ * Order inside a primitive: edge index ascending, face rows y ascending and x ascending inside a row
+ * (vertexdof::macroface::Iterator( level, 1 )); descending for backwards. */
+static void unit_of_vertex( int k, int64_t n, int64_t* c )
+{
+   c[0] = k == 1 ? n : 0;
+   c[1] = k == 2 ? n : 0;
+   c[2] = k == 3 ? n : 0;
+}
+
+HO_API void ho_sor_shell_cell( double* dst, const double* rhs, const double* rest, int level, const int* edge_verts,
+                               const double* edge_w, const int* face_verts, const double* face_w, const double* vertex_w,
+                               double relax, unsigned mask, int backwards )
+{
+   const int64_t N = ho_width( level ), n = N - 1;
+   static const int FD[6][2] = { { -1, 0 }, { 1, 0 }, { 0, -1 }, { 0, 1 }, { 1, -1 }, { -1, 1 } };
+   for ( int phase = 0; phase < 3; ++phase )
+   {
+      const int cls = backwards ? 2 - phase : phase; /* 0 vertices, 1 edges, 2 faces */
+      if ( cls == 0 )
+      {
+         for ( int k = 0; k < 4; ++k )
+         {
+            if ( !point_selected( mask, 10 + k ) )
+               continue;
+            int64_t c[3];
+            unit_of_vertex( k, n, c );
+            const int64_t i   = cell_index_w( N, c[0], c[1], c[2] );
+            double        tmp = rhs[i];
+            tmp -= rest[i];
+            dst[i] = ( 1.0 - relax ) * dst[i] + relax * tmp / vertex_w[k];
+         }
+      }
+      else if ( cls == 1 )
+      {
+         for ( int e = 0; e < 6; ++e )
+         {
+            if ( !point_selected( mask, e ) )
+               continue;
+            int64_t o[3], ua[3], ub[3];
+            unit_of_vertex( edge_verts[2 * e], n, o );
+            unit_of_vertex( edge_verts[2 * e], 1, ua );
+            unit_of_vertex( edge_verts[2 * e + 1], 1, ub );
+            const int64_t d[3]            = { ub[0] - ua[0], ub[1] - ua[1], ub[2] - ua[2] };
+            const double  invCenterWeight = 1.0 / edge_w[3 * e];
+            for ( int64_t ii = backwards ? n - 1 : 1; ii != ( backwards ? 0 : n ); ii += backwards ? -1 : 1 )
+            {
+               const int64_t iC  = cell_index_w( N, o[0] + ii * d[0], o[1] + ii * d[1], o[2] + ii * d[2] );
+               const int64_t iW  = cell_index_w( N, o[0] + ( ii - 1 ) * d[0], o[1] + ( ii - 1 ) * d[1], o[2] + ( ii - 1 ) * d[2] );
+               const int64_t iE  = cell_index_w( N, o[0] + ( ii + 1 ) * d[0], o[1] + ( ii + 1 ) * d[1], o[2] + ( ii + 1 ) * d[2] );
+               double        tmp = rhs[iC];
+               tmp -= edge_w[3 * e + 1] * dst[iW] + edge_w[3 * e + 2] * dst[iE];
+               tmp -= rest[iC];
+               dst[iC] = ( 1.0 - relax ) * dst[iC] + relax * invCenterWeight * tmp;
+            }
+         }
+      }
+      else
+      {
+         for ( int f = 0; f < 4; ++f )
+         {
+            if ( !point_selected( mask, 6 + f ) )
+               continue;
+            int64_t o[3], u0[3], u1[3], u2[3];
+            unit_of_vertex( face_verts[3 * f], n, o );
+            unit_of_vertex( face_verts[3 * f], 1, u0 );
+            unit_of_vertex( face_verts[3 * f + 1], 1, u1 );
+            unit_of_vertex( face_verts[3 * f + 2], 1, u2 );
+            const double invCenterWeight = 1.0 / face_w[7 * f];
+            const int64_t count = ( n - 2 ) * ( n - 1 ) / 2; /* inner points of the face */
+            for ( int64_t q = 0; q < count; ++q )
+            {
+               /* q-th inner point in (y outer, x inner) order, reversed for backwards */
+               int64_t r = backwards ? count - 1 - q : q, y = 1, x;
+               while ( r >= n - 1 - y )
+               {
+                  r -= n - 1 - y;
+                  ++y;
+               }
+               x = 1 + r;
+               int64_t p[3];
+               for ( int a = 0; a < 3; ++a )
+                  p[a] = o[a] + x * ( u1[a] - u0[a] ) + y * ( u2[a] - u0[a] );
+               const int64_t iC  = cell_index_w( N, p[0], p[1], p[2] );
+               double        tmp = rhs[iC];
+               for ( int k = 0; k < 6; ++k )
+               {
+                  int64_t l[3];
+                  for ( int a = 0; a < 3; ++a )
+                     l[a] = p[a] + FD[k][0] * ( u1[a] - u0[a] ) + FD[k][1] * ( u2[a] - u0[a] );
+                  tmp -= face_w[7 * f + 1 + k] * dst[cell_index_w( N, l[0], l[1], l[2] )];
+               }
+               tmp -= rest[iC];
+               dst[iC] = ( 1.0 - relax ) * dst[iC] + relax * tmp * invCenterWeight;
+            }
+         }
+      }
+   }
+}

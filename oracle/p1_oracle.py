@@ -72,6 +72,7 @@ def _bind(lib):
         "ho_copy_face_to_cell": (None, [_P, _P, i, i, i, i]),
         "ho_copy_cell_to_face": (None, [_P, _P, i, i, i, i, i]),
         "ho_apply_face3d": (None, [_P, _P, i, i, C.POINTER(C.c_int), _P, i]),
+        "ho_sor_shell_cell": (None, [_P, _P, _P, i, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), _P, _P, d, C.c_uint, i]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)
@@ -302,6 +303,19 @@ def apply_face3d(dst, src, level, vmaps, ws, update=REPLACE):
     w = np.ascontiguousarray(ws, dtype=np.float64).reshape(-1, 15)
     assert len(vm) == len(w)
     lib().ho_apply_face3d(_p(dst), _p(src), level, len(vm), vm.ctypes.data_as(C.POINTER(C.c_int)), _p(w.reshape(-1)), update)
+    return dst
+
+
+def sor_shell_cell(dst, rhs, rest, level, edge_verts, edge_w, face_verts, face_w, vertex_w, relax, mask, backwards=False):
+    """vertices -> edges -> faces (reverse if backwards) of one cell; see ho_sor_shell_cell"""
+    ev = np.ascontiguousarray(edge_verts, dtype=np.int32).reshape(6, 2)
+    fv = np.ascontiguousarray(face_verts, dtype=np.int32).reshape(4, 3)
+    ew = np.ascontiguousarray(edge_w, dtype=np.float64).reshape(6, 3)
+    fw = np.ascontiguousarray(face_w, dtype=np.float64).reshape(4, 7)
+    vw = np.ascontiguousarray(vertex_w, dtype=np.float64).reshape(4)
+    lib().ho_sor_shell_cell(_p(dst), _p(rhs), _p(rest), level, ev.ctypes.data_as(C.POINTER(C.c_int)), _p(ew.reshape(-1)),
+                            fv.ctypes.data_as(C.POINTER(C.c_int)), _p(fw.reshape(-1)), _p(vw), float(relax), int(mask),
+                            1 if backwards else 0)
     return dst
 
 

@@ -387,8 +387,8 @@ def test_gmg_v33_gauss_seidel_single_macro_cell(env):
 
 def test_gmg_v33_jacobi_eight_macro_cells(env):
     """Same V(3,3) cycle on regular_octahedron_8el (the mesh of P1GMG3DConvergenceTest.cpp:52) with the weighted-Jacobi
-    smoother (SOR on shared macro-faces/edges/vertices is not implemented yet).  Damped Jacobi smooths less than
-    Gauss-Seidel, so the bound is the looser 0.15 per cycle in the squared residual (measured: ~0.05)."""
+    smoother (the Gauss-Seidel version, the reference's own, is in tests/test_gpu_sor_shell.py).  Damped Jacobi smooths less
+    than Gauss-Seidel, so the bound is the looser 0.15 per cycle in the squared residual (measured: ~0.05)."""
     torch, capi, host, po = env
     st = _storage(host, "regular_octahedron_8el")
     res = _vcycle_residuals(host, st, 2, 4, host.JACOBI, 2.0 / 3.0, 4)
