@@ -34,7 +34,7 @@ def _fields(host, storage, level):
 
 
 def _run(host, storage, level, ctx=None):
-    """apply + dot + one V(2,2) Jacobi cycle; returns {global cell id: arrays}"""
+    """apply + dot + one V(2,2) Jacobi cycle + a forward and a backward Gauss-Seidel sweep; returns {global cell id: arrays}"""
     A = host.P1ConstantOperator(storage, 2, level)
     A.compute_inverse_diagonal()
     u, r, b = (host.P1Function(storage, n, 2, level) for n in ("u", "r", "b"))
@@ -48,7 +48,11 @@ def _run(host, storage, level, ctx=None):
     gmg = host.Solver.gmg(storage, 2, level, smoother=host.JACOBI, relax=2.0 / 3.0, pre=2, post=2)
     gmg.solve(A, u, b, level)
     cycled = {storage.local_cell(c)[0]: u.download_cell(c, level) for c in range(storage.n_local_cells)}
-    return applied, dot, cycled
+    b.interpolate(1.0, level, host.All)
+    A.smooth_sor(u, b, 1.0, level, host.Inner, False)
+    A.smooth_sor(u, b, 1.0, level, host.Inner, True)
+    swept = {storage.local_cell(c)[0]: u.download_cell(c, level) for c in range(storage.n_local_cells)}
+    return applied, dot, cycled, swept
 
 
 def _worker(rank, world, port, level, q):
@@ -83,7 +87,7 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_rank_results():
     level, world = 3, 2
     st = host.Storage.from_gmsh(MESH)
     st.set_stream(torch.cuda.current_stream().cuda_stream)
-    ref_applied, ref_dot, ref_cycled = _run(host, st, level)
+    ref_applied, ref_dot, ref_cycled, ref_swept = _run(host, st, level)
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -96,11 +100,13 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_rank_results():
         p.join(timeout=60)
         assert p.exitcode == 0
     cells = 0
-    for rank, applied, dot, cycled in results:
+    for rank, applied, dot, cycled, swept in results:
         assert abs(dot - ref_dot) <= 1e-12 * abs(ref_dot)  # different partial-sum grouping across ranks
         for gid, arr in applied.items():
             assert np.array_equal(arr, ref_applied[gid]), f"apply differs on rank {rank}, cell {gid}"
             cells += 1
         for gid, arr in cycled.items():
             assert np.allclose(arr, ref_cycled[gid], rtol=1e-11, atol=1e-13), f"V-cycle differs on rank {rank}, cell {gid}"
+        for gid, arr in swept.items():
+            assert np.allclose(arr, ref_swept[gid], rtol=1e-11, atol=1e-13), f"Gauss-Seidel sweeps differ on rank {rank}, cell {gid}"
     assert cells == 8

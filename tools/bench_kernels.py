@@ -73,9 +73,23 @@ def main():
            8 * (n + nc), n)
     timeit("SOR forward sweep (hyperplane-exact)", lambda k: capi.p1_sor_cell(p(B, k), p(A, k), L, w, 1.0, False, sh), 24 * inner, inner,
            r=max(3, reps // 40))
+    # Gauss-Seidel on the cell's macro-vertices/-edges/-faces (what a multi-cell sweep adds per cell); octahedron weights
+    sys.path.insert(0, str(ROOT / "tests"))
+    import hostutil as hu  # noqa: E402
+
+    mv, mc = hu.read_msh(ROOT / "tests/golden/meshes/regular_octahedron_8el.msh")
+    T = hu.sor_tables(mv, mc, L)[0]
+    shell_pts = 4 * ((1 << L) + 1) * ((1 << L) + 2) // 2
+    timeit("SOR shell forward (4 faces, 6 edges, 4 vertices)",
+           lambda k: capi.p1_sor_shell_cell(p(B, k), p(A, k), p(Cc, k), L, T["edge_verts"], T["edge_w"], T["face_verts"], T["face_w"],
+                                            T["vertex_w"], 1.0, 0x3FFF, False, sh), 40 * shell_pts, shell_pts, r=max(3, reps // 10))
+    timeit("SOR shell backward", lambda k: capi.p1_sor_shell_cell(p(B, k), p(A, k), p(Cc, k), L, T["edge_verts"], T["edge_w"], T["face_verts"],
+                                                                  T["face_w"], T["vertex_w"], 1.0, 0x3FFF, True, sh),
+           40 * shell_pts, shell_pts, r=max(3, reps // 10))
     # V-cycles through the host layer
     for mesh, lo, hi, smoother, name in (("tet_1el", 2, L, host.JACOBI, "Jacobi(2/3)"), ("tet_1el", 2, min(L, 7), host.GAUSS_SEIDEL, "GS"),
-                                          ("regular_octahedron_8el", 2, min(L, 6), host.JACOBI, "Jacobi(2/3)")):
+                                          ("regular_octahedron_8el", 2, min(L, 6), host.JACOBI, "Jacobi(2/3)"),
+                                          ("regular_octahedron_8el", 0, min(L, 6), host.GAUSS_SEIDEL, "GS")):
         s2 = host.Storage.from_gmsh(ROOT / f"tests/golden/meshes/{mesh}.msh")
         s2.set_stream(sh)
         A2 = host.P1ConstantOperator(s2, lo, hi)
