@@ -37,6 +37,8 @@ __device__ inline bool inner_entry( int N, const Tile& tl, int s0, int i )
    return x >= 1 && x <= W - y - 2;
 }
 
+constexpr int kPerThread = kTile / kThreads; // entries per thread, all loads of a thread issued before the first use
+
 template < int OP, int NSRC >
 __global__ __launch_bounds__( kThreads ) void p1_vector_kernel( const VecArgs A )
 {
@@ -45,28 +47,42 @@ __global__ __launch_bounds__( kThreads ) void p1_vector_kernel( const VecArgs A 
       return;
    const Tile tl = A.tiles[t];
    const int  s0 = slice_start( A.N, tl.z );
-   for ( int e = threadIdx.x; e < tl.cnt; e += kThreads )
+   double     v[kPerThread][NSRC + 1];
+   bool       in[kPerThread];
+#pragma unroll
+   for ( int u = 0; u < kPerThread; ++u )
    {
-      const int i = tl.a + e;
-      if ( !inner_entry( A.N, tl, s0, i ) )
-         continue;
+      const int e = (int) threadIdx.x + u * kThreads;
+      const int i = tl.a + ( e < tl.cnt ? e : tl.cnt - 1 ); // clamped: the load is always legal, the store is predicated
+      in[u]       = e < tl.cnt && inner_entry( A.N, tl, s0, i );
+#pragma unroll
+      for ( int k = 0; k < NSRC; ++k )
+         v[u][k] = A.src[k][i];
+      if ( OP == OP_ADD )
+         v[u][NSRC] = A.dst[i];
+   }
+#pragma unroll
+   for ( int u = 0; u < kPerThread; ++u )
+   {
       double tmp;
       if ( OP == OP_MULT )
       {
-         tmp = A.src[0][i];
+         tmp = v[u][0];
 #pragma unroll
          for ( int k = 1; k < NSRC; ++k )
-            tmp *= A.src[k][i];
-         A.dst[i] = tmp;
+            tmp *= v[u][k];
       }
       else
       {
-         tmp = A.c[0] * A.src[0][i];
+         tmp = A.c[0] * v[u][0];
 #pragma unroll
          for ( int k = 1; k < NSRC; ++k )
-            tmp += A.c[k] * A.src[k][i];
-         A.dst[i] = ( OP == OP_ADD ) ? A.dst[i] + tmp : tmp;
+            tmp += A.c[k] * v[u][k];
+         if ( OP == OP_ADD )
+            tmp = v[u][NSRC] + tmp;
       }
+      if ( in[u] )
+         __builtin_nontemporal_store( tmp, &A.dst[tl.a + (int) threadIdx.x + u * kThreads] );
    }
 }
 
@@ -150,12 +166,20 @@ __global__ __launch_bounds__( kThreads ) void p1_dot_partial_kernel( const doubl
    {
       const Tile tl = tiles[t];
       const int  s0 = slice_start( N, tl.z );
-      for ( int e = threadIdx.x; e < tl.cnt; e += kThreads )
+      double     va[kPerThread], vb[kPerThread];
+      bool       in[kPerThread];
+#pragma unroll
+      for ( int u = 0; u < kPerThread; ++u )
       {
-         const int i = tl.a + e;
-         if ( inner_entry( N, tl, s0, i ) )
-            acc = fma( a[i], b[i], acc );
+         const int e = (int) threadIdx.x + u * kThreads;
+         const int i = tl.a + ( e < tl.cnt ? e : tl.cnt - 1 );
+         in[u]       = e < tl.cnt && inner_entry( N, tl, s0, i );
+         va[u]       = a[i];
+         vb[u]       = b[i];
       }
+#pragma unroll
+      for ( int u = 0; u < kPerThread; ++u )
+         acc = in[u] ? fma( va[u], vb[u], acc ) : acc;
    }
    const double r = block_sum( acc, sh );
    if ( threadIdx.x == 0 )
@@ -280,6 +304,9 @@ HYTEG_HIP_API int hyteg_hip_prepare_level( int level )
    if ( rc != HYTEG_HIP_OK )
       return rc;
    rc = get_tiles( level, TILES_FULL, kTile, &tt );
+   if ( rc != HYTEG_HIP_OK )
+      return rc;
+   rc = get_tiles( level, TILES_FULL, 256, &tt ); // restriction onto this level (p1_transfer.hip, kRestrictTile)
    if ( rc != HYTEG_HIP_OK )
       return rc;
    BrickTable bt;
