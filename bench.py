@@ -211,7 +211,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "p1_apply_zmarch_kernel<REPLACE,4,4>",
+                "kernel": "p1_apply_zmarch_kernel<REPLACE,NY=4,LZ=8>" if level >= 8 else "p1_apply_zmarch_kernel<REPLACE,NY=4,LZ=4>",
                 "achieved": achieved if world == 1 else None,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -134,6 +134,28 @@ __global__ __launch_bounds__( 256 ) void copy_w_kernel( T* __restrict__ dst, con
          dst[k] = v;
    }
 }
+// copy where every wave reads an unaligned 64-element window and writes only lanes 1..62 of it (the z-march kernel's
+// access shape: 496-byte stores that start and end inside a 64-byte sector); SHIFT = offset of the windows in elements
+template < bool NT, int ACTIVE >
+__global__ __launch_bounds__( 256 ) void copy_seg_kernel( double* __restrict__ dst, const double* __restrict__ src, int n, int shift )
+{
+   const int lane = threadIdx.x & 63;
+   const int nw   = gridDim.x * 4;
+   for ( int w = blockIdx.x * 4 + ( threadIdx.x >> 6 ); w * ACTIVE + shift < n; w += nw )
+   {
+      const int k = w * ACTIVE + shift + lane - ( 64 - ACTIVE ) / 2;
+      if ( k < 0 || k >= n )
+         continue;
+      const double v = src[k];
+      if ( lane >= ( 64 - ACTIVE ) / 2 && lane < ( 64 - ACTIVE ) / 2 + ACTIVE )
+      {
+         if ( NT )
+            __builtin_nontemporal_store( v, &dst[k] );
+         else
+            dst[k] = v;
+      }
+   }
+}
 template < typename T, bool NT >
 __global__ __launch_bounds__( 256 ) void fill_w_kernel( T* __restrict__ dst, T v, int n )
 {
@@ -264,6 +286,16 @@ int main( int argc, char** argv )
          timeit( nm, [&]( int b ) { hipLaunchKernelGGL( ( copy_w_kernel< d2, false > ), dim3( grid ), dim3( 256 ), 0, 0, (d2*) dst[b], (const d2*) src[b], total / 2 ); } );
          snprintf( nm, 96, "copy 16B/lane nt-store grid=%d", grid );
          timeit( nm, [&]( int b ) { hipLaunchKernelGGL( ( copy_w_kernel< d2, true > ), dim3( grid ), dim3( 256 ), 0, 0, (d2*) dst[b], (const d2*) src[b], total / 2 ); } );
+         snprintf( nm, 96, "copy seg 62-of-64 lanes nt shift=1 grid=%d", grid );
+         timeit( nm, [&]( int b ) { hipLaunchKernelGGL( ( copy_seg_kernel< true, 62 > ), dim3( grid ), dim3( 256 ), 0, 0, dst[b], src[b], total, 1 ); } );
+         snprintf( nm, 96, "copy seg 64-of-64 lanes nt shift=0 grid=%d", grid );
+         timeit( nm, [&]( int b ) { hipLaunchKernelGGL( ( copy_seg_kernel< true, 64 > ), dim3( grid ), dim3( 256 ), 0, 0, dst[b], src[b], total, 0 ); } );
+         snprintf( nm, 96, "copy seg 64-of-64 lanes nt shift=3 grid=%d", grid );
+         timeit( nm, [&]( int b ) { hipLaunchKernelGGL( ( copy_seg_kernel< true, 64 > ), dim3( grid ), dim3( 256 ), 0, 0, dst[b], src[b], total, 3 ); } );
+         snprintf( nm, 96, "copy seg 56-of-64 lanes nt shift=0 grid=%d", grid );
+         timeit( nm, [&]( int b ) { hipLaunchKernelGGL( ( copy_seg_kernel< true, 56 > ), dim3( grid ), dim3( 256 ), 0, 0, dst[b], src[b], total, 4 ); } );
+         snprintf( nm, 96, "copy seg 62-of-64 lanes plain shift=1 grid=%d", grid );
+         timeit( nm, [&]( int b ) { hipLaunchKernelGGL( ( copy_seg_kernel< false, 62 > ), dim3( grid ), dim3( 256 ), 0, 0, dst[b], src[b], total, 1 ); } );
          snprintf( nm, 96, "fill 8B/lane grid=%d", grid );
          timeit( nm, [&]( int b ) { hipLaunchKernelGGL( ( fill_w_kernel< double, false > ), dim3( grid ), dim3( 256 ), 0, 0, dst[b], 1.5, total ); } );
          snprintf( nm, 96, "fill 16B/lane grid=%d", grid );
@@ -641,9 +673,11 @@ int main( int argc, char** argv )
          int nblocks = ( A.ntasks + kZMarchWavesPerBlock - 1 ) / kZMarchWavesPerBlock;
          nblocks     = ( nblocks + 7 ) & ~7;
          A.xcd_chunk = xcd ? nblocks / 8 : 0;
+         A.relax = 0.66;
          auto launch = [&]( int b ) {
             A.dst = dst[b];
             A.src = src[b];
+            A.rhs = src[( b + 1 ) % nbuf]; // only read by the Jacobi instantiations
             hipLaunchKernelGGL( kern, dim3( nblocks ), dim3( 64 * kZMarchWavesPerBlock ), 0, 0, A );
          };
          CK( hipMemset( dst[0], 0, (size_t) total * 8 ) );
@@ -680,6 +714,120 @@ int main( int argc, char** argv )
          run( 8, 8, xcd, p1_apply_zmarch_kernel< APPLY_REPLACE, 8, 8 > );
       }
       run( 4, 8, 0, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 8 > );
+      if ( want( "zfact" ) )
+      {
+         filter = "";
+         printf( "unfactorised shifts (8 per output): NY,LZ = 4,4  4,8  2,8\n" );
+         run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 0, 2, 0, 0 > );
+         run( 4, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 8, 0, 2, 0, 0 > );
+         run( 2, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 2, 8, 0, 2, 0, 0 > );
+         printf( "factorised, ablations (none / no stores / no arithmetic / neither) at 4,4:\n" );
+         run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 0 > );
+         run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 4 > );
+         run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 8 > );
+         run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 12 > );
+         filter = "zfact";
+      }
+      if ( want( "zpf" ) )
+      {
+         filter = "";
+         printf( "all loads before the first store: NY,LZ = 4,4  4,2  2,4  4,3  2,8  4,6  (then 4,4 without stores)\n" );
+         run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 0, 2, 0, 1, true > );
+         run( 4, 2, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 2, 0, 2, 0, 1, true > );
+         run( 2, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 2, 4, 0, 2, 0, 1, true > );
+         run( 4, 3, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 3, 0, 2, 0, 1, true > );
+         run( 2, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 2, 8, 0, 2, 0, 1, true > );
+         run( 4, 6, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 6, 0, 2, 0, 1, true > );
+         run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 4, 2, 0, true, true > );
+         printf( "same with plain (aux 0) stores: 4,4  2,4\n" );
+         run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 0, 0, 0, 1, true > );
+         run( 2, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 2, 4, 0, 0, 0, 1, true > );
+         filter = "zpf";
+      }
+      if ( want( "zmask" ) )
+      {
+         filter = "";
+         printf( "loads masked beyond the row end: NY,LZ = 4,4  4,8  2,8  2,4  6,4 (then 4,4: no stores / neither)\n" );
+         run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 0, 2, 0, 1, false, true > );
+         run( 4, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 8, 0, 2, 0, 1, false, true > );
+         run( 2, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 2, 8, 0, 2, 0, 1, false, true > );
+         run( 2, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 2, 4, 0, 2, 0, 1, false, true > );
+         run( 6, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 6, 4, 0, 2, 0, 1, false, true > );
+         run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 4, 2, 0, true, false, true > );
+         run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 12, 2, 0, true, false, true > );
+         filter = "zmask";
+      }
+      if ( want( "zilp" ) )
+      {
+         filter = "";
+         printf( "rows evaluated side by side (FACT=2): NY,LZ = 4,4  4,8  2,8  2,4  6,4  8,4 | 4,4 masked loads | 4,4 serial (FACT=1)\n" );
+         run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 0, 2, 0, 2 > );
+         run( 4, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 8, 0, 2, 0, 2 > );
+         run( 2, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 2, 8, 0, 2, 0, 2 > );
+         run( 2, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 2, 4, 0, 2, 0, 2 > );
+         run( 6, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 6, 4, 0, 2, 0, 2 > );
+         run( 8, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 8, 4, 0, 2, 0, 2 > );
+         run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 0, 2, 0, 2, false, true > );
+         run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 0, 2, 0, 1 > );
+         filter = "zilp";
+      }
+      if ( want( "zfinal" ) )
+      {
+         filter = "";
+         printf( "candidates: 4,4,F0 | 4,8,F1,mask | 4,8,F2,mask | 4,4,F1,mask | 2,8,F1,mask | 4,8,F1 | 4,6,F1,mask | 3,6,F1,mask\n" );
+         for ( int rep = 0; rep < 2; ++rep )
+         {
+            run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 0, 2, 0, 0 > );
+            run( 4, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 8, 0, 2, 0, 1, false, true > );
+            run( 4, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 8, 0, 2, 0, 2, false, true > );
+            run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 0, 2, 0, 1, false, true > );
+            run( 2, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 2, 8, 0, 2, 0, 1, false, true > );
+            run( 4, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 8, 0, 2, 0, 1 > );
+            run( 4, 6, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 6, 0, 2, 0, 1, false, true > );
+            run( 3, 6, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 3, 6, 0, 2, 0, 1, false, true > );
+         }
+         filter = "zfinal";
+      }
+      if ( want( "zmodes" ) )
+      {
+         filter = "";
+         printf( "ADD: 4,4,F0 | 4,4,F1,mask | 4,4,F1 | 4,8,F1,mask | 2,4,F1,mask | 4,2,F1,mask ; then the same for JACOBI (maxdiff not meaningful)\n" );
+         for ( int rep = 0; rep < 2; ++rep )
+         {
+            run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_ADD, 4, 4, 0, 2, 0, 0 > );
+            run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_ADD, 4, 4, 0, 2, 0, 1, false, true > );
+            run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_ADD, 4, 4, 0, 2, 0, 1 > );
+            run( 4, 8, 1, p1_apply_zmarch_kernel< APPLY_ADD, 4, 8, 0, 2, 0, 1, false, true > );
+            run( 2, 4, 1, p1_apply_zmarch_kernel< APPLY_ADD, 2, 4, 0, 2, 0, 1, false, true > );
+            run( 4, 2, 1, p1_apply_zmarch_kernel< APPLY_ADD, 4, 2, 0, 2, 0, 1, false, true > );
+         }
+         for ( int rep = 0; rep < 2; ++rep )
+         {
+            run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_JACOBI, 4, 4, 0, 2, 0, 0 > );
+            run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_JACOBI, 4, 4, 0, 2, 0, 1, false, true > );
+            run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_JACOBI, 4, 4, 0, 2, 0, 1 > );
+            run( 4, 8, 1, p1_apply_zmarch_kernel< APPLY_JACOBI, 4, 8, 0, 2, 0, 1, false, true > );
+            run( 2, 4, 1, p1_apply_zmarch_kernel< APPLY_JACOBI, 2, 4, 0, 2, 0, 1, false, true > );
+            run( 4, 2, 1, p1_apply_zmarch_kernel< APPLY_JACOBI, 4, 2, 0, 2, 0, 1, false, true > );
+         }
+         filter = "zmodes";
+      }
+      if ( want( "zaddaux" ) )
+      {
+         filter = "";
+         printf( "ADD 4,4,F1: st nt/ld plain | st plain/ld plain | st nt/ld nt | st plain/ld nt | st sc1/ld plain | st nt/ld sc1 | st nt+sc0 / ld sc0\n" );
+         for ( int rep = 0; rep < 2; ++rep )
+         {
+            run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_ADD, 4, 4, 0, 2, 0, 1, false, false, 0 > );
+            run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_ADD, 4, 4, 0, 0, 0, 1, false, false, 0 > );
+            run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_ADD, 4, 4, 0, 2, 0, 1, false, false, 2 > );
+            run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_ADD, 4, 4, 0, 0, 0, 1, false, false, 2 > );
+            run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_ADD, 4, 4, 0, 16, 0, 1, false, false, 0 > );
+            run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_ADD, 4, 4, 0, 2, 0, 1, false, false, 16 > );
+            run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_ADD, 4, 4, 0, 3, 0, 1, false, false, 1 > );
+         }
+         filter = "zaddaux";
+      }
       if ( want( "zaux" ) )
       {
          filter = "";

@@ -85,7 +85,17 @@ __device__ inline double zm_lane_plus_1( double v )
 // lines for the end-of-kernel L2 write-back).  ABL: developer ablation switches, 0 in production
 // (4 = no stores, 8 = no stencil arithmetic).
 constexpr int kStoreAuxDefault = 2;
-template < int MODE, int NY, int LZ, int ABL = 0, int ST_AUX = kStoreAuxDefault, int LD_AUX = 0 >
+// FACT: the eight x-shifted stencil terms are summed per shift direction BEFORE the lane shift (two wave shifts per
+// output instead of eight; the shifts were half of the kernel's VALU time).  Changes the summation order, not the terms.
+// FACT == 2 additionally evaluates the NY rows of a step side by side (16 independent FMA chains instead of one 8-deep
+// chain per row): measured equal to FACT == 1 within noise at levels 6..9, kept for the harness only.
+// PFALL: all source loads of the brick are issued before the first store (tests whether loads queue behind the
+// nontemporal stores in the wave's in-order vmcnt): measured 4-5% SLOWER at level 8, harness only.
+// MASKLD: lanes whose x lies beyond the end of the row being loaded get an out-of-range offset (the buffer range check
+// returns 0 without touching the cache) instead of fetching the next row's entries: ~30% of all lanes at level 8.
+// Also means the kernel never reads past the end of the source array.  Level 8: -1..2%.
+template < int MODE, int NY, int LZ, int ABL = 0, int ST_AUX = kStoreAuxDefault, int LD_AUX = 0, int FACT = 1, bool PFALL = false,
+           bool MASKLD = false, int EX_AUX = 0 >
 __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_kernel( const ZMarchArgs A )
 {
    int b = blockIdx.x;
@@ -122,7 +132,15 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_k
          // slice 0 is only ever a "down" slice (rows y0..y0+NY), the last one only an "up" slice (rows ym..)
          const bool need = ( q == 0 ) ? ( r >= 1 ) : ( q == LZ + 1 ? ( r <= NY ) : true );
          if ( need )
-            S[q][r] = zm_load< LD_AUX >( rs, ix * 8 + lane_off );
+         {
+            if constexpr ( MASKLD )
+            {
+               const int last = W_q - ( ym + r ) - 1 - t.xb; // lane holding the last entry of this row
+               S[q][r]        = zm_load< LD_AUX >( rs, lane <= last ? ix * 8 + lane_off : -8 );
+            }
+            else
+               S[q][r] = zm_load< LD_AUX >( rs, ix * 8 + lane_off );
+         }
          ix += W_q - ( ym + r ); // next row of the same slice
       }
    };
@@ -140,6 +158,13 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_k
    load_slice( std::integral_constant< int, 0 >{}, baseq[0], Wqs[0] );
    load_slice( std::integral_constant< int, 1 >{}, baseq[1], Wqs[1] );
    load_slice( std::integral_constant< int, 2 >{}, baseq[2], Wqs[2] );
+   if constexpr ( PFALL )
+   {
+      [&]< int... Is >( std::integer_sequence< int, Is... > ) {
+         ( load_slice( std::integral_constant< int, Is + 3 >{}, baseq[Is + 3], Wqs[Is + 3] ), ... );
+      }
+      ( std::make_integer_sequence< int, LZ - 1 >{} );
+   }
 
    const double* w       = A.st.w;
    const double  invc    = 1.0 / w[7];
@@ -149,7 +174,7 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_k
    auto step = [&]( auto sc ) {
       constexpr int s = decltype( sc )::value; // output slice z0 + s, centre q = s+1
       constexpr int q = s + 1;
-      if constexpr ( q + 2 <= LZ + 1 )
+      if constexpr ( q + 2 <= LZ + 1 && !PFALL )
          load_slice( std::integral_constant< int, q + 2 >{}, baseq[q + 2], Wqs[q + 2] );
 
       const int W  = Wqs[q];
@@ -164,43 +189,107 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_k
          for ( int j = 0; j < NY; ++j )
          {
             const int off = ie * 8 + lane_off;
-            ex0[j]        = MODE == APPLY_ADD ? zm_load( rd, off ) : zm_load( rr, off );
-            ex1[j]        = ( MODE == APPLY_JACOBI && A.invdiag ) ? zm_load( ri, off ) : invc;
+            ex0[j]        = MODE == APPLY_ADD ? zm_load< EX_AUX >( rd, off ) : zm_load< EX_AUX >( rr, off );
+            ex1[j]        = ( MODE == APPLY_JACOBI && A.invdiag ) ? zm_load( ri, off ) : invc; // nt here: 18.8 -> 21.0 us
             ie += W - ( t.y0 + j );
          }
       }
+      double accs[NY];
+      if constexpr ( FACT == 2 && ( ABL & 8 ) == 0 )
+      {
+         double pe[NY], pw[NY], s1[NY], s2[NY];
+#define ZM_ROWS( expr )               \
+   _Pragma( "unroll" ) for ( int j = 0; j < NY; ++j ) \
+   {                                  \
+      const double am = S[q][j], a0 = S[q][j + 1], ap = S[q][j + 2];          \
+      const double um = S[q + 1][j], u0 = S[q + 1][j + 1];                    \
+      const double d0 = S[q - 1][j + 1], dp = S[q - 1][j + 2];                \
+      (void) am, (void) a0, (void) ap, (void) um, (void) u0, (void) d0, (void) dp; \
+      expr;                           \
+   }
+         // pe: what the lane to the left needs from this lane (E, SE, TSE, BE); pw: what the lane to the right needs
+         // (W, TW, BNW, NW); s1, s2: the seven unshifted terms
+         ZM_ROWS( pe[j] = w[8] * a0 )
+         ZM_ROWS( pw[j] = w[6] * a0 )
+         ZM_ROWS( s1[j] = w[3] * dp )
+         ZM_ROWS( s2[j] = w[4] * am )
+         ZM_ROWS( pe[j] = fma( w[5], am, pe[j] ) )
+         ZM_ROWS( pw[j] = fma( w[13], u0, pw[j] ) )
+         ZM_ROWS( s1[j] = fma( w[10], ap, s1[j] ) )
+         ZM_ROWS( s2[j] = fma( w[11], um, s2[j] ) )
+         ZM_ROWS( pe[j] = fma( w[12], um, pe[j] ) )
+         ZM_ROWS( pw[j] = fma( w[2], dp, pw[j] ) )
+         ZM_ROWS( s1[j] = fma( w[0], d0, s1[j] ) )
+         ZM_ROWS( s2[j] = fma( w[7], a0, s2[j] ) )
+         ZM_ROWS( pe[j] = fma( w[1], d0, pe[j] ) )
+         ZM_ROWS( pw[j] = fma( w[9], ap, pw[j] ) )
+         ZM_ROWS( s1[j] = fma( w[14], u0, s1[j] ) )
+         ZM_ROWS( s1[j] = s1[j] + s2[j] )
+         ZM_ROWS( pe[j] = zm_lane_plus_1( pe[j] ) + zm_lane_minus_1( pw[j] ) )
+         ZM_ROWS( accs[j] = pe[j] + s1[j] )
+#undef ZM_ROWS
+      }
+      else
+      {
 #pragma unroll
       for ( int j = 0; j < NY; ++j )
       {
-         const int    R  = W - ( t.y0 + j );
          const double am = S[q][j], a0 = S[q][j + 1], ap = S[q][j + 2];
          const double um = S[q + 1][j], u0 = S[q + 1][j + 1];
          const double d0 = S[q - 1][j + 1], dp = S[q - 1][j + 2];
          double       acc;
          if constexpr ( ( ABL & 8 ) != 0 )
             acc = am + a0 + ap + um + u0 + d0 + dp;
+         else if constexpr ( FACT == 1 )
+         {
+            double pe = w[8] * a0; // what the lane to the left needs from this lane: E, SE, TSE, BE
+            pe        = fma( w[5], am, pe );
+            pe        = fma( w[12], um, pe );
+            pe        = fma( w[1], d0, pe );
+            double pw = w[6] * a0; // what the lane to the right needs: W, TW, BNW, NW
+            pw        = fma( w[13], u0, pw );
+            pw        = fma( w[2], dp, pw );
+            pw        = fma( w[9], ap, pw );
+            acc       = zm_lane_plus_1( pe ) + zm_lane_minus_1( pw );
+            acc       = fma( w[3], dp, acc );  // BN
+            acc       = fma( w[10], ap, acc ); // N
+            acc       = fma( w[4], am, acc );  // S
+            acc       = fma( w[11], um, acc ); // TS
+            acc       = fma( w[0], d0, acc );  // BC
+            acc       = fma( w[7], a0, acc );  // C
+            acc       = fma( w[14], u0, acc ); // TC
+         }
          else
          {
-         acc = w[6] * zm_lane_minus_1( a0 );           // W
-         acc = fma( w[3], dp, acc );                   // BN
-         acc = fma( w[10], ap, acc );                  // N
-         acc = fma( w[5], zm_lane_plus_1( am ), acc ); // SE
-         acc = fma( w[12], zm_lane_plus_1( um ), acc ); // TSE
-         acc = fma( w[1], zm_lane_plus_1( d0 ), acc ); // BE
-         acc = fma( w[8], zm_lane_plus_1( a0 ), acc ); // E
-         acc = fma( w[13], zm_lane_minus_1( u0 ), acc ); // TW
-         acc = fma( w[2], zm_lane_minus_1( dp ), acc ); // BNW
-         acc = fma( w[9], zm_lane_minus_1( ap ), acc ); // NW
-         acc = fma( w[4], am, acc );                   // S
-         acc = fma( w[11], um, acc );                  // TS
-         acc = fma( w[0], d0, acc );                   // BC
-         acc = fma( w[7], a0, acc );                   // C
-         acc = fma( w[14], u0, acc );                  // TC
+            // the reference's summation order (apply_3D_macrocell_vertexdof_to_vertexdof_replace)
+            acc = w[6] * zm_lane_minus_1( a0 );             // W
+            acc = fma( w[3], dp, acc );                     // BN
+            acc = fma( w[10], ap, acc );                    // N
+            acc = fma( w[5], zm_lane_plus_1( am ), acc );   // SE
+            acc = fma( w[12], zm_lane_plus_1( um ), acc );  // TSE
+            acc = fma( w[1], zm_lane_plus_1( d0 ), acc );   // BE
+            acc = fma( w[8], zm_lane_plus_1( a0 ), acc );   // E
+            acc = fma( w[13], zm_lane_minus_1( u0 ), acc ); // TW
+            acc = fma( w[2], zm_lane_minus_1( dp ), acc );  // BNW
+            acc = fma( w[9], zm_lane_minus_1( ap ), acc );  // NW
+            acc = fma( w[4], am, acc );                     // S
+            acc = fma( w[11], um, acc );                    // TS
+            acc = fma( w[0], d0, acc );                     // BC
+            acc = fma( w[7], a0, acc );                     // C
+            acc = fma( w[14], u0, acc );                    // TC
          }
-
-         const bool active = lane_ok && x <= R - 2 && s < t.nz;
-         const int  off    = io * 8 + lane_off;
-         double     out;
+         accs[j] = acc;
+      }
+      }
+#pragma unroll
+      for ( int j = 0; j < NY; ++j )
+      {
+         const int    R      = W - ( t.y0 + j );
+         const double a0     = S[q][j + 1];
+         const double acc    = accs[j];
+         const bool   active = lane_ok && x <= R - 2 && s < t.nz;
+         const int    off    = io * 8 + lane_off;
+         double       out;
          if ( MODE == APPLY_REPLACE )
             out = acc;
          else if ( MODE == APPLY_ADD )

@@ -309,7 +309,10 @@ HYTEG_HIP_API int hyteg_hip_prepare_level( int level )
    rc = get_tiles( level, TILES_FULL, 256, &tt ); // restriction onto this level (p1_transfer.hip, kRestrictTile)
    if ( rc != HYTEG_HIP_OK )
       return rc;
-   BrickTable bt;
-   return get_bricks( level, 4, 4, &bt );
+   BrickTable bt; // same shapes as p1_apply.hip: 4 x 8 for Replace from level 8 on, 4 x 4 otherwise
+   rc = get_bricks( level, 4, 4, &bt );
+   if ( rc != HYTEG_HIP_OK || level < 8 )
+      return rc;
+   return get_bricks( level, 4, 8, &bt );
 }
 }

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Post-process the PMC passes of hyteg_amd/csrc/exp/pmc_bench.sh (gpurun_out/pmc_bench/) into profiles/pmc_traffic.json:
+HBM bytes per launch of the apply kernel, FETCH_SIZE corrected with the factor calibrated in the same session on a copy
+kernel of known size and the same access width (MI355X_MICROARCH.md, HBM / rocprofv3 section).
+Usage: python tools/pmc_traffic.py [gpurun_out/pmc_bench] [round tag]"""
+import csv
+import glob
+import json
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+src = Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "gpurun_out" / "pmc_bench"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+COPY_BYTES = 2862209 * 8  # one level-8 cell array, read once and written once by the calibration copy kernel
+
+
+def mean_counter(prefix, kernel_substr, counter):
+    vals = []
+    for f in glob.glob(str(src / f"{prefix}_*" / "**" / "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                vals.append(float(r["Counter_Value"]))
+    return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
+
+
+fetch, nf = mean_counter("bench", "p1_apply_zmarch_kernel", "FETCH_SIZE")
+write, nw = mean_counter("bench", "p1_apply_zmarch_kernel", "WRITE_SIZE")
+cfetch, _ = mean_counter("calib", "copy_w_kernel<double, false>", "FETCH_SIZE")
+cwrite, _ = mean_counter("calib", "copy_w_kernel<double, false>", "WRITE_SIZE")
+kname = None
+for f in glob.glob(str(src / "bench_*" / "**" / "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "p1_apply_zmarch_kernel" in r["Kernel_Name"]:
+            kname = r["Kernel_Name"].split("(")[0]
+            break
+    if kname:
+        break
+if None in (fetch, write, cfetch, cwrite):
+    raise SystemExit(f"missing counters under {src}: fetch={fetch} write={write} calib fetch={cfetch} write={cwrite}")
+kf, kw = COPY_BYTES / (cfetch * 1024), COPY_BYTES / (cwrite * 1024)
+read_b, write_b = fetch * 1024 * kf, write * 1024 * kw
+alg = 2731135 * 16
+out = {
+    "p1_apply_zmarch_kernel_bytes_per_launch": int(round(read_b + write_b)),
+    "read_bytes": int(round(read_b)),
+    "write_bytes": int(round(write_b)),
+    "kernel": kname,
+    "method": "rocprofv3 --kernel-trace --pmc, separate passes for FETCH_SIZE and WRITE_SIZE over `python3 bench.py --steps 200 "
+              f"--warmup 20 --no-cpu-baseline` ({nf} / {nw} dispatches, level 8, rotating buffers); counters are in KiB "
+              "(hyteg_amd/csrc/exp/pmc_bench.sh, tools/pmc_traffic.py)",
+    "raw": {"FETCH_SIZE_avg_KiB": fetch, "WRITE_SIZE_avg_KiB": write, "calib_FETCH_SIZE_avg_KiB": cfetch, "calib_WRITE_SIZE_avg_KiB": cwrite},
+    "gfx950_correction": f"calibration copy kernel (8 B per lane, {COPY_BYTES} B known each way): FETCH_SIZE*1024*{kf:.3f} = known bytes, "
+                         f"WRITE_SIZE*1024*{kw:.3f} = known bytes; the apply's figures use these factors "
+                         "(FETCH_SIZE reports half of a coalesced stream on gfx950, MI355X_MICROARCH.md)",
+    "algorithmic_bytes_per_launch": alg,
+    "traffic_over_algorithmic": round((read_b + write_b) / alg, 3),
+    "round": tag,
+}
+(ROOT / "profiles" / "pmc_traffic.json").write_text(json.dumps(out, indent=1) + "\n")
+print(json.dumps(out, indent=1))
