@@ -54,6 +54,13 @@ SIGNATURES = {
     "hyteg_hip_copy_shared": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "hyteg_hip_p1_copy_face_to_cell": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "hyteg_hip_p1_copy_cell_to_face": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "hyteg_hip_p1_vector_cells": (_i, [_i, _i, C.POINTER(_vp), _i, C.POINTER(_vp), _dp, _i, C.POINTER(C.c_uint), _vp]),
+    "hyteg_hip_p1_dot_cells": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), _i, C.POINTER(C.c_uint), _vp, _vp, _vp]),
+    "hyteg_hip_p1_apply_cells": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), _i, _vp, C.POINTER(C.c_uint), _i, _vp]),
+    "hyteg_hip_p1_jacobi_cells": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i, _vp, _d,
+                                        C.POINTER(C.c_uint), _i, _vp]),
+    "hyteg_hip_p1_restrict_cells": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), _i, _vp, C.POINTER(C.c_uint), _vp]),
+    "hyteg_hip_p1_prolongate_cells": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), _i, _vp, C.POINTER(C.c_uint), _i, _vp]),
     "hyteg_hip_p1_sor_shell_cell": (_i, [_vp, _vp, _vp, _i, C.POINTER(_i), _dp, C.POINTER(_i), _dp, _dp, _d, C.c_uint, _i, _vp]),
     "hyteg_hip_p1_apply_face3d": (_i, [_vp, _vp, _i, _i, C.POINTER(_i), _dp, _i, _vp]),
     "hyteg_hip_gather_entries": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
@@ -212,6 +219,46 @@ def p1_copy_face_to_cell(cell, face, level, v, stream=0):
 def p1_copy_cell_to_face(face, cell, level, v, neighbor, stream=0):
     check(lib().hyteg_hip_p1_copy_cell_to_face(face, cell, level, int(v[0]), int(v[1]), int(v[2]), int(neighbor), stream),
           "p1_copy_cell_to_face")
+
+
+def _ptrs(ps):
+    return (C.c_void_p * len(ps))(*[int(p) for p in ps])
+
+
+def _masks(ms):
+    return (C.c_uint * len(ms))(*[int(m) for m in ms])
+
+
+def p1_vector_cells(op, dst, srcs, scalars, level, masks, stream=0):
+    """dst: list of device pointers (one per cell); srcs: list (per function) of lists (per cell)"""
+    n = len(dst)
+    flat = [p for f in srcs for p in f]
+    sc = (C.c_double * max(1, len(scalars or [])))(*[float(v) for v in (scalars or [0.0])])
+    check(lib().hyteg_hip_p1_vector_cells(op, n, _ptrs(dst), len(srcs), _ptrs(flat) if flat else None, sc if scalars is not None else None,
+                                          level, _masks(masks), stream), "p1_vector_cells")
+
+
+def p1_dot_cells(a, b, level, masks, result_dev, workspace_dev, stream=0):
+    check(lib().hyteg_hip_p1_dot_cells(len(a), _ptrs(a), _ptrs(b), level, _masks(masks), result_dev, workspace_dev, stream), "p1_dot_cells")
+
+
+def p1_apply_cells(dst, src, level, stencils_dev, masks, update=REPLACE, stream=0):
+    check(lib().hyteg_hip_p1_apply_cells(len(dst), _ptrs(dst), _ptrs(src), level, stencils_dev, _masks(masks), update, stream), "p1_apply_cells")
+
+
+def p1_jacobi_cells(dst, rhs, src, invdiag, level, stencils_dev, relax, masks, phase, stream=0):
+    check(lib().hyteg_hip_p1_jacobi_cells(len(dst), _ptrs(dst), _ptrs(rhs), _ptrs(src), _ptrs(invdiag), level, stencils_dev, float(relax),
+                                          _masks(masks), phase, stream), "p1_jacobi_cells")
+
+
+def p1_restrict_cells(coarse, fine, coarse_level, nnc_inv_dev, masks, stream=0):
+    check(lib().hyteg_hip_p1_restrict_cells(len(coarse), _ptrs(coarse), _ptrs(fine), coarse_level, nnc_inv_dev, _masks(masks), stream),
+          "p1_restrict_cells")
+
+
+def p1_prolongate_cells(coarse, fine, coarse_level, nnc_inv_dev, masks, update=REPLACE, stream=0):
+    check(lib().hyteg_hip_p1_prolongate_cells(len(coarse), _ptrs(coarse), _ptrs(fine), coarse_level, nnc_inv_dev, _masks(masks), update, stream),
+          "p1_prolongate_cells")
 
 
 def p1_sor_shell_cell(dst, rhs, rest, level, edge_verts, edge_w, face_verts, face_w, vertex_w, relax, mask, backwards=False, stream=0):

@@ -1,0 +1,570 @@
+// Batched forms of the P1 kernels: ONE launch covers all macro-cells a rank owns (grid.y = cell) and both the inner and
+// the boundary points of every cell (the 15-bit point mask selects, the point's class selects the stencil).
+// They exist for the coarse and middle levels of a multi-cell V-cycle, where a level-2..6 cell has 35..48k points and
+// the per-cell kernels of the other files spend their time in launch latency: regular_octahedron_8el needed ~5,500
+// launches of 2-6 us kernels per V(3,3) cycle.  The fine levels keep the tuned per-cell kernels.
+// One thread per array entry over FULL tiles; neighbours are direct global loads (the arrays of these levels live in L2).
+#include "common.hpp"
+
+using namespace hyteg_hip;
+
+namespace {
+
+constexpr int kTile    = 1024;
+constexpr int kThreads = 256;
+constexpr int kPer     = kTile / kThreads;
+constexpr int kMaxB    = HYTEG_HIP_MAX_BATCH;
+
+__constant__ int kOffsB[15][3] = { { 0, 0, -1 }, { 1, 0, -1 }, { -1, 1, -1 }, { 0, 1, -1 }, { 0, -1, 0 },
+                                   { 1, -1, 0 }, { -1, 0, 0 }, { 0, 0, 0 },   { 1, 0, 0 },  { -1, 1, 0 },
+                                   { 0, 1, 0 },  { 0, -1, 1 }, { 1, -1, 1 },  { -1, 0, 1 }, { 0, 0, 1 } };
+
+// class of a point: 0..13 = slot of the macro-primitive it lies on, 14 = inner point (bit numbers of the point mask)
+__device__ inline int point_class( int N, int x, int y, int z )
+{
+   const int f0 = ( z == 0 ), f1 = ( y == 0 ), f2 = ( x == 0 ), f3 = ( x + y + z == N - 1 );
+   const int cnt = f0 + f1 + f2 + f3;
+   if ( cnt == 0 )
+      return 14;
+   if ( cnt == 1 )
+      return 6 + ( f0 ? 0 : f1 ? 1 : f2 ? 2 : 3 );
+   if ( cnt == 2 )
+   {
+      if ( f0 )
+         return f1 ? 0 : ( f2 ? 1 : 2 );
+      if ( f1 )
+         return f2 ? 3 : 4;
+      return 5;
+   }
+   if ( f0 && f1 && f2 )
+      return 10;
+   if ( f0 && f1 && f3 )
+      return 11;
+   if ( f0 && f2 && f3 )
+      return 12;
+   return 13;
+}
+
+struct Point
+{
+   int  i, x, y, z, cls;
+   bool ok;
+};
+// u-th entry of this thread in tile tl
+__device__ inline Point decode( const Tile& tl, int N, int u )
+{
+   Point     p;
+   const int e = (int) threadIdx.x + u * kThreads;
+   p.ok        = e < tl.cnt;
+   p.i         = tl.a + ( p.ok ? e : tl.cnt - 1 );
+   const int W = N - tl.z, j = p.i - slice_start( N, tl.z );
+   p.z         = tl.z;
+   p.y         = row_of( W, j );
+   p.x         = j - row_start( W, p.y );
+   p.cls       = point_class( N, p.x, p.y, p.z );
+   return p;
+}
+
+template < int NP >
+struct Cells
+{
+   double*  p[NP][kMaxB]; // p[0] = destination (or first operand), the others sources
+   unsigned mask[kMaxB];
+};
+
+// ---- vector ops -------------------------------------------------------------------------------------------
+struct VecB
+{
+   Cells< 1 + HYTEG_HIP_MAX_SRCS > c;
+   double                          s[HYTEG_HIP_MAX_SRCS];
+   const Tile*                     tiles;
+   int                             N, nsrc, op; // op 0 assign, 1 add, 2 mult, 3 set constant s[0]
+};
+
+template < int NSRC >
+__global__ __launch_bounds__( kThreads ) void batch_vector_kernel( const VecB A )
+{
+   const Tile     tl   = A.tiles[blockIdx.x];
+   const int      cell = blockIdx.y;
+   const unsigned mask = A.c.mask[cell];
+   double*        dst  = A.c.p[0][cell];
+#pragma unroll
+   for ( int u = 0; u < kPer; ++u )
+   {
+      const Point p = decode( tl, A.N, u );
+      if ( !p.ok || !( ( mask >> p.cls ) & 1u ) )
+         continue;
+      double tmp;
+      if ( A.op == 3 )
+         tmp = A.s[0];
+      else if ( A.op == 2 )
+      {
+         tmp = A.c.p[1][cell][p.i];
+#pragma unroll
+         for ( int k = 1; k < NSRC; ++k )
+            tmp *= A.c.p[1 + k][cell][p.i];
+      }
+      else
+      {
+         tmp = A.s[0] * A.c.p[1][cell][p.i];
+#pragma unroll
+         for ( int k = 1; k < NSRC; ++k )
+            tmp += A.s[k] * A.c.p[1 + k][cell][p.i];
+         if ( A.op == 1 )
+            tmp = dst[p.i] + tmp;
+      }
+      dst[p.i] = tmp;
+   }
+}
+
+// ---- dot ---------------------------------------------------------------------------------------------------
+struct DotB
+{
+   Cells< 2 >  c;
+   const Tile* tiles;
+   int         N, ntiles, ncells;
+   double*     partial;
+};
+
+__device__ inline double wave_sum_b( double v )
+{
+#pragma unroll
+   for ( int off = 32; off > 0; off >>= 1 )
+      v += __shfl_down( v, off, 64 );
+   return v;
+}
+__device__ inline double block_sum_b( double v, double* sh )
+{
+   v = wave_sum_b( v );
+   if ( ( threadIdx.x & 63 ) == 0 )
+      sh[threadIdx.x >> 6] = v;
+   __syncthreads();
+   double r = 0.0;
+   if ( threadIdx.x == 0 )
+      for ( int k = 0; k < kThreads / 64; ++k )
+         r += sh[k];
+   return r;
+}
+
+// fixed (cell, tile) -> workgroup assignment and fixed reduction trees: the result does not depend on timing
+__global__ __launch_bounds__( kThreads ) void batch_dot_kernel( const DotB A )
+{
+   __shared__ double sh[kThreads / 64];
+   double            acc   = 0.0;
+   const int         total = A.ntiles * A.ncells;
+   for ( int w = blockIdx.x; w < total; w += gridDim.x )
+   {
+      const int      cell = w / A.ntiles;
+      const Tile     tl   = A.tiles[w - cell * A.ntiles];
+      const unsigned mask = A.c.mask[cell];
+      const double * a = A.c.p[0][cell], *b = A.c.p[1][cell];
+#pragma unroll
+      for ( int u = 0; u < kPer; ++u )
+      {
+         const Point p = decode( tl, A.N, u );
+         if ( p.ok && ( ( mask >> p.cls ) & 1u ) )
+            acc = fma( a[p.i], b[p.i], acc );
+      }
+   }
+   const double r = block_sum_b( acc, sh );
+   if ( threadIdx.x == 0 )
+      A.partial[blockIdx.x] = r;
+}
+__global__ __launch_bounds__( kThreads ) void batch_dot_final_kernel( const double* partial, int n, double* result )
+{
+   __shared__ double sh[kThreads / 64];
+   double            acc = 0.0;
+   for ( int k = threadIdx.x; k < n; k += kThreads )
+      acc += partial[k];
+   const double r = block_sum_b( acc, sh );
+   if ( threadIdx.x == 0 )
+      *result = r;
+}
+
+// ---- apply / Jacobi ------------------------------------------------------------------------------------------
+struct ApplyB
+{
+   Cells< 4 >    c; // dst, src, rhs, invdiag
+   const double* stencils; // [ncells][15 classes][15 weights]: classes 0..13 the cell's shares, 14 the inner stencil
+   const Tile*   tiles;
+   int           N, mode; // 0 replace, 1 add, 2 Jacobi phase 0, 3 Jacobi phase 1 (shell update after the exchange)
+   double        relax;
+};
+
+__device__ inline double stencil_sum( const double* __restrict__ w, const double* __restrict__ src, int N, const Point& p )
+{
+   double acc = 0.0;
+#pragma unroll
+   for ( int k = 0; k < 15; ++k )
+   {
+      const int nx = p.x + kOffsB[k][0], ny = p.y + kOffsB[k][1], nz = p.z + kOffsB[k][2];
+      if ( nx < 0 || ny < 0 || nz < 0 || nx + ny + nz > N - 1 )
+         continue;
+      acc = fma( w[k], src[cell_index( N, nx, ny, nz )], acc );
+   }
+   return acc;
+}
+
+__global__ __launch_bounds__( kThreads ) void batch_apply_kernel( const ApplyB A )
+{
+   const Tile     tl   = A.tiles[blockIdx.x];
+   const int      cell = blockIdx.y;
+   const unsigned mask = A.c.mask[cell];
+   double*        dst  = A.c.p[0][cell];
+   const double*  src  = A.c.p[1][cell];
+   const double*  tbl  = A.stencils + (size_t) cell * 225;
+#pragma unroll
+   for ( int u = 0; u < kPer; ++u )
+   {
+      const Point p = decode( tl, A.N, u );
+      if ( !p.ok || !( ( mask >> p.cls ) & 1u ) )
+         continue;
+      if ( A.mode == 3 )
+      {
+         // shell points after the shares were summed into dst: dst = src + relax * invdiag * ( rhs - dst )
+         if ( p.cls != 14 )
+            dst[p.i] = src[p.i] + A.relax * ( A.c.p[3][cell][p.i] * ( A.c.p[2][cell][p.i] - dst[p.i] ) );
+         continue;
+      }
+      const double acc = stencil_sum( tbl + p.cls * 15, src, A.N, p );
+      if ( A.mode == 0 )
+         dst[p.i] = acc;
+      else if ( A.mode == 1 )
+         dst[p.i] = dst[p.i] + acc;
+      else if ( p.cls == 14 )
+         dst[p.i] = src[p.i] + A.relax * ( A.c.p[3][cell][p.i] * ( A.c.p[2][cell][p.i] - acc ) );
+      else
+         dst[p.i] = acc; // this cell's share, summed over cells before phase 1
+   }
+}
+
+// ---- grid transfer ---------------------------------------------------------------------------------------------
+struct TransferB
+{
+   Cells< 2 >    c;      // p[0] = written array, p[1] = read array
+   const double* nncInv; // [ncells][14]
+   const Tile*   tiles;  // FULL tiles of the written level
+   int           Nc, update;
+};
+
+__constant__ int kNB14B[14][3] = { { -1, 0, 0 }, { -1, 0, 1 }, { -1, 1, -1 }, { -1, 1, 0 }, { 0, -1, 0 },
+                                   { 0, -1, 1 }, { 0, 0, -1 }, { 0, 0, 1 },   { 0, 1, -1 }, { 0, 1, 0 },
+                                   { 1, -1, 0 }, { 1, -1, 1 }, { 1, 0, -1 },  { 1, 0, 0 } };
+__constant__ int kAxisB[8][3]  = { { 0, 0, 0 }, { 1, 0, 0 }, { 0, 1, 0 }, { 1, -1, 0 },
+                                  { 0, 0, 1 }, { 1, 0, -1 }, { 0, 1, -1 }, { 1, -1, 1 } };
+__constant__ int kLoFirstB[8] = { 1, 1, 1, 0, 1, 0, 0, 1 };
+
+// same terms and summation order as p1_restrict_kernel (p1_transfer.hip)
+__global__ __launch_bounds__( kThreads ) void batch_restrict_kernel( const TransferB A )
+{
+   const Tile     tl     = A.tiles[blockIdx.x];
+   const int      cell   = blockIdx.y, Nc = A.Nc, Nf = 2 * Nc - 1;
+   const unsigned mask   = A.c.mask[cell];
+   double*        coarse = A.c.p[0][cell];
+   const double*  fine   = A.c.p[1][cell];
+   const double*  inv    = A.nncInv + cell * 14;
+#pragma unroll
+   for ( int u = 0; u < kPer; ++u )
+   {
+      const Point p = decode( tl, Nc, u );
+      if ( !p.ok || !( ( mask >> p.cls ) & 1u ) )
+         continue;
+      double acc   = 0.0;
+      bool   first = true;
+#pragma unroll
+      for ( int k = 0; k < 14; ++k )
+      {
+         const int fx = 2 * p.x + kNB14B[k][0], fy = 2 * p.y + kNB14B[k][1], fz = 2 * p.z + kNB14B[k][2];
+         if ( fx < 0 || fy < 0 || fz < 0 || fx + fy + fz > Nf - 1 )
+            continue;
+         const int    fc   = point_class( Nf, fx, fy, fz );
+         const double term = ( fc == 14 ? 1.0 : inv[fc] ) * 0.5 * fine[cell_index( Nf, fx, fy, fz )];
+         acc               = first ? term : acc + term;
+         first             = false;
+      }
+      const int    fc   = point_class( Nf, 2 * p.x, 2 * p.y, 2 * p.z );
+      const double term = ( fc == 14 ? 1.0 : inv[fc] ) * fine[cell_index( Nf, 2 * p.x, 2 * p.y, 2 * p.z )];
+      coarse[p.i]       = first ? term : acc + term;
+   }
+}
+
+// same terms and order as p1_prolongate_kernel; tiles of the FINE level, A.Nc = coarse width
+__global__ __launch_bounds__( kThreads ) void batch_prolongate_kernel( const TransferB A )
+{
+   const Tile     tl     = A.tiles[blockIdx.x];
+   const int      cell   = blockIdx.y, Nc = A.Nc, Nf = 2 * Nc - 1;
+   const unsigned mask   = A.c.mask[cell];
+   double*        fine   = A.c.p[0][cell];
+   const double*  coarse = A.c.p[1][cell];
+   const double*  inv    = A.nncInv + cell * 14;
+#pragma unroll
+   for ( int u = 0; u < kPer; ++u )
+   {
+      const Point p = decode( tl, Nf, u );
+      if ( !p.ok || !( ( mask >> p.cls ) & 1u ) )
+         continue;
+      const double sc   = p.cls == 14 ? 1.0 : inv[p.cls];
+      const int    code = ( p.x & 1 ) | ( ( p.y & 1 ) << 1 ) | ( ( p.z & 1 ) << 2 );
+      const double old  = ( A.update == HYTEG_HIP_ADD && p.cls == 14 ) ? fine[p.i] : 0.0;
+      double       v;
+      if ( code == 0 )
+         v = old + sc * coarse[cell_index( Nc, p.x >> 1, p.y >> 1, p.z >> 1 )];
+      else
+      {
+         const int    ex = kAxisB[code][0], ey = kAxisB[code][1], ez = kAxisB[code][2];
+         const double lo = coarse[cell_index( Nc, ( p.x - ex ) >> 1, ( p.y - ey ) >> 1, ( p.z - ez ) >> 1 )];
+         const double hi = coarse[cell_index( Nc, ( p.x + ex ) >> 1, ( p.y + ey ) >> 1, ( p.z + ez ) >> 1 )];
+         const double h  = sc * 0.5;
+         v               = kLoFirstB[code] ? ( old + h * lo ) + h * hi : ( old + h * hi ) + h * lo;
+      }
+      fine[p.i] = v;
+   }
+}
+
+inline bool batch_level_ok( int level ) { return level >= 0 && level <= HYTEG_HIP_MAX_LEVEL; }
+
+// tiles that cover the whole array also exist for levels 0 and 1 (get_tiles builds them for any level)
+int full_tiles( int level, TileTable* tt ) { return get_tiles( level, TILES_FULL, kTile, tt ); }
+
+} // namespace
+
+extern "C" {
+
+#define BATCH_CHECKS( name )                                                                                   \
+   HH_REQUIRE( ncells >= 1 && ncells <= kMaxB, name ": ncells must be 1..HYTEG_HIP_MAX_BATCH" );              \
+   HH_REQUIRE( batch_level_ok( level ), name ": level out of range [0,11]" );                                 \
+   HH_REQUIRE( masks != nullptr, name ": null masks" );
+
+HYTEG_HIP_API int hyteg_hip_p1_vector_cells( int                  op,
+                                             int                  ncells,
+                                             double* const*       dst,
+                                             int                  nsrc,
+                                             const double* const* srcs,
+                                             const double*        scalars,
+                                             int                  level,
+                                             const unsigned*      masks,
+                                             hyteg_hip_stream_t   stream )
+{
+   BATCH_CHECKS( "p1_vector_cells" );
+   HH_REQUIRE( op >= 0 && op <= 3 && dst, "p1_vector_cells: bad op or null dst" );
+   HH_REQUIRE( op == 3 ? scalars != nullptr : ( nsrc >= 1 && nsrc <= HYTEG_HIP_MAX_SRCS && srcs ), "p1_vector_cells: bad sources" );
+   HH_REQUIRE( op == 2 || op == 3 || scalars, "p1_vector_cells: null scalars" );
+   TileTable tt;
+   int       rc = full_tiles( level, &tt );
+   if ( rc != HYTEG_HIP_OK )
+      return rc;
+   VecB A{};
+   bool any = false;
+   for ( int c = 0; c < ncells; ++c )
+   {
+      HH_REQUIRE( dst[c], "p1_vector_cells: null destination" );
+      A.c.p[0][c]  = dst[c];
+      A.c.mask[c]  = masks[c] & HYTEG_HIP_MASK_ALL;
+      any          = any || A.c.mask[c];
+      if ( op != 3 )
+         for ( int k = 0; k < nsrc; ++k )
+         {
+            HH_REQUIRE( srcs[k * ncells + c], "p1_vector_cells: null source" );
+            A.c.p[1 + k][c] = const_cast< double* >( srcs[k * ncells + c] );
+         }
+   }
+   if ( !any || tt.count == 0 )
+      return HYTEG_HIP_OK;
+   if ( op == 3 )
+      A.s[0] = scalars[0];
+   else
+      for ( int k = 0; k < nsrc; ++k )
+         A.s[k] = scalars ? scalars[k] : 1.0;
+   A.tiles = tt.dev, A.N = ( 1 << level ) + 1, A.nsrc = nsrc, A.op = op;
+   const dim3 grid( tt.count, ncells );
+   switch ( op == 3 ? 1 : nsrc )
+   {
+   case 1:
+      hipLaunchKernelGGL( batch_vector_kernel< 1 >, grid, dim3( kThreads ), 0, as_stream( stream ), A );
+      break;
+   case 2:
+      hipLaunchKernelGGL( batch_vector_kernel< 2 >, grid, dim3( kThreads ), 0, as_stream( stream ), A );
+      break;
+   case 3:
+      hipLaunchKernelGGL( batch_vector_kernel< 3 >, grid, dim3( kThreads ), 0, as_stream( stream ), A );
+      break;
+   default:
+      hipLaunchKernelGGL( batch_vector_kernel< 4 >, grid, dim3( kThreads ), 0, as_stream( stream ), A );
+      break;
+   }
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_p1_dot_cells( int                  ncells,
+                                          const double* const* a,
+                                          const double* const* b,
+                                          int                  level,
+                                          const unsigned*      masks,
+                                          double*              result_dev,
+                                          void*                workspace_dev,
+                                          hyteg_hip_stream_t   stream )
+{
+   BATCH_CHECKS( "p1_dot_cells" );
+   HH_REQUIRE( a && b && result_dev && workspace_dev, "p1_dot_cells: null pointer" );
+   TileTable tt;
+   int       rc = full_tiles( level, &tt );
+   if ( rc != HYTEG_HIP_OK )
+      return rc;
+   DotB A{};
+   for ( int c = 0; c < ncells; ++c )
+   {
+      HH_REQUIRE( a[c] && b[c], "p1_dot_cells: null operand" );
+      A.c.p[0][c] = const_cast< double* >( a[c] );
+      A.c.p[1][c] = const_cast< double* >( b[c] );
+      A.c.mask[c] = masks[c] & HYTEG_HIP_MASK_ALL;
+   }
+   A.tiles = tt.dev, A.N = ( 1 << level ) + 1, A.ntiles = tt.count, A.ncells = ncells;
+   A.partial = static_cast< double* >( workspace_dev );
+   const int total  = tt.count * ncells;
+   const int blocks = total < 1024 ? ( total > 0 ? total : 1 ) : 1024; // workspace holds 1024 + 256 doubles
+   hipLaunchKernelGGL( batch_dot_kernel, dim3( blocks ), dim3( kThreads ), 0, as_stream( stream ), A );
+   hipLaunchKernelGGL( batch_dot_final_kernel, dim3( 1 ), dim3( kThreads ), 0, as_stream( stream ), A.partial, blocks, result_dev );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
+static int launch_apply_b( int                  mode,
+                           int                  ncells,
+                           double* const*       dst,
+                           const double* const* src,
+                           const double* const* rhs,
+                           const double* const* invdiag,
+                           int                  level,
+                           const double*        stencils_dev,
+                           double               relax,
+                           const unsigned*      masks,
+                           hyteg_hip_stream_t   stream )
+{
+   TileTable tt;
+   int       rc = full_tiles( level, &tt );
+   if ( rc != HYTEG_HIP_OK )
+      return rc;
+   ApplyB A{};
+   bool   any = false;
+   for ( int c = 0; c < ncells; ++c )
+   {
+      HH_REQUIRE( dst[c] && src[c] && dst[c] != src[c], "batched apply: null or aliased dst / src" );
+      A.c.p[0][c] = dst[c];
+      A.c.p[1][c] = const_cast< double* >( src[c] );
+      if ( mode >= 2 )
+      {
+         HH_REQUIRE( rhs && invdiag && rhs[c] && invdiag[c], "p1_jacobi_cells: null rhs / inverse diagonal" );
+         A.c.p[2][c] = const_cast< double* >( rhs[c] );
+         A.c.p[3][c] = const_cast< double* >( invdiag[c] );
+      }
+      A.c.mask[c] = masks[c] & HYTEG_HIP_MASK_ALL;
+      any         = any || A.c.mask[c];
+   }
+   if ( !any || tt.count == 0 )
+      return HYTEG_HIP_OK;
+   A.stencils = stencils_dev, A.tiles = tt.dev, A.N = ( 1 << level ) + 1, A.mode = mode, A.relax = relax;
+   hipLaunchKernelGGL( batch_apply_kernel, dim3( tt.count, ncells ), dim3( kThreads ), 0, as_stream( stream ), A );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_p1_apply_cells( int                  ncells,
+                                            double* const*       dst,
+                                            const double* const* src,
+                                            int                  level,
+                                            const double*        stencils_dev,
+                                            const unsigned*      masks,
+                                            int                  update,
+                                            hyteg_hip_stream_t   stream )
+{
+   BATCH_CHECKS( "p1_apply_cells" );
+   HH_REQUIRE( dst && src && stencils_dev, "p1_apply_cells: null pointer" );
+   HH_REQUIRE( update == HYTEG_HIP_REPLACE || update == HYTEG_HIP_ADD, "p1_apply_cells: bad update type" );
+   return launch_apply_b( update == HYTEG_HIP_ADD ? 1 : 0, ncells, dst, src, nullptr, nullptr, level, stencils_dev, 0.0, masks, stream );
+}
+
+HYTEG_HIP_API int hyteg_hip_p1_jacobi_cells( int                  ncells,
+                                             double* const*       dst,
+                                             const double* const* rhs,
+                                             const double* const* src,
+                                             const double* const* invdiag,
+                                             int                  level,
+                                             const double*        stencils_dev,
+                                             double               relax,
+                                             const unsigned*      masks,
+                                             int                  phase,
+                                             hyteg_hip_stream_t   stream )
+{
+   BATCH_CHECKS( "p1_jacobi_cells" );
+   HH_REQUIRE( dst && rhs && src && invdiag && stencils_dev, "p1_jacobi_cells: null pointer" );
+   HH_REQUIRE( phase == 0 || phase == 1, "p1_jacobi_cells: phase must be 0 or 1" );
+   return launch_apply_b( 2 + phase, ncells, dst, src, rhs, invdiag, level, stencils_dev, relax, masks, stream );
+}
+
+static int launch_transfer_b( bool                 restrict_,
+                              int                  ncells,
+                              double* const*       out,
+                              const double* const* in,
+                              int                  coarse_level,
+                              const double*        nnc_inv_dev,
+                              const unsigned*      masks,
+                              int                  update,
+                              hyteg_hip_stream_t   stream )
+{
+   TileTable tt;
+   int       rc = full_tiles( restrict_ ? coarse_level : coarse_level + 1, &tt );
+   if ( rc != HYTEG_HIP_OK )
+      return rc;
+   TransferB A{};
+   bool      any = false;
+   for ( int c = 0; c < ncells; ++c )
+   {
+      HH_REQUIRE( out[c] && in[c], "batched grid transfer: null array" );
+      A.c.p[0][c] = out[c];
+      A.c.p[1][c] = const_cast< double* >( in[c] );
+      A.c.mask[c] = masks[c] & HYTEG_HIP_MASK_ALL;
+      any         = any || A.c.mask[c];
+   }
+   if ( !any || tt.count == 0 )
+      return HYTEG_HIP_OK;
+   A.nncInv = nnc_inv_dev, A.tiles = tt.dev, A.Nc = ( 1 << coarse_level ) + 1, A.update = update;
+   if ( restrict_ )
+      hipLaunchKernelGGL( batch_restrict_kernel, dim3( tt.count, ncells ), dim3( kThreads ), 0, as_stream( stream ), A );
+   else
+      hipLaunchKernelGGL( batch_prolongate_kernel, dim3( tt.count, ncells ), dim3( kThreads ), 0, as_stream( stream ), A );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_p1_restrict_cells( int                  ncells,
+                                               double* const*       coarse,
+                                               const double* const* fine,
+                                               int                  coarse_level,
+                                               const double*        nnc_inv_dev,
+                                               const unsigned*      masks,
+                                               hyteg_hip_stream_t   stream )
+{
+   const int level = coarse_level;
+   BATCH_CHECKS( "p1_restrict_cells" );
+   HH_REQUIRE( coarse && fine && nnc_inv_dev && coarse_level + 1 <= HYTEG_HIP_MAX_LEVEL, "p1_restrict_cells: null pointer or level" );
+   return launch_transfer_b( true, ncells, coarse, fine, coarse_level, nnc_inv_dev, masks, 0, stream );
+}
+
+HYTEG_HIP_API int hyteg_hip_p1_prolongate_cells( int                  ncells,
+                                                 const double* const* coarse,
+                                                 double* const*       fine,
+                                                 int                  coarse_level,
+                                                 const double*        nnc_inv_dev,
+                                                 const unsigned*      masks,
+                                                 int                  update,
+                                                 hyteg_hip_stream_t   stream )
+{
+   const int level = coarse_level;
+   BATCH_CHECKS( "p1_prolongate_cells" );
+   HH_REQUIRE( coarse && fine && nnc_inv_dev && coarse_level + 1 <= HYTEG_HIP_MAX_LEVEL, "p1_prolongate_cells: null pointer or level" );
+   HH_REQUIRE( update == HYTEG_HIP_REPLACE || update == HYTEG_HIP_ADD, "p1_prolongate_cells: bad update type" );
+   return launch_transfer_b( false, ncells, fine, coarse, coarse_level, nnc_inv_dev, masks, update, stream );
+}
+
+} // extern "C"

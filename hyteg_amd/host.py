@@ -30,6 +30,7 @@ SIGNATURES = {
     "hyteg_host_storage_mask": (_i, [_vp, _i, _i, _i, C.POINTER(_u)]),
     "hyteg_host_storage_set_boundary_type": (_i, [_vp, _i]),
     "hyteg_host_storage_set_stream": (_i, [_vp, _vp]),
+    "hyteg_host_storage_set_batch_max_level": (_i, [_vp, _i]),
     "hyteg_host_storage_set_hooks": (_i, [_vp, EXCHANGE_CB, EXCHANGE_CB, ALLREDUCE_CB, _vp]),
     "hyteg_host_plan_sizes": (_i, [_vp, _i, _i, _ip]),
     "hyteg_host_plan_export": (_i, [_vp, _i, _i, _ip, _ip, _ip, _ip, _ip, _ip, _ip, _ip]),
@@ -144,6 +145,10 @@ class Storage:
 
     def set_boundary_type(self, t):
         _ck(lib().hyteg_host_storage_set_boundary_type(self.h, t), "set_boundary_type")
+
+    def set_batch_max_level(self, level):
+        """levels <= level run the batched kernels (one launch for all local cells); -1: per-cell kernels everywhere"""
+        _ck(lib().hyteg_host_storage_set_batch_max_level(self.h, level), "set_batch_max_level")
 
     def set_stream(self, stream):
         _ck(lib().hyteg_host_storage_set_stream(self.h, stream), "set_stream")

@@ -416,6 +416,57 @@ class PrimitiveStorage
       return n;
    }
 
+   // ---- batched launches (p1_batch.hip): one launch for all local cells on the levels where a cell is small ----
+   // Default: levels <= 6 whenever the rank owns more than one cell; HYTEG_AMD_BATCH_MAX_LEVEL overrides (-1 disables).
+   bool useBatch( uint_t level ) const
+   {
+      if ( batchMaxLevel_ == -2 )
+      {
+         const char* e  = std::getenv( "HYTEG_AMD_BATCH_MAX_LEVEL" );
+         batchMaxLevel_ = e ? std::atoi( e ) : 6;
+      }
+      return localCells_.size() > 1 && (int) level <= batchMaxLevel_;
+   }
+   void setBatchMaxLevel( int l ) { batchMaxLevel_ = l; }
+   std::vector< unsigned > masksFor( DoFType flag, bool owned = false, unsigned keep = HYTEG_HIP_MASK_ALL ) const
+   {
+      std::vector< unsigned > m;
+      for ( int id : localCells_ )
+         m.push_back( ( owned ? ownedMaskFor( cells_[id], flag ) : maskFor( cells_[id], flag ) ) & keep );
+      return m;
+   }
+   // device table [local cell][14] of 1 / numNeighborCells (grid transfer)
+   const double* nncInvDevice() const
+   {
+      if ( !nncInv_ && !localCells_.empty() )
+      {
+         std::vector< double > h;
+         for ( int id : localCells_ )
+            for ( double n : numNeighborCells( cells_[id] ) )
+               h.push_back( 1.0 / n );
+         nncInv_ = uploadTable( h );
+      }
+      return nncInv_;
+   }
+   // small read-only device table owned by the storage (freed with it)
+   double* uploadTable( const std::vector< double >& h ) const
+   {
+      void* p = nullptr;
+      hipCheck( hyteg_hip_malloc( &p, std::max< size_t >( 1, h.size() ) * sizeof( double ) ), "uploadTable: malloc" );
+      hipCheck( hyteg_hip_upload( p, h.data(), h.size() * sizeof( double ), stream_ ), "uploadTable: upload" );
+      hipCheck( hyteg_hip_stream_synchronize( stream_ ), "uploadTable: sync" );
+      scratchAll_.push_back( p );
+      return static_cast< double* >( p );
+   }
+   // calls fn( first, count ) for chunks of at most HYTEG_HIP_MAX_BATCH local cells
+   template < typename F >
+   void forCellChunks( F&& fn ) const
+   {
+      const int n = (int) localCells_.size();
+      for ( int first = 0; first < n; first += HYTEG_HIP_MAX_BATCH )
+         fn( first, std::min( HYTEG_HIP_MAX_BATCH, n - first ) );
+   }
+
    void              setStream( hyteg_hip_stream_t s ) { stream_ = s; }
    hyteg_hip_stream_t stream() const { return stream_; }
    void              setCommHooks( const CommHooks& h ) { hooks_ = h; }
@@ -684,6 +735,8 @@ class PrimitiveStorage
    mutable void *                                          dotResult_ = nullptr, *dotWorkspace_ = nullptr;
    mutable std::map< size_t, std::vector< double* > >      scratchFree_;
    mutable std::vector< void* >                            scratchAll_;
+   mutable double*                                         nncInv_        = nullptr;
+   mutable int                                             batchMaxLevel_ = -2; // -2: read HYTEG_AMD_BATCH_MAX_LEVEL on first use
    mutable std::map< std::pair< int, int >, ExchangePlan > plans_;
 };
 
@@ -755,9 +808,29 @@ class P1Function
       return data_.at( c )[level - minLevel_];
    }
 
+   // device pointers of local cells [first, first + count) at `level`
+   std::vector< double* > cellPointers( uint_t level, int first, int count ) const
+   {
+      std::vector< double* > p;
+      for ( int c = first; c < first + count; ++c )
+         p.push_back( getCellPointer( (uint_t) c, level ) );
+      return p;
+   }
+
    // ---- interpolate ( VertexDoFFunction.cpp:380-392, :395-470 ) ----
    void interpolate( ValueType constant, uint_t level, DoFType flag = All ) const
    {
+      if ( storage_->useBatch( level ) )
+      {
+         const auto masks = storage_->masksFor( flag );
+         storage_->forCellChunks( [&]( int first, int count ) {
+            const auto dst = cellPointers( level, first, count );
+            hipCheck( hyteg_hip_p1_vector_cells( 3, count, dst.data(), 0, nullptr, &constant, (int) level, masks.data() + first,
+                                                 storage_->stream() ),
+                      "interpolate (batched)" );
+         } );
+         return;
+      }
       forCells( [&]( uint_t c, const MacroCell& cell ) {
          hipCheck( hyteg_hip_p1_set_cell_masked( getCellPointer( c, level ), constant, (int) level, storage_->maskFor( cell, flag ),
                                                  storage_->stream() ),
@@ -825,6 +898,26 @@ class P1Function
       // one result slot per local cell, a single download (= one host synchronisation) per dot product; the
       // workspace is reused cell after cell, which is safe because all launches are ordered on one stream
       const uint_t nLocal = storage_->getNumberOfLocalCells();
+      if ( storage_->useBatch( level ) )
+      {
+         // one partial + one final launch per chunk of cells, one number per chunk comes back
+         const auto masks  = storage_->masksFor( flag, true );
+         int        nchunk = 0;
+         storage_->forCellChunks( [&]( int first, int count ) {
+            const auto a = cellPointers( level, first, count ), b = rhs.cellPointers( level, first, count );
+            hipCheck( hyteg_hip_p1_dot_cells( count, a.data(), b.data(), (int) level, masks.data() + first, storage_->dotResult() + nchunk,
+                                              storage_->dotWorkspace(), storage_->stream() ),
+                      "dotLocal (batched)" );
+            ++nchunk;
+         } );
+         std::vector< double > parts( (size_t) nchunk, 0.0 );
+         hipCheck( hyteg_hip_download( parts.data(), storage_->dotResult(), parts.size() * sizeof( double ), storage_->stream() ),
+                   "dotLocal: download" );
+         double sum = 0.0;
+         for ( double v : parts )
+            sum += v;
+         return sum;
+      }
       forCells( [&]( uint_t c, const MacroCell& cell ) {
          hipCheck( hyteg_hip_p1_dot_cell_masked( getCellPointer( c, level ), rhs.getCellPointer( c, level ), (int) level,
                                                  storage_->ownedMaskFor( cell, flag ), storage_->dotResult() + c, storage_->dotWorkspace(),
@@ -904,6 +997,21 @@ class P1Function
    {
       if ( functions.empty() || functions.size() > HYTEG_HIP_MAX_SRCS || ( op != 2 && scalars.size() != functions.size() ) )
          throw std::runtime_error( "P1Function::assign/add/multElementwise: bad number of functions or scalars" );
+      if ( storage_->useBatch( level ) )
+      {
+         const auto masks = storage_->masksFor( flag );
+         storage_->forCellChunks( [&]( int first, int count ) {
+            const auto             dst = cellPointers( level, first, count );
+            std::vector< double* > srcs; // [function][cell]
+            for ( const auto& f : functions )
+               for ( double* q : f.get().cellPointers( level, first, count ) )
+                  srcs.push_back( q );
+            hipCheck( hyteg_hip_p1_vector_cells( op, count, dst.data(), (int) functions.size(), srcs.data(),
+                                                 op == 2 ? nullptr : scalars.data(), (int) level, masks.data() + first, storage_->stream() ),
+                      "P1Function vector op (batched)" );
+         } );
+         return;
+      }
       forCells( [&]( uint_t c, const MacroCell& cell ) {
          const double* srcs[HYTEG_HIP_MAX_SRCS];
          for ( uint_t k = 0; k < functions.size(); ++k )
@@ -1185,6 +1293,11 @@ class P1ConstantOperator
    {
       if ( &src == &dst )
          throw std::runtime_error( "P1ConstantOperator::apply: src and dst must differ (P1Operator.hpp:198)" );
+      if ( storage_->useBatch( level ) )
+      {
+         applyBatched( src, dst, level, flag, updateType );
+         return;
+      }
       const P1Function< double >* shellDst = &dst;
       std::unique_ptr< P1Function< double > > tmp;
       if ( updateType == Add && hasSharedPoints( level, flag ) )
@@ -1234,6 +1347,25 @@ class P1ConstantOperator
       if ( &src == &dst )
          throw std::runtime_error( "smooth_jac: src and dst must differ" );
       const auto& invDiag = *getInverseDiagonalValues();
+      if ( storage_->useBatch( level ) )
+      {
+         // phase 0: inner points complete, shell points this cell's share; exchange; phase 1: shell update
+         const auto masks = storage_->masksFor( flag );
+         for ( int phase = 0; phase < 2; ++phase )
+         {
+            storage_->forCellChunks( [&]( int first, int count ) {
+               const auto d = dst.cellPointers( level, first, count ), r = rhs.cellPointers( level, first, count ),
+                          u = src.cellPointers( level, first, count ), iv = invDiag.cellPointers( level, first, count );
+               hipCheck( hyteg_hip_p1_jacobi_cells( count, d.data(), r.data(), u.data(), iv.data(), (int) level,
+                                                    stencilTable( level ) + (size_t) first * 225, relax, masks.data() + first, phase,
+                                                    storage_->stream() ),
+                         "smooth_jac (batched)" );
+            } );
+            if ( phase == 0 )
+               dst.sumSharedCopies( level, flag );
+         }
+         return;
+      }
       forCells( [&]( uint_t c, const MacroCell& cell ) {
          const auto&    S    = getCellStencils( cell.id, level );
          const unsigned mask = storage_->maskFor( cell, flag );
@@ -1296,6 +1428,17 @@ class P1ConstantOperator
          restSlot.reset( new P1Function< double >( "sor_rest", storage_, level, level ) );
       P1Function< double >& rest = *restSlot;
       auto                 sweepShell = [&]( unsigned bits ) {
+         if ( storage_->useBatch( level ) )
+         {
+            const auto masks = storage_->masksFor( flag, false, bits & HYTEG_HIP_MASK_SHELL );
+            storage_->forCellChunks( [&]( int first, int count ) {
+               const auto r = rest.cellPointers( level, first, count ), u = dst.cellPointers( level, first, count );
+               hipCheck( hyteg_hip_p1_apply_cells( count, r.data(), u.data(), (int) level, restTable( level ) + (size_t) first * 225,
+                                                   masks.data() + first, HYTEG_HIP_REPLACE, storage_->stream() ),
+                         "smooth_sor: rest (batched)" );
+            } );
+         }
+         else
          forCells( [&]( uint_t c, const MacroCell& cell ) {
             const auto&    T    = sorTables_.at( level ).at( cell.id );
             const unsigned mask = storage_->maskFor( cell, flag ) & bits;
@@ -1406,6 +1549,68 @@ class P1ConstantOperator
       for ( uint_t c = 0; c < storage_->getNumberOfLocalCells(); ++c )
          fn( c, storage_->getLocalCell( c ) );
    }
+   // Operator::apply with one launch for all local cells: every selected point gets (this cell's share of) its stencil sum,
+   // then the shares of the shared points are summed.  Add needs the summed shares in a temporary first.
+   void applyBatched( const P1Function< double >& src, const P1Function< double >& dst, uint_t level, DoFType flag, UpdateType updateType ) const
+   {
+      const bool sharedAdd = updateType == Add && hasSharedPoints( level, flag );
+      auto       run       = [&]( const P1Function< double >& out, unsigned keep, int update ) {
+         const auto masks = storage_->masksFor( flag, false, keep );
+         storage_->forCellChunks( [&]( int first, int count ) {
+            const auto d = out.cellPointers( level, first, count ), u = src.cellPointers( level, first, count );
+            hipCheck( hyteg_hip_p1_apply_cells( count, d.data(), u.data(), (int) level, stencilTable( level ) + (size_t) first * 225,
+                                                masks.data() + first, update, storage_->stream() ),
+                      "apply (batched)" );
+         } );
+      };
+      if ( !sharedAdd )
+      {
+         run( dst, HYTEG_HIP_MASK_ALL, updateType == Add ? HYTEG_HIP_ADD : HYTEG_HIP_REPLACE );
+         dst.sumSharedCopies( level, flag );
+         return;
+      }
+      P1Function< double > tmp( "apply_tmp", storage_, level, level, true );
+      tmp.interpolate( 0.0, level, All );
+      run( dst, HYTEG_HIP_MASK_INNER, HYTEG_HIP_ADD );
+      run( tmp, HYTEG_HIP_MASK_SHELL, HYTEG_HIP_REPLACE );
+      tmp.sumSharedCopies( level, flag );
+      const auto masks = storage_->masksFor( flag, false, HYTEG_HIP_MASK_SHELL );
+      storage_->forCellChunks( [&]( int first, int count ) {
+         const auto   d = dst.cellPointers( level, first, count ), t = tmp.cellPointers( level, first, count );
+         const double one = 1.0;
+         hipCheck( hyteg_hip_p1_vector_cells( 1, count, d.data(), 1, t.data(), &one, (int) level, masks.data() + first, storage_->stream() ),
+                   "apply: add shell (batched)" );
+      } );
+   }
+   // device tables [local cell][15 point classes][15 weights] for the batched kernels: classes 0..13 the cell's shares, 14 inner
+   const double* stencilTable( uint_t level ) const
+   {
+      auto it = stencilTables_.find( level );
+      if ( it != stencilTables_.end() )
+         return it->second;
+      std::vector< double > h;
+      for ( int id : storage_->getLocalCellIDs() )
+      {
+         const auto& S = getCellStencils( id, level );
+         h.insert( h.end(), &S.slots[0][0], &S.slots[0][0] + 14 * 15 );
+         h.insert( h.end(), S.inner, S.inner + 15 );
+      }
+      return stencilTables_[level] = storage_->uploadTable( h );
+   }
+   const double* restTable( uint_t level ) const
+   {
+      auto it = restTables_.find( level );
+      if ( it != restTables_.end() )
+         return it->second;
+      std::vector< double > h;
+      for ( int id : storage_->getLocalCellIDs() )
+      {
+         const auto& T = sorTables_.at( level ).at( id );
+         h.insert( h.end(), &T.rest[0][0], &T.rest[0][0] + 14 * 15 );
+         h.insert( h.end(), 15, 0.0 );
+      }
+      return restTables_[level] = storage_->uploadTable( h );
+   }
    // total weights and sweep orientations of every macro-primitive, handed to each adjacent cell in its local numbering
    std::vector< stencil::CellSorTables > buildSorTables( const std::vector< stencil::CellStencils >& S ) const
    {
@@ -1481,6 +1686,7 @@ class P1ConstantOperator
    std::map< uint_t, std::vector< stencil::CellStencils > >   stencils_;
    std::map< uint_t, std::vector< stencil::CellSorTables > >  sorTables_;
    mutable std::map< uint_t, std::unique_ptr< P1Function< double > > > sorRest_;
+   mutable std::map< uint_t, const double* >                  stencilTables_, restTables_;
    std::shared_ptr< P1Function< double > >                    inverseDiagonalValues_;
 };
 
@@ -1497,6 +1703,18 @@ class P1toP1LinearRestriction
    {
       auto         storage = function.getStorage();
       const uint_t dstLevel = sourceLevel - 1;
+      if ( storage->useBatch( sourceLevel ) )
+      {
+         const auto masks = storage->masksFor( flag );
+         storage->forCellChunks( [&]( int first, int count ) {
+            const auto co = function.cellPointers( dstLevel, first, count ), fi = function.cellPointers( sourceLevel, first, count );
+            hipCheck( hyteg_hip_p1_restrict_cells( count, co.data(), fi.data(), (int) dstLevel, storage->nncInvDevice() + (size_t) first * 14,
+                                                   masks.data() + first, storage->stream() ),
+                      "restrict (batched)" );
+         } );
+         function.sumSharedCopies( dstLevel, flag );
+         return;
+      }
       for ( uint_t c = 0; c < storage->getNumberOfLocalCells(); ++c )
       {
          const MacroCell& cell = storage->getLocalCell( c );
@@ -1532,6 +1750,19 @@ class P1toP1LinearProlongation
    static void run( const P1Function< double >& src, const P1Function< double >& dst, uint_t sourceLevel, DoFType flag )
    {
       auto storage = src.getStorage();
+      if ( storage->useBatch( sourceLevel + 1 ) )
+      {
+         const auto masks = storage->masksFor( flag );
+         storage->forCellChunks( [&]( int first, int count ) {
+            const auto co = src.cellPointers( sourceLevel, first, count ), fi = dst.cellPointers( sourceLevel + 1, first, count );
+            hipCheck( hyteg_hip_p1_prolongate_cells( count, co.data(), fi.data(), (int) sourceLevel,
+                                                     storage->nncInvDevice() + (size_t) first * 14, masks.data() + first, HYTEG_HIP_REPLACE,
+                                                     storage->stream() ),
+                      "prolongate (batched)" );
+         } );
+         dst.sumSharedCopies( sourceLevel + 1, flag );
+         return;
+      }
       for ( uint_t c = 0; c < storage->getNumberOfLocalCells(); ++c )
       {
          const MacroCell& cell = storage->getLocalCell( c );

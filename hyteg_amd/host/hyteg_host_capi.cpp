@@ -116,6 +116,10 @@ HYTEG_HOST_API int hyteg_host_storage_set_stream( hh_storage_t s, void* stream )
 {
    return guarded( [&] { S( s ).setStream( stream ); } );
 }
+HYTEG_HOST_API int hyteg_host_storage_set_batch_max_level( hh_storage_t s, int level )
+{
+   return guarded( [&] { S( s ).setBatchMaxLevel( level ); } );
+}
 HYTEG_HOST_API int hyteg_host_storage_set_hooks( hh_storage_t s, void ( *exb )( void*, int, int ), void ( *exe )( void*, int, int ),
                                                  void ( *ar )( void*, double*, int ), void* user )
 {

@@ -302,6 +302,72 @@ HYTEG_HIP_API int hyteg_hip_p1_sor_shell_cell( double*            dst,
                                                int                backwards,
                                                hyteg_hip_stream_t stream );
 
+/* ---- batched forms: ONE launch for up to HYTEG_HIP_MAX_BATCH macro-cells of the same level, inner and
+ * boundary points together.  They replace the per-primitive loops of the reference (`for ( cell : storage->getCells() )`,
+ * P1Operator.hpp:286-309; VertexDoFFunction.cpp:1130-1221, 1710-1793; P1toP1LinearRestriction.cpp:193-243) on the levels
+ * where a cell is too small to fill the GPU.  `dst`, `src`, ... are HOST arrays of `ncells` device pointers, `masks` a host
+ * array of `ncells` point masks (bits 0..13 macro-primitive slots, bit 14 inner points); tables ending in `_dev` are device
+ * memory.  Levels 0..11. */
+#define HYTEG_HIP_MAX_BATCH 64
+/* op 0 assign, 1 add, 2 multElementwise, 3 set to scalars[0]; srcs = [nsrc][ncells] */
+HYTEG_HIP_API int hyteg_hip_p1_vector_cells( int                  op,
+                                             int                  ncells,
+                                             double* const*       dst,
+                                             int                  nsrc,
+                                             const double* const* srcs,
+                                             const double*        scalars,
+                                             int                  level,
+                                             const unsigned*      masks,
+                                             hyteg_hip_stream_t   stream );
+/* *result_dev = sum over all cells and masked points of a.b (two launches); workspace: hyteg_hip_dot_workspace_bytes() */
+HYTEG_HIP_API int hyteg_hip_p1_dot_cells( int                  ncells,
+                                          const double* const* a,
+                                          const double* const* b,
+                                          int                  level,
+                                          const unsigned*      masks,
+                                          double*              result_dev,
+                                          void*                workspace_dev,
+                                          hyteg_hip_stream_t   stream );
+/* stencils_dev: [ncells][15][15]; rows 0..13 = the cell's share of the stencil at a point of macro-primitive slot s
+ * (w_slots of hyteg_hip_p1_apply_cell_boundary), row 14 = the inner stencil (w of hyteg_hip_p1_apply_cell) */
+HYTEG_HIP_API int hyteg_hip_p1_apply_cells( int                  ncells,
+                                            double* const*       dst,
+                                            const double* const* src,
+                                            int                  level,
+                                            const double*        stencils_dev,
+                                            const unsigned*      masks,
+                                            int                  update,
+                                            hyteg_hip_stream_t   stream );
+/* smooth_jac in two phases around the additive exchange of dst: phase 0 writes the complete update on inner points and the
+ * cell's share of A.src on boundary points; phase 1 turns the summed shares into dst = src + relax*invdiag*( rhs - dst ) */
+HYTEG_HIP_API int hyteg_hip_p1_jacobi_cells( int                  ncells,
+                                             double* const*       dst,
+                                             const double* const* rhs,
+                                             const double* const* src,
+                                             const double* const* invdiag,
+                                             int                  level,
+                                             const double*        stencils_dev,
+                                             double               relax,
+                                             const unsigned*      masks,
+                                             int                  phase,
+                                             hyteg_hip_stream_t   stream );
+/* nnc_inv_dev: [ncells][14] = 1 / numNeighborCells in the slot order of hyteg_hip_p1_restrict_cell */
+HYTEG_HIP_API int hyteg_hip_p1_restrict_cells( int                  ncells,
+                                               double* const*       coarse,
+                                               const double* const* fine,
+                                               int                  coarse_level,
+                                               const double*        nnc_inv_dev,
+                                               const unsigned*      masks,
+                                               hyteg_hip_stream_t   stream );
+HYTEG_HIP_API int hyteg_hip_p1_prolongate_cells( int                  ncells,
+                                                 const double* const* coarse,
+                                                 double* const*       fine,
+                                                 int                  coarse_level,
+                                                 const double*        nnc_inv_dev,
+                                                 const unsigned*      masks,
+                                                 int                  update,
+                                                 hyteg_hip_stream_t   stream );
+
 /* a10: additive exchange of shared points (the reduce-into-owner of VertexDoFAdditivePackInfo.hpp:676-745,
  * followed by the copy back into every adjacent cell).  A group is one physical DoF; its entries are the
  * places that hold a partial value of it: (buffer index into `bases`, element offset).
