@@ -61,6 +61,8 @@ SIGNATURES = {
                                         C.POINTER(C.c_uint), _i, _vp]),
     "hyteg_hip_p1_restrict_cells": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), _i, _vp, C.POINTER(C.c_uint), _vp]),
     "hyteg_hip_p1_prolongate_cells": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), _i, _vp, C.POINTER(C.c_uint), _i, _vp]),
+    "hyteg_hip_p1_sor_cells": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), _i, _vp, _d, _i, C.POINTER(C.c_uint), _vp]),
+    "hyteg_hip_p1_sor_shell_cells": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i, _vp, _d, C.POINTER(C.c_uint), _i, _vp]),
     "hyteg_hip_p1_sor_shell_cell": (_i, [_vp, _vp, _vp, _i, C.POINTER(_i), _dp, C.POINTER(_i), _dp, _dp, _d, C.c_uint, _i, _vp]),
     "hyteg_hip_p1_apply_face3d": (_i, [_vp, _vp, _i, _i, C.POINTER(_i), _dp, _i, _vp]),
     "hyteg_hip_gather_entries": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
@@ -259,6 +261,30 @@ def p1_restrict_cells(coarse, fine, coarse_level, nnc_inv_dev, masks, stream=0):
 def p1_prolongate_cells(coarse, fine, coarse_level, nnc_inv_dev, masks, update=REPLACE, stream=0):
     check(lib().hyteg_hip_p1_prolongate_cells(len(coarse), _ptrs(coarse), _ptrs(fine), coarse_level, nnc_inv_dev, _masks(masks), update, stream),
           "p1_prolongate_cells")
+
+
+def p1_sor_cells(u, rhs, level, stencils_dev, relax, masks, backwards=False, stream=0):
+    check(lib().hyteg_hip_p1_sor_cells(len(u), _ptrs(u), _ptrs(rhs), level, stencils_dev, float(relax), 1 if backwards else 0, _masks(masks),
+                                       stream), "p1_sor_cells")
+
+
+def p1_sor_shell_cells(dst, rhs, rest, level, tables_dev, relax, masks, backwards=False, stream=0):
+    check(lib().hyteg_hip_p1_sor_shell_cells(len(dst), _ptrs(dst), _ptrs(rhs), _ptrs(rest), level, tables_dev, float(relax), _masks(masks),
+                                             1 if backwards else 0, stream), "p1_sor_shell_cells")
+
+
+def sor_shell_tables_bytes(tables):
+    """pack hostutil.sor_tables()-style dicts into the byte layout of hyteg_hip_sor_shell_tables (for upload)"""
+    import struct
+
+    out = b""
+    for t in tables:
+        out += struct.pack("12i", *[int(v) for row in t["edge_verts"] for v in row])
+        out += struct.pack("12i", *[int(v) for row in t["face_verts"] for v in row])
+        out += struct.pack("18d", *[float(v) for row in t["edge_w"] for v in row])
+        out += struct.pack("28d", *[float(v) for row in t["face_w"] for v in row])
+        out += struct.pack("4d", *[float(v) for v in t["vertex_w"]])
+    return out
 
 
 def p1_sor_shell_cell(dst, rhs, rest, level, edge_verts, edge_w, face_verts, face_w, vertex_w, relax, mask, backwards=False, stream=0):

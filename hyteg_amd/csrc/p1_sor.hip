@@ -104,14 +104,45 @@ struct SorBlockArgs
    double          relax, one_minus_relax, invc;
    Stencil15       st;
 };
+// batched form: blockIdx.y = cell; weights from the device table [cell][15][15] (row 14 = inner stencil)
+struct SorBlockBatchArgs
+{
+   double*         u[HYTEG_HIP_MAX_BATCH];
+   const double*   rhs[HYTEG_HIP_MAX_BATCH];
+   const double*   stencils;
+   const SorBlock* blocks;
+   int             N;
+   int             backwards;
+   double          relax, one_minus_relax;
+};
 
 __device__ inline int lds_index( int pl, int ql, int rl ) { return ( ( rl + 1 ) * kBH + ( ql + 1 ) ) * kBH + ( pl + 1 ); }
 
+struct SorBlockView
+{
+   double*       u;
+   const double* rhs;
+   const double* w;
+   double        relax, one_minus_relax, invc;
+   int           N, backwards;
+};
+__device__ inline void sor_block_body( const SorBlockView A, const SorBlock blk );
+
 __global__ __launch_bounds__( kB* kB ) void p1_sor_block_kernel( const SorBlockArgs A )
+{
+   sor_block_body( SorBlockView{ A.u, A.rhs, A.st.w, A.relax, A.one_minus_relax, A.invc, A.N, A.backwards }, A.blocks[blockIdx.x] );
+}
+__global__ __launch_bounds__( kB* kB ) void p1_sor_block_batch_kernel( const SorBlockBatchArgs A )
+{
+   const int     cell = blockIdx.y;
+   const double* w    = A.stencils + (size_t) cell * 225 + 14 * 15;
+   sor_block_body( SorBlockView{ A.u[cell], A.rhs[cell], w, A.relax, A.one_minus_relax, 1.0 / w[7], A.N, A.backwards }, A.blocks[blockIdx.x] );
+}
+
+__device__ inline void sor_block_body( const SorBlockView A, const SorBlock blk )
 {
    __shared__ double lu[kBH * kBH * kBH];
    __shared__ double lr[kB * kB * kB]; // rhs of the block (a per-thread register row would be runtime-indexed -> scratch)
-   const SorBlock    blk = A.blocks[blockIdx.x];
    const int         N = A.N, n = N - 1;
    const int         p0 = blk.P * kB, q0 = blk.Q * kB, r0 = blk.R * kB;
    double*           u = A.u;
@@ -161,7 +192,7 @@ __global__ __launch_bounds__( kB* kB ) void p1_sor_block_kernel( const SorBlockA
    }
    __syncthreads();
 
-   const double* w = A.st.w;
+   const double* w = A.w;
 #pragma unroll 1
    for ( int step = 0; step < 3 * kB - 2; ++step )
    {
@@ -273,9 +304,151 @@ int get_sor_blocks( int level, const SorBlockTable** out )
    return HYTEG_HIP_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Levels <= 5 of a batch: the whole cell array (<= 6,545 entries) lives in LDS and ONE workgroup runs all hyperplanes
+// of the sweep, blockIdx.x = cell.  Same update order and the same summation order as p1_sor_plane_kernel.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kSmallThreads = 256;
+struct SorSmallArgs
+{
+   double*       u[HYTEG_HIP_MAX_BATCH];
+   const double* rhs[HYTEG_HIP_MAX_BATCH];
+   const double* stencils;
+   int           N, size, backwards;
+   double        relax, one_minus_relax;
+};
+__global__ __launch_bounds__( kSmallThreads ) void p1_sor_small_kernel( const SorSmallArgs A )
+{
+   extern __shared__ double lu[];
+   const int                cell = blockIdx.x, N = A.N, n = N - 1;
+   double*                  ug   = A.u[cell];
+   const double*            rhs  = A.rhs[cell];
+   const double*            w    = A.stencils + (size_t) cell * 225 + 14 * 15;
+   const double             invc = 1.0 / w[7];
+   for ( int i = threadIdx.x; i < A.size; i += kSmallThreads )
+      lu[i] = ug[i];
+   __syncthreads();
+   const int tmin = 6, tmax = 1 + 2 + 3 * ( n - 3 );
+   const int nzy  = ( n - 3 ) * ( n - 2 ); // candidate (z, y) pairs: z in [1, n-3], y in [1, n-2]
+   for ( int k = 0; k <= tmax - tmin; ++k )
+   {
+      const int t = A.backwards ? tmax - k : tmin + k;
+      for ( int c = threadIdx.x; c < nzy; c += kSmallThreads )
+      {
+         const int z = 1 + c / ( n - 2 ), y = 1 + c % ( n - 2 );
+         const int x = t - 2 * y - 3 * z;
+         if ( x < 1 || x + y + z > n - 1 )
+            continue;
+         const int W = N - z, R = W - y, S0 = tri( W ), Sm = tri( W + 1 );
+         const int i = slice_start( N, z ) + row_start( W, y ) + x;
+         double    acc = -w[3] * lu[i - Sm + W + 1];          // BN
+         acc           = fma( -w[10], lu[i + R], acc );       // N
+         acc           = fma( -w[5], lu[i - R], acc );        // SE
+         acc           = fma( -w[12], lu[i + S0 - W + 1], acc ); // TSE
+         acc           = fma( -w[1], lu[i - Sm + y + 1], acc );  // BE
+         acc           = fma( -w[8], lu[i + 1], acc );        // E
+         acc           = fma( -w[6], lu[i - 1], acc );        // W
+         acc           = fma( -w[13], lu[i + S0 - y - 1], acc ); // TW
+         acc           = fma( -w[2], lu[i - Sm + W], acc );      // BNW
+         acc           = fma( -w[9], lu[i + R - 1], acc );       // NW
+         acc           = fma( -w[4], lu[i - R - 1], acc );       // S
+         acc           = fma( -w[11], lu[i + S0 - W], acc );     // TS
+         acc           = fma( -w[0], lu[i - Sm + y], acc );      // BC
+         acc           = fma( -w[14], lu[i + S0 - y], acc );     // TC
+         acc           = acc + rhs[i];
+         lu[i]         = A.relax * invc * acc + A.one_minus_relax * lu[i];
+      }
+      __syncthreads();
+   }
+   for ( int i = threadIdx.x; i < A.size; i += kSmallThreads )
+      ug[i] = lu[i];
+}
+
 } // namespace
 
 extern "C" {
+
+HYTEG_HIP_API int hyteg_hip_p1_sor_cells( int                  ncells,
+                                          double* const*       u,
+                                          const double* const* rhs,
+                                          int                  level,
+                                          const double*        stencils_dev,
+                                          double               relax,
+                                          int                  backwards,
+                                          const unsigned*      masks,
+                                          hyteg_hip_stream_t   stream )
+{
+   HH_REQUIRE( ncells >= 1 && ncells <= HYTEG_HIP_MAX_BATCH, "p1_sor_cells: ncells must be 1..HYTEG_HIP_MAX_BATCH" );
+   HH_REQUIRE( u && rhs && stencils_dev && masks, "p1_sor_cells: null pointer" );
+   HH_REQUIRE( level >= 0 && level <= HYTEG_HIP_MAX_LEVEL, "p1_sor_cells: level out of range [0,11]" );
+   if ( level < 2 )
+      return HYTEG_HIP_OK; // no inner points
+   // cells whose inner points are not selected are left out of the batch
+   int           sel[HYTEG_HIP_MAX_BATCH], m = 0;
+   for ( int c = 0; c < ncells; ++c )
+      if ( masks[c] & HYTEG_HIP_MASK_INNER )
+      {
+         HH_REQUIRE( u[c] && rhs[c] && u[c] != rhs[c], "p1_sor_cells: null or aliased arrays" );
+         sel[m++] = c;
+      }
+   if ( m == 0 )
+      return HYTEG_HIP_OK;
+   const int N = ( 1 << level ) + 1;
+   if ( level <= 5 )
+   {
+      // the stencil table is indexed by the position in the batch: compact batches need the original cell index,
+      // so the kernel gets one launch per run of consecutive selected cells
+      int k = 0;
+      while ( k < m )
+      {
+         int e = k;
+         while ( e + 1 < m && sel[e + 1] == sel[e] + 1 )
+            ++e;
+         SorSmallArgs A{};
+         for ( int j = k; j <= e; ++j )
+            A.u[j - k] = u[sel[j]], A.rhs[j - k] = rhs[sel[j]];
+         A.stencils = stencils_dev + (size_t) sel[k] * 225;
+         A.N = N, A.size = (int) tet64( N ), A.backwards = backwards ? 1 : 0;
+         A.relax = relax, A.one_minus_relax = 1.0 + ( -relax );
+         const size_t lds = (size_t) A.size * sizeof( double );
+         if ( lds > 48 * 1024 )
+            HH_CHECK_HIP( hipFuncSetAttribute( reinterpret_cast< const void* >( p1_sor_small_kernel ),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds ) );
+         hipLaunchKernelGGL( p1_sor_small_kernel, dim3( e - k + 1 ), dim3( kSmallThreads ), lds, as_stream( stream ), A );
+         k = e + 1;
+      }
+      HH_CHECK_HIP( hipGetLastError() );
+      return HYTEG_HIP_OK;
+   }
+   const SorBlockTable* tab = nullptr;
+   int                  rc  = get_sor_blocks( level, &tab );
+   if ( rc != HYTEG_HIP_OK )
+      return rc;
+   int k = 0;
+   while ( k < m )
+   {
+      int e = k;
+      while ( e + 1 < m && sel[e + 1] == sel[e] + 1 )
+         ++e;
+      SorBlockBatchArgs B{};
+      for ( int j = k; j <= e; ++j )
+         B.u[j - k] = u[sel[j]], B.rhs[j - k] = rhs[sel[j]];
+      B.stencils = stencils_dev + (size_t) sel[k] * 225;
+      B.N = N, B.backwards = backwards ? 1 : 0, B.relax = relax, B.one_minus_relax = 1.0 + ( -relax );
+      const int nw = (int) tab->wavefrontStart.size() - 1;
+      for ( int q = 0; q < nw; ++q )
+      {
+         const int wv = backwards ? nw - 1 - q : q;
+         const int lo = tab->wavefrontStart[wv], hi = tab->wavefrontStart[wv + 1];
+         B.blocks     = tab->dev + lo;
+         hipLaunchKernelGGL( p1_sor_block_batch_kernel, dim3( hi - lo, e - k + 1 ), dim3( kB * kB ), 0, as_stream( stream ), B );
+      }
+      k = e + 1;
+   }
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
 
 HYTEG_HIP_API int hyteg_hip_p1_sor_cell( double*            u,
                                          const double*      rhs,

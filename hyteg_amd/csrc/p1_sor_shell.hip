@@ -18,20 +18,45 @@ using namespace hyteg_hip;
 
 namespace {
 
+// per-cell descriptors; same layout as hyteg_hip_sor_shell_tables (include/hyteg_hip.h)
+struct SorShellDesc
+{
+   int    edgeV[6][2];
+   int    faceV[4][3];
+   double edgeW[6][3];
+   double faceW[4][7];
+   double vertexW[4];
+};
+static_assert( sizeof( SorShellDesc ) == sizeof( hyteg_hip_sor_shell_tables ), "descriptor layout" );
+
+// one launch covers `ncells` cells (the cell index is a grid dimension); the single-cell entry point passes its
+// descriptor by value in `one`, the batched one a device table
 struct SorShellArgs
 {
-   double*       dst;
-   const double* rhs;
-   double*       rest;
-   int           N;
-   unsigned      mask;
-   double        relax;
-   int           backwards;
-   int           edgeV[6][2];
-   double        edgeW[6][3];
-   int           faceV[4][3];
-   double        faceW[4][7];
-   double        vertexW[4];
+   double*             dst[HYTEG_HIP_MAX_BATCH];
+   const double*       rhs[HYTEG_HIP_MAX_BATCH];
+   double*             rest[HYTEG_HIP_MAX_BATCH];
+   unsigned            mask[HYTEG_HIP_MAX_BATCH];
+   const SorShellDesc* table;
+   SorShellDesc        one;
+   int                 N;
+   int                 backwards;
+   double              relax;
+};
+// view of one cell
+struct SorShellCell
+{
+   double*             dst;
+   const double*       rhs;
+   double*             rest;
+   unsigned            mask;
+   const SorShellDesc* S;
+   int                 N, backwards;
+   double              relax;
+   __device__ inline SorShellCell( const SorShellArgs& A, int cell )
+   : dst( A.dst[cell] ), rhs( A.rhs[cell] ), rest( A.rest[cell] ), mask( A.mask[cell] ), S( A.table ? A.table + cell : &A.one ), N( A.N ),
+     backwards( A.backwards ), relax( A.relax )
+   {}
 };
 
 // index-space position of cell-local vertex k scaled by n (n = N-1 gives the vertex, n = 1 its unit vector)
@@ -42,25 +67,27 @@ __device__ inline void vtx( int k, int n, int& x, int& y, int& z )
    z = k == 3 ? n : 0;
 }
 
-__global__ __launch_bounds__( 64 ) void p1_sor_vertices_kernel( const SorShellArgs A )
+__global__ __launch_bounds__( 64 ) void p1_sor_vertices_kernel( const SorShellArgs AA )
 {
-   const int k = threadIdx.x;
+   const SorShellCell A( AA, blockIdx.x );
+   const int          k = threadIdx.x;
    if ( k >= 4 || !( ( A.mask >> ( 10 + k ) ) & 1u ) )
       return;
    int x, y, z;
    vtx( k, A.N - 1, x, y, z );
    const int i = cell_index( A.N, x, y, z );
-   A.dst[i]    = ( 1.0 - A.relax ) * A.dst[i] + A.relax * ( A.rhs[i] - A.rest[i] ) / A.vertexW[k];
+   A.dst[i]    = ( 1.0 - A.relax ) * A.dst[i] + A.relax * ( A.rhs[i] - A.rest[i] ) / A.S->vertexW[k];
 }
 
-__global__ __launch_bounds__( 64 ) void p1_sor_edges_kernel( const SorShellArgs A )
+__global__ __launch_bounds__( 64 ) void p1_sor_edges_kernel( const SorShellArgs AA )
 {
-   const int e = blockIdx.x;
+   const SorShellCell A( AA, blockIdx.y );
+   const int          e = blockIdx.x;
    if ( !( ( A.mask >> e ) & 1u ) )
       return;
    const int N = A.N, n = N - 1;
-   int       first = A.edgeV[e][0], last = A.edgeV[e][1];
-   double    wPrev = A.edgeW[e][1], wNext = A.edgeW[e][2];
+   int       first = A.S->edgeV[e][0], last = A.S->edgeV[e][1];
+   double    wPrev = A.S->edgeW[e][1], wNext = A.S->edgeW[e][2];
    if ( A.backwards )
    {
       const int    t = first;
@@ -73,7 +100,7 @@ __global__ __launch_bounds__( 64 ) void p1_sor_edges_kernel( const SorShellArgs 
    vtx( first, 1, fx, fy, fz );
    vtx( last, 1, lx, ly, lz );
    const int    dx = lx - fx, dy = ly - fy, dz = lz - fz;
-   const double sc = A.relax / A.edgeW[e][0];
+   const double sc = A.relax / A.S->edgeW[e][0];
    const double b  = -sc * wPrev;
 
    __shared__ double sa[64], sr[64];
@@ -110,13 +137,13 @@ __global__ __launch_bounds__( 64 ) void p1_sor_edges_kernel( const SorShellArgs 
 struct FaceFrame
 {
    int ox, oy, oz, ax, ay, az, bx, by, bz;
-   __device__ inline FaceFrame( const SorShellArgs& A, int f )
+   __device__ inline FaceFrame( const SorShellCell& A, int f )
    {
       int ux, uy, uz, vx, vy, vz, wx, wy, wz;
-      vtx( A.faceV[f][0], A.N - 1, ox, oy, oz );
-      vtx( A.faceV[f][0], 1, ux, uy, uz );
-      vtx( A.faceV[f][1], 1, vx, vy, vz );
-      vtx( A.faceV[f][2], 1, wx, wy, wz );
+      vtx( A.S->faceV[f][0], A.N - 1, ox, oy, oz );
+      vtx( A.S->faceV[f][0], 1, ux, uy, uz );
+      vtx( A.S->faceV[f][1], 1, vx, vy, vz );
+      vtx( A.S->faceV[f][2], 1, wx, wy, wz );
       ax = vx - ux, ay = vy - uy, az = vz - uz;
       bx = wx - ux, by = wy - uy, bz = wz - uz;
    }
@@ -133,14 +160,15 @@ constexpr int kPrepThreads = 128;
 
 // rest[p] <- a_p = (1-relax) u_p + relax/c ( rhs_p - rest_p - sum_{not-yet-updated in-plane neighbours} w u
 //                                            - sum_{already-final in-plane neighbours on the face boundary} w u )
-__global__ __launch_bounds__( kPrepThreads ) void p1_sor_face_prep_kernel( const SorShellArgs A )
+__global__ __launch_bounds__( kPrepThreads ) void p1_sor_face_prep_kernel( const SorShellArgs AA )
 {
-   const int f = blockIdx.y;
+   const SorShellCell A( AA, blockIdx.z );
+   const int          f = blockIdx.y;
    if ( !( ( A.mask >> ( 6 + f ) ) & 1u ) )
       return;
    const int       N = A.N, j = blockIdx.x + 1;
    const FaceFrame F( A, f );
-   const double    sc = A.relax / A.faceW[f][0];
+   const double    sc = A.relax / A.S->faceW[f][0];
    for ( int i = 1 + (int) threadIdx.x; i <= N - 2 - j; i += kPrepThreads )
    {
       const int idx = F.index( N, i, j );
@@ -152,7 +180,7 @@ __global__ __launch_bounds__( kPrepThreads ) void p1_sor_face_prep_kernel( const
          const bool prev = A.backwards ? ( d & 1 ) : !( d & 1 );
          const int  ni = i + kFaceDirs[d][0], nj = j + kFaceDirs[d][1];
          if ( !prev || !face_interior( N, ni, nj ) )
-            t -= A.faceW[f][1 + d] * A.dst[F.index( N, ni, nj )];
+            t -= A.S->faceW[f][1 + d] * A.dst[F.index( N, ni, nj )];
       }
       A.rest[idx] = ( 1.0 - A.relax ) * A.dst[idx] + sc * t;
    }
@@ -161,20 +189,21 @@ __global__ __launch_bounds__( kPrepThreads ) void p1_sor_face_prep_kernel( const
 constexpr int kSweepDepth = 8; // software prefetch distance of the a-values along a row
 
 template < int RPT >
-__global__ __launch_bounds__( 1024 ) void p1_sor_face_sweep_kernel( const SorShellArgs A )
+__global__ __launch_bounds__( 1024 ) void p1_sor_face_sweep_kernel( const SorShellArgs AA )
 {
-   const int f = blockIdx.x;
+   const SorShellCell A( AA, blockIdx.y );
+   const int          f = blockIdx.x;
    if ( !( ( A.mask >> ( 6 + f ) ) & 1u ) )
       return;
    extern __shared__ double val[]; // [3][stride]
    const int                N = A.N, R = N - 3, bw = A.backwards;
    const int                stride = RPT * (int) blockDim.x + 2;
    const FaceFrame          F( A, f );
-   const double             sc    = A.relax / A.faceW[f][0];
+   const double             sc    = A.relax / A.S->faceW[f][0];
    const int                kappa = bw ? 1 : 2;
    // neighbour in the same row, neighbour of step tau-1, neighbour of step tau-2
    const int    dL = bw ? 1 : 0, d1 = bw ? 5 : 4, d2 = bw ? 3 : 2;
-   const double bL = -sc * A.faceW[f][1 + dL], b1 = -sc * A.faceW[f][1 + d1], b2 = -sc * A.faceW[f][1 + d2];
+   const double bL = -sc * A.S->faceW[f][1 + dL], b1 = -sc * A.S->faceW[f][1 + d1], b2 = -sc * A.S->faceW[f][1 + d2];
    const int    tauMin = 1 + kappa, tauMax = bw ? 2 * N - 6 : 2 * N - 5;
 
    double q[RPT][kSweepDepth];
@@ -248,6 +277,46 @@ const int kFaceVerts[4][3] = { { 0, 1, 2 }, { 0, 1, 3 }, { 0, 2, 3 }, { 1, 2, 3 
 
 } // namespace
 
+// launches for the cells already placed in A (ncells of them), classes selected by the union of their masks
+static int launch_sor_shell( SorShellArgs& A, int ncells, unsigned any_mask, int backwards, hipStream_t s )
+{
+   const int  N        = A.N;
+   const bool vertices = ( any_mask >> 10 ) & 0xFu, edges = ( any_mask & 0x3Fu ) && N >= 3, faces = ( ( any_mask >> 6 ) & 0xFu ) && N >= 5;
+   auto       doVertices = [&]() { hipLaunchKernelGGL( p1_sor_vertices_kernel, dim3( ncells ), dim3( 64 ), 0, s, A ); };
+   auto       doEdges    = [&]() { hipLaunchKernelGGL( p1_sor_edges_kernel, dim3( 6, ncells ), dim3( 64 ), 0, s, A ); };
+   auto       doFaces    = [&]() {
+      const int R = N - 3;
+      hipLaunchKernelGGL( p1_sor_face_prep_kernel, dim3( R, 4, ncells ), dim3( kPrepThreads ), 0, s, A );
+      const int    rpt     = R > 512 ? 2 : 1;
+      const int    threads = ( ( ( R + rpt - 1 ) / rpt + 63 ) / 64 ) * 64;
+      const size_t lds     = size_t( 3 ) * ( size_t( rpt ) * threads + 2 ) * sizeof( double );
+      if ( rpt == 2 )
+         hipLaunchKernelGGL( p1_sor_face_sweep_kernel< 2 >, dim3( 4, ncells ), dim3( threads ), lds, s, A );
+      else
+         hipLaunchKernelGGL( p1_sor_face_sweep_kernel< 1 >, dim3( 4, ncells ), dim3( threads ), lds, s, A );
+   };
+   if ( !backwards )
+   {
+      if ( vertices )
+         doVertices();
+      if ( edges )
+         doEdges();
+      if ( faces )
+         doFaces();
+   }
+   else
+   {
+      if ( faces )
+         doFaces();
+      if ( edges )
+         doEdges();
+      if ( vertices )
+         doVertices();
+   }
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
 extern "C" {
 
 HYTEG_HIP_API int hyteg_hip_p1_sor_shell_cell( double*            dst,
@@ -270,67 +339,64 @@ HYTEG_HIP_API int hyteg_hip_p1_sor_shell_cell( double*            dst,
    mask &= HYTEG_HIP_MASK_SHELL;
    if ( mask == 0 )
       return HYTEG_HIP_OK;
-   SorShellArgs A;
-   A.dst = dst, A.rhs = rhs, A.rest = rest, A.N = ( 1 << level ) + 1, A.mask = mask, A.relax = relax, A.backwards = backwards ? 1 : 0;
+   SorShellArgs A{};
+   A.dst[0] = dst, A.rhs[0] = rhs, A.rest[0] = rest, A.mask[0] = mask;
+   A.table = nullptr, A.N = ( 1 << level ) + 1, A.relax = relax, A.backwards = backwards ? 1 : 0;
+   SorShellDesc& S = A.one;
    for ( int e = 0; e < 6; ++e )
    {
       HH_REQUIRE( is_perm( edge_verts + 2 * e, 2, kEdgeVerts[e] ), "p1_sor_shell_cell: edge_verts[e] must name the two vertices of cell edge e" );
       for ( int k = 0; k < 2; ++k )
-         A.edgeV[e][k] = edge_verts[2 * e + k];
+         S.edgeV[e][k] = edge_verts[2 * e + k];
       for ( int k = 0; k < 3; ++k )
-         A.edgeW[e][k] = edge_w[3 * e + k];
-      HH_REQUIRE( !( ( mask >> e ) & 1u ) || A.edgeW[e][0] != 0.0, "p1_sor_shell_cell: zero centre weight on an edge" );
+         S.edgeW[e][k] = edge_w[3 * e + k];
+      HH_REQUIRE( !( ( mask >> e ) & 1u ) || S.edgeW[e][0] != 0.0, "p1_sor_shell_cell: zero centre weight on an edge" );
    }
    for ( int f = 0; f < 4; ++f )
    {
       HH_REQUIRE( is_perm( face_verts + 3 * f, 3, kFaceVerts[f] ), "p1_sor_shell_cell: face_verts[f] must name the three vertices of cell face f" );
       for ( int k = 0; k < 3; ++k )
-         A.faceV[f][k] = face_verts[3 * f + k];
+         S.faceV[f][k] = face_verts[3 * f + k];
       for ( int k = 0; k < 7; ++k )
-         A.faceW[f][k] = face_w[7 * f + k];
-      HH_REQUIRE( !( ( mask >> ( 6 + f ) ) & 1u ) || A.faceW[f][0] != 0.0, "p1_sor_shell_cell: zero centre weight on a face" );
+         S.faceW[f][k] = face_w[7 * f + k];
+      HH_REQUIRE( !( ( mask >> ( 6 + f ) ) & 1u ) || S.faceW[f][0] != 0.0, "p1_sor_shell_cell: zero centre weight on a face" );
    }
    for ( int k = 0; k < 4; ++k )
    {
-      A.vertexW[k] = vertex_w[k];
-      HH_REQUIRE( !( ( mask >> ( 10 + k ) ) & 1u ) || A.vertexW[k] != 0.0, "p1_sor_shell_cell: zero centre weight on a vertex" );
+      S.vertexW[k] = vertex_w[k];
+      HH_REQUIRE( !( ( mask >> ( 10 + k ) ) & 1u ) || S.vertexW[k] != 0.0, "p1_sor_shell_cell: zero centre weight on a vertex" );
    }
-   const int  N        = A.N;
-   const bool vertices = ( mask >> 10 ) & 0xFu, edges = ( mask & 0x3Fu ) && N >= 3, faces = ( ( mask >> 6 ) & 0xFu ) && N >= 5;
-   hipStream_t s = as_stream( stream );
-   auto        doVertices = [&]() { hipLaunchKernelGGL( p1_sor_vertices_kernel, dim3( 1 ), dim3( 64 ), 0, s, A ); };
-   auto        doEdges    = [&]() { hipLaunchKernelGGL( p1_sor_edges_kernel, dim3( 6 ), dim3( 64 ), 0, s, A ); };
-   auto        doFaces    = [&]() {
-      const int R = N - 3;
-      hipLaunchKernelGGL( p1_sor_face_prep_kernel, dim3( R, 4 ), dim3( kPrepThreads ), 0, s, A );
-      const int rpt     = R > 512 ? 2 : 1;
-      const int threads = ( ( ( R + rpt - 1 ) / rpt + 63 ) / 64 ) * 64;
-      const size_t lds  = size_t( 3 ) * ( size_t( rpt ) * threads + 2 ) * sizeof( double );
-      if ( rpt == 2 )
-         hipLaunchKernelGGL( p1_sor_face_sweep_kernel< 2 >, dim3( 4 ), dim3( threads ), lds, s, A );
-      else
-         hipLaunchKernelGGL( p1_sor_face_sweep_kernel< 1 >, dim3( 4 ), dim3( threads ), lds, s, A );
-   };
-   if ( !backwards )
+   return launch_sor_shell( A, 1, mask, backwards, as_stream( stream ) );
+}
+
+HYTEG_HIP_API int hyteg_hip_p1_sor_shell_cells( int                               ncells,
+                                                double* const*                    dst,
+                                                const double* const*              rhs,
+                                                double* const*                    rest,
+                                                int                               level,
+                                                const hyteg_hip_sor_shell_tables* tables_dev,
+                                                double                            relax,
+                                                const unsigned*                   masks,
+                                                int                               backwards,
+                                                hyteg_hip_stream_t                stream )
+{
+   HH_REQUIRE( ncells >= 1 && ncells <= HYTEG_HIP_MAX_BATCH, "p1_sor_shell_cells: ncells must be 1..HYTEG_HIP_MAX_BATCH" );
+   HH_REQUIRE( dst && rhs && rest && tables_dev && masks, "p1_sor_shell_cells: null pointer" );
+   HH_REQUIRE( level >= 0 && level <= HYTEG_HIP_MAX_LEVEL, "p1_sor_shell_cells: level out of range [0,11]" );
+   SorShellArgs A{};
+   unsigned     any = 0;
+   for ( int c = 0; c < ncells; ++c )
    {
-      if ( vertices )
-         doVertices();
-      if ( edges )
-         doEdges();
-      if ( faces )
-         doFaces();
+      HH_REQUIRE( dst[c] && rhs[c] && rest[c] && dst[c] != rhs[c] && dst[c] != rest[c] && rhs[c] != rest[c],
+                  "p1_sor_shell_cells: null or aliased arrays" );
+      A.dst[c] = dst[c], A.rhs[c] = rhs[c], A.rest[c] = rest[c], A.mask[c] = masks[c] & HYTEG_HIP_MASK_SHELL;
+      any |= A.mask[c];
    }
-   else
-   {
-      if ( faces )
-         doFaces();
-      if ( edges )
-         doEdges();
-      if ( vertices )
-         doVertices();
-   }
-   HH_CHECK_HIP( hipGetLastError() );
-   return HYTEG_HIP_OK;
+   if ( any == 0 )
+      return HYTEG_HIP_OK;
+   A.table = reinterpret_cast< const SorShellDesc* >( tables_dev );
+   A.N = ( 1 << level ) + 1, A.relax = relax, A.backwards = backwards ? 1 : 0;
+   return launch_sor_shell( A, ncells, any, backwards, as_stream( stream ) );
 }
 
 } // extern "C"

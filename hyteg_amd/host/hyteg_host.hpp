@@ -417,7 +417,8 @@ class PrimitiveStorage
    }
 
    // ---- batched launches (p1_batch.hip): one launch for all local cells on the levels where a cell is small ----
-   // Default: levels <= 6 whenever the rank owns more than one cell; HYTEG_AMD_BATCH_MAX_LEVEL overrides (-1 disables).
+   // Default: levels <= 6 (also for a single cell: inner and boundary points in one launch, the whole Gauss-Seidel sweep of
+   // a level <= 5 cell in one workgroup); HYTEG_AMD_BATCH_MAX_LEVEL overrides (-1 disables).
    bool useBatch( uint_t level ) const
    {
       if ( batchMaxLevel_ == -2 )
@@ -425,7 +426,7 @@ class PrimitiveStorage
          const char* e  = std::getenv( "HYTEG_AMD_BATCH_MAX_LEVEL" );
          batchMaxLevel_ = e ? std::atoi( e ) : 6;
       }
-      return localCells_.size() > 1 && (int) level <= batchMaxLevel_;
+      return !localCells_.empty() && (int) level <= batchMaxLevel_;
    }
    void setBatchMaxLevel( int l ) { batchMaxLevel_ = l; }
    std::vector< unsigned > masksFor( DoFType flag, bool owned = false, unsigned keep = HYTEG_HIP_MASK_ALL ) const
@@ -449,14 +450,18 @@ class PrimitiveStorage
       return nncInv_;
    }
    // small read-only device table owned by the storage (freed with it)
-   double* uploadTable( const std::vector< double >& h ) const
+   void* uploadBytes( const void* h, size_t bytes ) const
    {
       void* p = nullptr;
-      hipCheck( hyteg_hip_malloc( &p, std::max< size_t >( 1, h.size() ) * sizeof( double ) ), "uploadTable: malloc" );
-      hipCheck( hyteg_hip_upload( p, h.data(), h.size() * sizeof( double ), stream_ ), "uploadTable: upload" );
+      hipCheck( hyteg_hip_malloc( &p, std::max< size_t >( 8, bytes ) ), "uploadTable: malloc" );
+      hipCheck( hyteg_hip_upload( p, h, bytes, stream_ ), "uploadTable: upload" );
       hipCheck( hyteg_hip_stream_synchronize( stream_ ), "uploadTable: sync" );
       scratchAll_.push_back( p );
-      return static_cast< double* >( p );
+      return p;
+   }
+   double* uploadTable( const std::vector< double >& h ) const
+   {
+      return static_cast< double* >( uploadBytes( h.data(), h.size() * sizeof( double ) ) );
    }
    // calls fn( first, count ) for chunks of at most HYTEG_HIP_MAX_BATCH local cells
    template < typename F >
@@ -1410,6 +1415,17 @@ class P1ConstantOperator
       bool anyShell = false;
       forCells( [&]( uint_t, const MacroCell& cell ) { anyShell = anyShell || ( storage_->maskFor( cell, flag ) & HYTEG_HIP_MASK_SHELL ); } );
       auto sweepCells = [&]() {
+         if ( storage_->useBatch( level ) )
+         {
+            const auto masks = storage_->masksFor( flag );
+            storage_->forCellChunks( [&]( int first, int count ) {
+               const auto u = dst.cellPointers( level, first, count ), r = rhs.cellPointers( level, first, count );
+               hipCheck( hyteg_hip_p1_sor_cells( count, u.data(), r.data(), (int) level, stencilTable( level ) + (size_t) first * 225, relax,
+                                                 backwards ? 1 : 0, masks.data() + first, storage_->stream() ),
+                         "smooth_sor: cells (batched)" );
+            } );
+            return;
+         }
          forCells( [&]( uint_t c, const MacroCell& cell ) {
             const unsigned mask = storage_->maskFor( cell, flag );
             if ( ( mask & HYTEG_HIP_MASK_INNER ) && level >= HYTEG_HIP_MIN_LEVEL )
@@ -1447,6 +1463,18 @@ class P1ConstantOperator
                       "smooth_sor: rest" );
          } );
          rest.sumSharedCopies( level, flag );
+         if ( storage_->useBatch( level ) )
+         {
+            const auto masks = storage_->masksFor( flag, false, bits & HYTEG_HIP_MASK_SHELL );
+            storage_->forCellChunks( [&]( int first, int count ) {
+               const auto u = dst.cellPointers( level, first, count ), r = rhs.cellPointers( level, first, count ),
+                          q = rest.cellPointers( level, first, count );
+               hipCheck( hyteg_hip_p1_sor_shell_cells( count, u.data(), r.data(), q.data(), (int) level, shellTable( level ) + first, relax,
+                                                       masks.data() + first, backwards ? 1 : 0, storage_->stream() ),
+                         "smooth_sor: shell (batched)" );
+            } );
+            return;
+         }
          forCells( [&]( uint_t c, const MacroCell& cell ) {
             const auto&    T    = sorTables_.at( level ).at( cell.id );
             const unsigned mask = storage_->maskFor( cell, flag ) & bits;
@@ -1597,6 +1625,26 @@ class P1ConstantOperator
       }
       return stencilTables_[level] = storage_->uploadTable( h );
    }
+   const hyteg_hip_sor_shell_tables* shellTable( uint_t level ) const
+   {
+      auto it = shellTables_.find( level );
+      if ( it != shellTables_.end() )
+         return it->second;
+      std::vector< hyteg_hip_sor_shell_tables > h;
+      for ( int id : storage_->getLocalCellIDs() )
+      {
+         const auto&                T = sorTables_.at( level ).at( id );
+         hyteg_hip_sor_shell_tables r;
+         std::memcpy( r.edge_verts, T.edgeVerts, sizeof( r.edge_verts ) );
+         std::memcpy( r.face_verts, T.faceVerts, sizeof( r.face_verts ) );
+         std::memcpy( r.edge_w, T.edgeW, sizeof( r.edge_w ) );
+         std::memcpy( r.face_w, T.faceW, sizeof( r.face_w ) );
+         std::memcpy( r.vertex_w, T.vertexW, sizeof( r.vertex_w ) );
+         h.push_back( r );
+      }
+      return shellTables_[level] =
+                 static_cast< const hyteg_hip_sor_shell_tables* >( storage_->uploadBytes( h.data(), h.size() * sizeof( h[0] ) ) );
+   }
    const double* restTable( uint_t level ) const
    {
       auto it = restTables_.find( level );
@@ -1687,6 +1735,7 @@ class P1ConstantOperator
    std::map< uint_t, std::vector< stencil::CellSorTables > >  sorTables_;
    mutable std::map< uint_t, std::unique_ptr< P1Function< double > > > sorRest_;
    mutable std::map< uint_t, const double* >                  stencilTables_, restTables_;
+   mutable std::map< uint_t, const hyteg_hip_sor_shell_tables* > shellTables_;
    std::shared_ptr< P1Function< double > >                    inverseDiagonalValues_;
 };
 

@@ -368,6 +368,38 @@ HYTEG_HIP_API int hyteg_hip_p1_prolongate_cells( int                  ncells,
                                                  int                  update,
                                                  hyteg_hip_stream_t   stream );
 
+/* in-place SOR / GS sweep over the inner points of every cell whose mask has bit 14 (hyteg_hip_p1_sor_cell for a batch);
+ * levels <= 5: one workgroup per cell with the array in LDS, above: the blocked sweep with the cell as second grid dimension.
+ * stencils_dev as for hyteg_hip_p1_apply_cells (row 14 is used). */
+HYTEG_HIP_API int hyteg_hip_p1_sor_cells( int                  ncells,
+                                          double* const*       u,
+                                          const double* const* rhs,
+                                          int                  level,
+                                          const double*        stencils_dev,
+                                          double               relax,
+                                          int                  backwards,
+                                          const unsigned*      masks,
+                                          hyteg_hip_stream_t   stream );
+/* per-cell tables of hyteg_hip_p1_sor_shell_cell as one record (device array of `ncells` records for the batched form) */
+typedef struct hyteg_hip_sor_shell_tables
+{
+   int    edge_verts[6][2];
+   int    face_verts[4][3];
+   double edge_w[6][3];
+   double face_w[4][7];
+   double vertex_w[4];
+} hyteg_hip_sor_shell_tables;
+HYTEG_HIP_API int hyteg_hip_p1_sor_shell_cells( int                               ncells,
+                                                double* const*                    dst,
+                                                const double* const*              rhs,
+                                                double* const*                    rest,
+                                                int                               level,
+                                                const hyteg_hip_sor_shell_tables* tables_dev,
+                                                double                            relax,
+                                                const unsigned*                   masks,
+                                                int                               backwards,
+                                                hyteg_hip_stream_t                stream );
+
 /* a10: additive exchange of shared points (the reduce-into-owner of VertexDoFAdditivePackInfo.hpp:676-745,
  * followed by the copy back into every adjacent cell).  A group is one physical DoF; its entries are the
  * places that hold a partial value of it: (buffer index into `bases`, element offset).

@@ -167,3 +167,60 @@ def test_vcycle_with_batched_kernels_equals_the_per_cell_kernels(env, mesh, lo, 
     for a, b in zip(xb, xc):
         assert np.abs(a - b).max() <= 1e-11 * scale
     assert abs(db - dc) <= 1e-9 * abs(dc)
+
+
+@pytest.mark.parametrize("level", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("backwards", [False, True])
+def test_sor_cells_match_the_per_cell_sweeps(env, level, backwards):
+    """levels <= 4: same update and summation order as the per-cell plane kernel (bit-identical); level 5 is compared
+    with the blocked per-cell kernel (other summation order inside an update), level 6 is the same blocked kernel batched"""
+    torch, capi, host, po = env
+    tabs = _cells(po, level)
+    n = po.cell_size(level)
+    rng = np.random.default_rng(level)
+    u0, b = [rng.standard_normal(n) for _ in range(3)], [rng.standard_normal(n) for _ in range(3)]
+    masks = [0x7FFF, 0x3FFF, 0x4000]  # the middle cell has no inner points selected: untouched
+    du, db, dtab = [_dev(torch, a) for a in u0], [_dev(torch, a) for a in b], _dev(torch, tabs.reshape(-1))
+    capi.p1_sor_cells([t.data_ptr() for t in du], [t.data_ptr() for t in db], level, dtab.data_ptr(), 1.15, masks, backwards)
+    torch.cuda.synchronize()
+    for c in range(3):
+        got = du[c].cpu().numpy()
+        if not masks[c] & po.MASK_INNER:
+            assert np.array_equal(got, u0[c])
+            continue
+        ref = _dev(torch, u0[c])
+        capi.p1_sor_cell(ref.data_ptr(), db[c].data_ptr(), level, list(tabs[c][14]), 1.15, backwards)
+        torch.cuda.synchronize()
+        want = ref.cpu().numpy()
+        if level == 5:
+            assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+        else:
+            assert np.array_equal(got, want)
+        oracle = po.sor_cell(u0[c].copy(), b[c], level, tabs[c][14], 1.15, backwards)
+        assert np.abs(got - oracle).max() <= 1e-12 * np.abs(oracle).max()
+
+
+@pytest.mark.parametrize("level", [0, 1, 2, 4, 6])
+@pytest.mark.parametrize("backwards", [False, True])
+def test_sor_shell_cells_match_the_per_cell_kernel(env, level, backwards):
+    torch, capi, host, po = env
+    import hostutil as hu
+
+    v, c = hu.read_msh(hu.MESHES / "regular_octahedron_8el.msh")
+    tables = [hu.sor_tables(v, c, level)[k] for k in (1, 4, 7)]
+    n = po.cell_size(level)
+    rng = np.random.default_rng(40 + level)
+    u0, b, rest = ([rng.standard_normal(n) for _ in range(3)] for _ in range(3))
+    masks = [0x3FFF, 0x2A5 | (0x5 << 10), 0x3C0]
+    raw = np.frombuffer(capi.sor_shell_tables_bytes(tables), dtype=np.uint8).copy()
+    dtab = torch.from_numpy(raw).to("cuda")
+    du, db, dr = ([_dev(torch, a) for a in arrs] for arrs in (u0, b, rest))
+    capi.p1_sor_shell_cells([t.data_ptr() for t in du], [t.data_ptr() for t in db], [t.data_ptr() for t in dr], level, dtab.data_ptr(), 1.1,
+                            masks, backwards)
+    torch.cuda.synchronize()
+    for k, t in enumerate(tables):
+        ref, rr = _dev(torch, u0[k]), _dev(torch, rest[k])
+        capi.p1_sor_shell_cell(ref.data_ptr(), db[k].data_ptr(), rr.data_ptr(), level, t["edge_verts"], t["edge_w"], t["face_verts"],
+                               t["face_w"], t["vertex_w"], 1.1, masks[k], backwards)
+        torch.cuda.synchronize()
+        assert np.array_equal(du[k].cpu().numpy(), ref.cpu().numpy())
