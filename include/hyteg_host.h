@@ -39,8 +39,8 @@ HYTEG_HOST_API int hyteg_host_storage_local_cell( hh_storage_t s, int local_inde
 HYTEG_HOST_API int hyteg_host_storage_mask( hh_storage_t s, int local_index, int flag, int owned, unsigned* mask );
 HYTEG_HOST_API int hyteg_host_storage_set_boundary_type( hh_storage_t s, int dof_type );
 HYTEG_HOST_API int hyteg_host_storage_set_stream( hh_storage_t s, void* stream );
-/* levels <= `level` use the batched kernels (one launch for all local cells, inner and boundary points together);
- * -1 disables batching.  Default 6, or the environment variable HYTEG_AMD_BATCH_MAX_LEVEL. */
+/* levels <= `level` use the batched kernels (one launch for all local cells, inner and boundary points together) when the
+ * rank owns more than one cell; -1 disables batching.  Default 6, or the environment variable HYTEG_AMD_BATCH_MAX_LEVEL. */
 HYTEG_HOST_API int hyteg_host_storage_set_batch_max_level( hh_storage_t s, int level );
 /* multi-rank hooks: exchange_begin( user, level, cls ) starts the all-to-all of the packed send buffer (may return
  * before completion), exchange_end( user, level, cls ) waits for it; allreduce_sum( user, values, n ) */
