@@ -101,13 +101,20 @@ def main():
         raise SystemExit(f"bench.py supports 1, 2, 4 or 8 GPUs (one macro-cell per GPU), not {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    # rehearsal on a box with fewer GPUs than ranks (development only): HYTEG_BENCH_BACKEND=gloo HYTEG_BENCH_SHARE_GPU=1
+    backend = os.environ.get("HYTEG_BENCH_BACKEND", "nccl")
+    if os.environ.get("HYTEG_BENCH_SHARE_GPU") == "1":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     level = args.level
     capi.lib()
@@ -168,7 +175,7 @@ def main():
     dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels are launched on
 
     if dist is not None:
-        tmax = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed, dev_ms = float(tmax[0]), float(tmax[1])
 
