@@ -828,6 +828,22 @@ int main( int argc, char** argv )
          }
          filter = "zaddaux";
       }
+      if ( want( "zsoff" ) )
+      {
+         filter = "";
+         printf( "instruction diet (SOFF): 4,8 shipped | 4,8 SOFF | 4,4 SOFF | 2,8 SOFF | 4,6 SOFF | 6,4 SOFF | 4,8 SOFF F2 ; twice\n" );
+         for ( int rep = 0; rep < 2; ++rep )
+         {
+            run( 4, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 8, 0, 2, 0, 1, false, true > );
+            run( 4, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 8, 0, 2, 0, 1, false, true, 0, true > );
+            run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 0, 2, 0, 1, false, true, 0, true > );
+            run( 2, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 2, 8, 0, 2, 0, 1, false, true, 0, true > );
+            run( 4, 6, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 6, 0, 2, 0, 1, false, true, 0, true > );
+            run( 6, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 6, 4, 0, 2, 0, 1, false, true, 0, true > );
+            run( 4, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 8, 0, 2, 0, 2, false, true, 0, true > );
+         }
+         filter = "zsoff";
+      }
       if ( want( "zaux" ) )
       {
          filter = "";

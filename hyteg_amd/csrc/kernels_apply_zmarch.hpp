@@ -60,6 +60,18 @@ __device__ inline double zm_load( __amdgpu_buffer_rsrc_t r, int byte_off )
    zm_v2i_t v = __builtin_amdgcn_raw_buffer_load_b64( r, byte_off, 0, AUX );
    return *reinterpret_cast< double* >( &v );
 }
+// wave-uniform row base in the scalar offset, lane part in the vector offset (the range check sees the vector offset only)
+template < int AUX = 0 >
+__device__ inline double zm_load2( __amdgpu_buffer_rsrc_t r, int voff, int soff )
+{
+   zm_v2i_t v = __builtin_amdgcn_raw_buffer_load_b64( r, voff, soff, AUX );
+   return *reinterpret_cast< double* >( &v );
+}
+template < int AUX = 0 >
+__device__ inline void zm_store2( __amdgpu_buffer_rsrc_t r, int voff, int soff, double d )
+{
+   __builtin_amdgcn_raw_buffer_store_b64( *reinterpret_cast< zm_v2i_t* >( &d ), r, voff, soff, AUX );
+}
 template < int AUX = 0 >
 __device__ inline void zm_store( __amdgpu_buffer_rsrc_t r, int byte_off, double d )
 {
@@ -91,11 +103,15 @@ constexpr int kStoreAuxDefault = 2;
 // chain per row): measured equal to FACT == 1 within noise at levels 6..9, kept for the harness only.
 // PFALL: all source loads of the brick are issued before the first store (tests whether loads queue behind the
 // nontemporal stores in the wave's in-order vmcnt): measured 4-5% SLOWER at level 8, harness only.
+// SOFF: instruction diet.  The kernel issues ~45 instructions per output row and a wave issues one every 4-5 cycles, which
+// at level 8 (62 wave-rows per SIMD) is ~5 us of issue time per SIMD, as much as the HBM time.  Row bases go into the
+// buffer instructions' scalar offset (no per-lane address add), masked loads become one v_min (lanes beyond the row end
+// re-read the row's last entry: same cache line), the store predicate one unsigned compare against a wave-uniform limit.
 // MASKLD: lanes whose x lies beyond the end of the row being loaded get an out-of-range offset (the buffer range check
 // returns 0 without touching the cache) instead of fetching the next row's entries: ~30% of all lanes at level 8.
 // Also means the kernel never reads past the end of the source array.  Level 8: -1..2%.
 template < int MODE, int NY, int LZ, int ABL = 0, int ST_AUX = kStoreAuxDefault, int LD_AUX = 0, int FACT = 1, bool PFALL = false,
-           bool MASKLD = false, int EX_AUX = 0 >
+           bool MASKLD = false, int EX_AUX = 0, bool SOFF = false >
 __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_kernel( const ZMarchArgs A )
 {
    int b = blockIdx.x;
@@ -133,7 +149,12 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_k
          const bool need = ( q == 0 ) ? ( r >= 1 ) : ( q == LZ + 1 ? ( r <= NY ) : true );
          if ( need )
          {
-            if constexpr ( MASKLD )
+            if constexpr ( SOFF )
+            {
+               const int last8 = ( W_q - ( ym + r ) - 1 - t.xb ) * 8; // byte offset of the row's last entry from lane 0's
+               S[q][r]         = zm_load2< LD_AUX >( rs, min( lane_off, last8 ), ix * 8 ); // negative: out of range, returns 0
+            }
+            else if constexpr ( MASKLD )
             {
                const int last = W_q - ( ym + r ) - 1 - t.xb; // lane holding the last entry of this row
                S[q][r]        = zm_load< LD_AUX >( rs, lane <= last ? ix * 8 + lane_off : -8 );
@@ -188,9 +209,19 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_k
 #pragma unroll
          for ( int j = 0; j < NY; ++j )
          {
+            if constexpr ( SOFF )
+            {
+               const int last8 = ( W - ( t.y0 + j ) - 1 - t.xb ) * 8;
+               const int vo    = min( lane_off, last8 );
+               ex0[j]          = MODE == APPLY_ADD ? zm_load2< EX_AUX >( rd, vo, ie * 8 ) : zm_load2< EX_AUX >( rr, vo, ie * 8 );
+               ex1[j]          = ( MODE == APPLY_JACOBI && A.invdiag ) ? zm_load2( ri, vo, ie * 8 ) : invc;
+            }
+            else
+            {
             const int off = ie * 8 + lane_off;
             ex0[j]        = MODE == APPLY_ADD ? zm_load< EX_AUX >( rd, off ) : zm_load< EX_AUX >( rr, off );
             ex1[j]        = ( MODE == APPLY_JACOBI && A.invdiag ) ? zm_load( ri, off ) : invc; // nt here: 18.8 -> 21.0 us
+            }
             ie += W - ( t.y0 + j );
          }
       }
@@ -300,6 +331,13 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_k
          {
             if ( out == 1.2345e-300 )
                zm_store< 0 >( rd, off, out );
+         }
+         else if constexpr ( SOFF )
+         {
+            // outputs are lanes 1 .. min( 62, R - 2 - xb ) of slices that exist: one unsigned compare of (lane - 1)
+            const int      cnt = s < t.nz ? min( 62, R - 2 - t.xb ) : 0; // wave-uniform
+            const unsigned lm1 = (unsigned) ( lane - 1 );
+            zm_store2< ST_AUX >( rd, lm1 < (unsigned) max( cnt, 0 ) ? lane_off : -8, io * 8, out );
          }
          else
             zm_store< ST_AUX >( rd, active ? off : -8, out );

@@ -40,7 +40,8 @@ int launch_zmarch_lz( double* dst, const double* src, const double* rhs, const d
    A.xcd_chunk = nblocks / 8;
    // nontemporal stores, plain source loads, factorised lane shifts, loads masked beyond the row end; the arrays that
    // are read exactly once (dst of Add, rhs / inverse diagonal of Jacobi) are loaded nontemporal (Add: 18.6 -> 17.2 us)
-   hipLaunchKernelGGL( ( p1_apply_zmarch_kernel< MODE, kBrickNY, LZ, 0, kStoreAuxDefault, 0, 1, false, true, 2 > ),
+   // ... and scalar-offset addressing with clamped loads and a one-compare store predicate (SOFF: -15% instructions)
+   hipLaunchKernelGGL( ( p1_apply_zmarch_kernel< MODE, kBrickNY, LZ, 0, kStoreAuxDefault, 0, 1, false, true, 2, true > ),
                        dim3( nblocks ),
                        dim3( 64 * kZMarchWavesPerBlock ),
                        0,
