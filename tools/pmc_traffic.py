@@ -15,9 +15,19 @@ tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
 COPY_BYTES = 2862209 * 8  # one level-8 cell array, read once and written once by the calibration copy kernel
 
 
+def newest_per_pass(prefix):
+    """gpurun merges every call's outputs into the same local tree: keep only the newest CSV of each pass directory"""
+    out = []
+    for d in sorted(src.glob(f"{prefix}_*")):
+        files = sorted((q for q in d.rglob("*counter_collection.csv")), key=lambda q: q.stat().st_mtime)
+        if files:
+            out.append(str(files[-1]))
+    return out
+
+
 def mean_counter(prefix, kernel_substr, counter):
     vals = []
-    for f in glob.glob(str(src / f"{prefix}_*" / "**" / "*counter_collection.csv"), recursive=True):
+    for f in newest_per_pass(prefix):
         for r in csv.DictReader(open(f)):
             if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter:
                 vals.append(float(r["Counter_Value"]))
@@ -29,7 +39,7 @@ write, nw = mean_counter("bench", "p1_apply_zmarch_kernel", "WRITE_SIZE")
 cfetch, _ = mean_counter("calib", "copy_w_kernel<double, false>", "FETCH_SIZE")
 cwrite, _ = mean_counter("calib", "copy_w_kernel<double, false>", "WRITE_SIZE")
 kname = None
-for f in glob.glob(str(src / "bench_*" / "**" / "*counter_collection.csv"), recursive=True):
+for f in newest_per_pass("bench"):
     for r in csv.DictReader(open(f)):
         if "p1_apply_zmarch_kernel" in r["Kernel_Name"]:
             kname = r["Kernel_Name"].split("(")[0]
