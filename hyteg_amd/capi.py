@@ -61,6 +61,8 @@ SIGNATURES = {
                                         C.POINTER(C.c_uint), _i, _vp]),
     "hyteg_hip_p1_restrict_cells": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), _i, _vp, C.POINTER(C.c_uint), _vp]),
     "hyteg_hip_p1_prolongate_cells": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), _i, _vp, C.POINTER(C.c_uint), _i, _vp]),
+    "hyteg_hip_p2_edge_array_size": (C.c_size_t, [_i]),
+    "hyteg_hip_p2_elementwise_apply_cell": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _d, _i, C.c_uint, _vp]),
     "hyteg_hip_p1_sor_cells": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), _i, _vp, _d, _i, C.POINTER(C.c_uint), _vp]),
     "hyteg_hip_p1_sor_shell_cells": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i, _vp, _d, C.POINTER(C.c_uint), _i, _vp]),
     "hyteg_hip_p1_sor_shell_cell": (_i, [_vp, _vp, _vp, _i, C.POINTER(_i), _dp, C.POINTER(_i), _dp, _dp, _d, C.c_uint, _i, _vp]),
@@ -261,6 +263,15 @@ def p1_restrict_cells(coarse, fine, coarse_level, nnc_inv_dev, masks, stream=0):
 def p1_prolongate_cells(coarse, fine, coarse_level, nnc_inv_dev, masks, update=REPLACE, stream=0):
     check(lib().hyteg_hip_p1_prolongate_cells(len(coarse), _ptrs(coarse), _ptrs(fine), coarse_level, nnc_inv_dev, _masks(masks), update, stream),
           "p1_prolongate_cells")
+
+
+def p2_edge_array_size(level):
+    return int(lib().hyteg_hip_p2_edge_array_size(level))
+
+
+def p2_elementwise_apply_cell(dst_v, dst_e, src_v, src_e, level, elmat_dev, alpha=1.0, update=REPLACE, mask=0x7FFF, stream=0):
+    check(lib().hyteg_hip_p2_elementwise_apply_cell(dst_v, dst_e, src_v, src_e, level, elmat_dev, float(alpha), update, mask, stream),
+          "p2_elementwise_apply_cell")
 
 
 def p1_sor_cells(u, rhs, level, stencils_dev, relax, masks, backwards=False, stream=0):

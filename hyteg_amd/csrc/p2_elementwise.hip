@@ -1,0 +1,280 @@
+// P2 elementwise operator on one macro-cell: dst = alpha * A * src for vertex + edge DoFs, where A is
+// given by the 10 x 10 element matrices of the six micro-cell types (constant over an affine macro-cell).
+// Reference: P2ElementwiseOperator::gemv / localMatrixVectorMultiply3D (src/hyteg/elementwiseoperators/
+// P2ElementwiseOperator.cpp:66-223): a loop over micro-cells that SCATTERS ten sums into the destination arrays.
+// Here the operation is a GATHER (no atomics, fixed summation order = the order the reference's scatter loop produces):
+// a destination DoF of kind c (vertex, or edge orientation X/Y/Z/XY/XZ/YZ/XYZ) is local DoF k of the micro-cell
+// (type t, index dof - offset[t][k]) for a fixed list of (t, k); each such cell contributes row k of its element matrix
+// times its ten source values.  The lists and offsets follow from celldof::macrocell::getMicroVerticesFromMicroCell
+// (volumedofspace/CellDoFIndexing.hpp:155-198) and edgedof::calcEdgeDoFIndex / calcEdgeDoFOrientation
+// (edgedofspace/EdgeDoFIndexing.hpp:89-165); they are built once on the host.
+// First version: table-driven, one thread per destination DoF, direct loads.  Parity first; the roofline work
+// (row-wise register reuse as in the P1 z-march kernel) is the next step for this row.
+#include <mutex>
+
+#include "common.hpp"
+
+using namespace hyteg_hip;
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct LocalDof
+{
+   signed char kind; // 0 vertex array, 1..7 edge array block X, Y, Z, XY, XZ, YZ, XYZ
+   signed char ox, oy, oz;
+};
+struct Entry
+{
+   signed char type, row, ox, oy, oz, pad[3];
+};
+struct P2Tables
+{
+   LocalDof    local[6][10];
+   Entry       entries[8][24];
+   signed char nentries[8];
+};
+
+const int kMicroVerts[6][4][3] = { { { 0, 0, 0 }, { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } }, { { 1, 0, 0 }, { 1, 1, 0 }, { 0, 1, 0 }, { 1, 0, 1 } },
+                                   { { 1, 0, 0 }, { 0, 1, 0 }, { 1, 0, 1 }, { 0, 0, 1 } }, { { 1, 1, 0 }, { 1, 1, 1 }, { 0, 1, 1 }, { 1, 0, 1 } },
+                                   { { 1, 0, 1 }, { 0, 1, 1 }, { 0, 0, 1 }, { 0, 1, 0 } }, { { 0, 1, 0 }, { 1, 1, 0 }, { 1, 0, 1 }, { 0, 1, 1 } } };
+const int kEdgePairs[6][2]      = { { 2, 3 }, { 1, 3 }, { 1, 2 }, { 0, 3 }, { 0, 2 }, { 0, 1 } };
+// logical edge index = (lower end point by the orientation's rule) + shift; orientation from the difference vector
+void edge_of( const int* a, const int* b, int& kind, int* e )
+{
+   const int  d[3] = { b[0] - a[0], b[1] - a[1], b[2] - a[2] };
+   const int* lo;
+   if ( d[1] == 0 && d[2] == 0 )
+   {
+      kind = 1, lo = a[0] < b[0] ? a : b;
+      e[0] = lo[0], e[1] = lo[1], e[2] = lo[2];
+   }
+   else if ( d[0] == 0 && d[2] == 0 )
+   {
+      kind = 2, lo = a[1] < b[1] ? a : b;
+      e[0] = lo[0], e[1] = lo[1], e[2] = lo[2];
+   }
+   else if ( d[0] == 0 && d[1] == 0 )
+   {
+      kind = 3, lo = a[2] < b[2] ? a : b;
+      e[0] = lo[0], e[1] = lo[1], e[2] = lo[2];
+   }
+   else if ( d[2] == 0 )
+   {
+      kind = 4, lo = a[0] < b[0] ? a : b;
+      e[0] = lo[0], e[1] = lo[1] - 1, e[2] = lo[2];
+   }
+   else if ( d[1] == 0 )
+   {
+      kind = 5, lo = a[0] < b[0] ? a : b;
+      e[0] = lo[0], e[1] = lo[1], e[2] = lo[2] - 1;
+   }
+   else if ( d[0] == 0 )
+   {
+      kind = 6, lo = a[1] < b[1] ? a : b;
+      e[0] = lo[0], e[1] = lo[1], e[2] = lo[2] - 1;
+   }
+   else
+   {
+      kind = 7, lo = a[0] < b[0] ? a : b;
+      e[0] = lo[0], e[1] = lo[1] - 1, e[2] = lo[2];
+   }
+}
+
+const P2Tables& tables()
+{
+   static P2Tables       T;
+   static std::once_flag once;
+   std::call_once( once, [] {
+      for ( int t = 0; t < 6; ++t )
+      {
+         for ( int k = 0; k < 4; ++k )
+            T.local[t][k] = LocalDof{ 0, (signed char) kMicroVerts[t][k][0], (signed char) kMicroVerts[t][k][1], (signed char) kMicroVerts[t][k][2] };
+         for ( int k = 0; k < 6; ++k )
+         {
+            int kind, e[3];
+            edge_of( kMicroVerts[t][kEdgePairs[k][0]], kMicroVerts[t][kEdgePairs[k][1]], kind, e );
+            T.local[t][4 + k] = LocalDof{ (signed char) kind, (signed char) e[0], (signed char) e[1], (signed char) e[2] };
+         }
+      }
+      for ( int c = 0; c < 8; ++c )
+      {
+         int n = 0;
+         for ( int t = 0; t < 6; ++t )
+         {
+            // cells of one type contribute in micro-cell iteration order (z, y, x ascending), i.e. offsets descending
+            int first = n;
+            for ( int k = 0; k < 10; ++k )
+               if ( T.local[t][k].kind == c )
+                  T.entries[c][n++] = Entry{ (signed char) t, (signed char) k, T.local[t][k].ox, T.local[t][k].oy, T.local[t][k].oz, { 0, 0, 0 } };
+            for ( int a = first; a < n; ++a )
+               for ( int b = a + 1; b < n; ++b )
+               {
+                  const Entry &A = T.entries[c][a], &B = T.entries[c][b];
+                  const bool   swap = B.oz > A.oz || ( B.oz == A.oz && ( B.oy > A.oy || ( B.oy == A.oy && B.ox > A.ox ) ) );
+                  if ( swap )
+                     std::swap( T.entries[c][a], T.entries[c][b] );
+               }
+         }
+         T.nentries[c] = (signed char) n;
+      }
+   } );
+   return T;
+}
+
+struct P2Args
+{
+   double*       dstV;
+   double*       dstE;
+   const double* srcV;
+   const double* srcE;
+   const double* elmat; // device, [6][10][10]
+   double        alpha;
+   int           N, update;
+   unsigned      mask;
+   P2Tables      T;
+};
+
+__device__ inline int class_from_flags( int f0, int f1, int f2, int f3 )
+{
+   const int cnt = f0 + f1 + f2 + f3;
+   if ( cnt == 0 )
+      return 14;
+   if ( cnt == 1 )
+      return 6 + ( f0 ? 0 : f1 ? 1 : f2 ? 2 : 3 );
+   if ( cnt == 2 )
+   {
+      if ( f0 )
+         return f1 ? 0 : ( f2 ? 1 : 2 );
+      if ( f1 )
+         return f2 ? 3 : 4;
+      return 5;
+   }
+   if ( f0 && f1 && f2 )
+      return 10;
+   if ( f0 && f1 && f3 )
+      return 11;
+   if ( f0 && f2 && f3 )
+      return 12;
+   return 13;
+}
+
+// end points of an edge DoF relative to its logical index, by orientation X, Y, Z, XY, XZ, YZ, XYZ
+__constant__ int kEdgeEnds[7][2][3] = { { { 0, 0, 0 }, { 1, 0, 0 } }, { { 0, 0, 0 }, { 0, 1, 0 } }, { { 0, 0, 0 }, { 0, 0, 1 } },
+                                        { { 1, 0, 0 }, { 0, 1, 0 } }, { { 1, 0, 0 }, { 0, 0, 1 } }, { { 0, 1, 0 }, { 0, 0, 1 } },
+                                        { { 0, 1, 0 }, { 1, 0, 1 } } };
+__constant__ int kRowDeficit[6]     = { 0, 1, 1, 2, 1, 1 }; // numCellsPerRowByType: n - deficit
+
+__device__ inline int64_t edge_block_start( int n, int kind ) { return (int64_t) ( kind - 1 ) * tet64( n ); }
+
+__global__ __launch_bounds__( kThreads ) void p2_elementwise_kernel( const P2Args A )
+{
+   const int c = blockIdx.y; // destination kind
+   const int N = A.N, n = N - 1;
+   const int W = c == 0 ? N : ( c == 7 ? n - 1 : n );
+   if ( W <= 0 )
+      return;
+   const int64_t size = tet64( W );
+   const int64_t i    = (int64_t) blockIdx.x * kThreads + threadIdx.x;
+   if ( i >= size )
+      return;
+   // decode (x, y, z) in a tetrahedral array of width W
+   int z = 0;
+   {
+      // largest z with slice_start(W, z) <= i
+      int lo = 0, hi = W - 1;
+      while ( lo < hi )
+      {
+         const int mid = ( lo + hi + 1 ) >> 1;
+         if ( tet64( W ) - tet64( W - mid ) <= i )
+            lo = mid;
+         else
+            hi = mid - 1;
+      }
+      z = lo;
+   }
+   const int j = (int) ( i - ( tet64( W ) - tet64( W - z ) ) );
+   const int y = row_of( W - z, j );
+   const int x = j - row_start( W - z, y );
+   int       cls;
+   if ( c == 0 )
+      cls = class_from_flags( z == 0, y == 0, x == 0, x + y + z == N - 1 );
+   else
+   {
+      int f0 = 1, f1 = 1, f2 = 1, f3 = 1;
+#pragma unroll
+      for ( int e = 0; e < 2; ++e )
+      {
+         const int px = x + kEdgeEnds[c - 1][e][0], py = y + kEdgeEnds[c - 1][e][1], pz = z + kEdgeEnds[c - 1][e][2];
+         f0 &= pz == 0, f1 &= py == 0, f2 &= px == 0, f3 &= px + py + pz == N - 1;
+      }
+      cls = class_from_flags( f0, f1, f2, f3 );
+   }
+   if ( !( ( A.mask >> cls ) & 1u ) )
+      return;
+   double acc = 0.0;
+   for ( int q = 0; q < A.T.nentries[c]; ++q )
+   {
+      const Entry en = A.T.entries[c][q];
+      const int   t = en.type, mx = x - en.ox, my = y - en.oy, mz = z - en.oz;
+      const int   rows = n - kRowDeficit[t];
+      if ( mx < 0 || my < 0 || mz < 0 || mx + my + mz > rows - 1 )
+         continue;
+      const double* M = A.elmat + 100 * t + 10 * en.row;
+      double        s = 0.0;
+#pragma unroll
+      for ( int k = 0; k < 10; ++k )
+      {
+         const LocalDof ld = A.T.local[t][k];
+         const int      px = mx + ld.ox, py = my + ld.oy, pz = mz + ld.oz;
+         const double   v  = ld.kind == 0 ? A.srcV[(int64_t) cell_index( N, px, py, pz )] :
+                                            A.srcE[edge_block_start( n, ld.kind ) + cell_index( ld.kind == 7 ? n - 1 : n, px, py, pz )];
+         s                 = s + M[k] * v;
+      }
+      acc += A.alpha * s;
+   }
+   double* out = c == 0 ? A.dstV + i : A.dstE + edge_block_start( n, c ) + i;
+   *out        = A.update == HYTEG_HIP_ADD ? *out + acc : acc;
+}
+
+} // namespace
+
+extern "C" {
+
+HYTEG_HIP_API size_t hyteg_hip_p2_edge_array_size( int level )
+{
+   if ( level < 0 || level > HYTEG_HIP_P2_MAX_LEVEL )
+      return 0;
+   const int64_t n = (int64_t) 1 << level;
+   return (size_t) ( 6 * tet64( n ) + tet64( n - 1 ) );
+}
+
+HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell( double*            dst_vertex,
+                                                       double*            dst_edge,
+                                                       const double*      src_vertex,
+                                                       const double*      src_edge,
+                                                       int                level,
+                                                       const double*      elmat_dev,
+                                                       double             alpha,
+                                                       int                update,
+                                                       unsigned           mask,
+                                                       hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( dst_vertex && dst_edge && src_vertex && src_edge && elmat_dev, "p2_elementwise_apply_cell: null pointer" );
+   HH_REQUIRE( level >= 0 && level <= HYTEG_HIP_P2_MAX_LEVEL, "p2_elementwise_apply_cell: level out of range [0,9]" );
+   HH_REQUIRE( dst_vertex != src_vertex && dst_edge != src_edge, "p2_elementwise_apply_cell: src and dst must not alias" );
+   HH_REQUIRE( update == HYTEG_HIP_REPLACE || update == HYTEG_HIP_ADD, "p2_elementwise_apply_cell: bad update type" );
+   if ( ( mask & HYTEG_HIP_MASK_ALL ) == 0 )
+      return HYTEG_HIP_OK;
+   P2Args A;
+   A.dstV = dst_vertex, A.dstE = dst_edge, A.srcV = src_vertex, A.srcE = src_edge, A.elmat = elmat_dev, A.alpha = alpha;
+   A.N = ( 1 << level ) + 1, A.update = update, A.mask = mask & HYTEG_HIP_MASK_ALL, A.T = tables();
+   const int64_t largest = tet64( A.N );
+   const dim3    grid( (unsigned) ( ( largest + kThreads - 1 ) / kThreads ), 8 );
+   hipLaunchKernelGGL( p2_elementwise_kernel, grid, dim3( kThreads ), 0, as_stream( stream ), A );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
+} // extern "C"

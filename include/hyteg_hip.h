@@ -400,6 +400,28 @@ HYTEG_HIP_API int hyteg_hip_p1_sor_shell_cells( int                             
                                                 int                               backwards,
                                                 hyteg_hip_stream_t                stream );
 
+/* ---- f1: P2 (vertex + edge DoFs) elementwise operator on one macro-cell ----
+ * P2ElementwiseOperator::gemv, src/hyteg/elementwiseoperators/P2ElementwiseOperator.cpp:110-223 (cell loop) with
+ * localMatrixVectorMultiply3D (:66-107).  Arrays: the vertex-DoF array of the P1 kernels and the edge-DoF array of
+ * src/hyteg/edgedofspace/EdgeDoFIndexing.hpp:920-985: blocks X, Y, Z, XY, XZ, YZ of tet(2^level) entries and XYZ of
+ * tet(2^level - 1).  elmat_dev: device array [6][10][10], the element matrices of the micro-cell types WHITE_UP, BLUE_UP,
+ * GREEN_UP, WHITE_DOWN, BLUE_DOWN, GREEN_DOWN (celldof::allCellTypes) in FEniCS ordering (constant on an affine cell;
+ * P2Form::integrateAll, kernel INPUT).  Every DoF whose point class is in `mask` (vertex DoFs as for the P1 kernels; an
+ * edge DoF belongs to the macro-primitive that contains both its end points) receives alpha * (A src) (REPLACE) or has
+ * it added (ADD); the sum over micro-cells is taken in the reference's loop order.  Levels 0..9. */
+#define HYTEG_HIP_P2_MAX_LEVEL 9
+HYTEG_HIP_API size_t hyteg_hip_p2_edge_array_size( int level );
+HYTEG_HIP_API int    hyteg_hip_p2_elementwise_apply_cell( double*            dst_vertex,
+                                                          double*            dst_edge,
+                                                          const double*      src_vertex,
+                                                          const double*      src_edge,
+                                                          int                level,
+                                                          const double*      elmat_dev,
+                                                          double             alpha,
+                                                          int                update,
+                                                          unsigned           mask,
+                                                          hyteg_hip_stream_t stream );
+
 /* a10: additive exchange of shared points (the reduce-into-owner of VertexDoFAdditivePackInfo.hpp:676-745,
  * followed by the copy back into every adjacent cell).  A group is one physical DoF; its entries are the
  * places that hold a partial value of it: (buffer index into `bases`, element offset).

@@ -888,3 +888,291 @@ HO_API void ho_sor_shell_cell( double* dst, const double* rhs, const double* res
       }
    }
 }
+
+/* =====================================================================================================================
+ * P2 on one macro-cell: vertex DoFs (the P1 array) + edge DoFs, P2ElementwiseOperator::gemv.
+ * Edge-DoF array of a macro-cell (src/hyteg/edgedofspace/EdgeDoFIndexing.hpp:920-985): seven blocks, one per orientation
+ * X, Y, Z, XY, XZ, YZ (tetrahedral arrays of width n = 2^level) and XYZ (width n - 1), in this order.
+ * ===================================================================================================================== */
+enum { EO_X = 0, EO_Y, EO_Z, EO_XY, EO_XZ, EO_YZ, EO_XYZ };
+
+HO_API int64_t ho_edge_array_size( int level )
+{
+   const int64_t n = (int64_t) 1 << level;
+   return 6 * tet_size( n ) + tet_size( n - 1 );
+}
+HO_API int64_t ho_edge_index( int level, int64_t x, int64_t y, int64_t z, int orientation )
+{
+   const int64_t n = (int64_t) 1 << level;
+   return orientation * tet_size( n ) + cell_index_w( orientation == EO_XYZ ? n - 1 : n, x, y, z );
+}
+
+/* calcEdgeDoFOrientation / calcEdgeDoFIndex, EdgeDoFIndexing.hpp:89-165: v0, v1 logical micro-vertex indices */
+static int edge_between( const int64_t* v0, const int64_t* v1, int64_t* e )
+{
+   const int64_t  d[3] = { v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2] };
+   const int64_t* lo;
+   int            o;
+   if ( d[1] == 0 && d[2] == 0 )
+      o = EO_X;
+   else if ( d[0] == 0 && d[2] == 0 )
+      o = EO_Y;
+   else if ( d[0] == 0 && d[1] == 0 )
+      o = EO_Z;
+   else if ( d[2] == 0 )
+      o = EO_XY;
+   else if ( d[1] == 0 )
+      o = EO_XZ;
+   else if ( d[0] == 0 )
+      o = EO_YZ;
+   else
+      o = EO_XYZ;
+   switch ( o )
+   {
+   case EO_X:
+      lo = v0[0] < v1[0] ? v0 : v1;
+      e[0] = lo[0], e[1] = lo[1], e[2] = lo[2];
+      break;
+   case EO_Y:
+      lo = v0[1] < v1[1] ? v0 : v1;
+      e[0] = lo[0], e[1] = lo[1], e[2] = lo[2];
+      break;
+   case EO_Z:
+      lo = v0[2] < v1[2] ? v0 : v1;
+      e[0] = lo[0], e[1] = lo[1], e[2] = lo[2];
+      break;
+   case EO_XY:
+      lo = v0[0] < v1[0] ? v0 : v1;
+      e[0] = lo[0], e[1] = lo[1] - 1, e[2] = lo[2];
+      break;
+   case EO_XZ:
+      lo = v0[0] < v1[0] ? v0 : v1;
+      e[0] = lo[0], e[1] = lo[1], e[2] = lo[2] - 1;
+      break;
+   case EO_YZ:
+      lo = v0[1] < v1[1] ? v0 : v1;
+      e[0] = lo[0], e[1] = lo[1], e[2] = lo[2] - 1;
+      break;
+   default:
+      lo = v0[0] < v1[0] ? v0 : v1;
+      e[0] = lo[0], e[1] = lo[1] - 1, e[2] = lo[2];
+      break;
+   }
+   return o;
+}
+
+/* celldof::macrocell::getMicroVerticesFromMicroCell, src/hyteg/volumedofspace/CellDoFIndexing.hpp:155-198;
+ * cell types in the order of celldof::allCellTypes (:55-60): WHITE_UP, BLUE_UP, GREEN_UP, WHITE_DOWN, BLUE_DOWN, GREEN_DOWN */
+static const int MICRO_CELL_VERTS[6][4][3] = {
+    { { 0, 0, 0 }, { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } }, { { 1, 0, 0 }, { 1, 1, 0 }, { 0, 1, 0 }, { 1, 0, 1 } },
+    { { 1, 0, 0 }, { 0, 1, 0 }, { 1, 0, 1 }, { 0, 0, 1 } }, { { 1, 1, 0 }, { 1, 1, 1 }, { 0, 1, 1 }, { 1, 0, 1 } },
+    { { 1, 0, 1 }, { 0, 1, 1 }, { 0, 0, 1 }, { 0, 1, 0 } }, { { 0, 1, 0 }, { 1, 1, 0 }, { 1, 0, 1 }, { 0, 1, 1 } } };
+/* numCellsPerRowByType, CellDoFIndexing.hpp:64-83: n, n-1, n-1, n-2, n-1, n-1 */
+static const int MICRO_CELL_ROW_DEFICIT[6] = { 0, 1, 1, 2, 1, 1 };
+/* FEniCS ordering of the six edges of a micro-cell, EdgeDoFIndexing.hpp:1370-1375 */
+static const int FENICS_EDGE_PAIRS[6][2] = { { 2, 3 }, { 1, 3 }, { 1, 2 }, { 0, 3 }, { 0, 2 }, { 0, 1 } };
+
+/* the ten array indices of micro-cell (type, mx, my, mz): 0..3 into the vertex array, 4..9 into the edge array */
+HO_API void ho_p2_micro_cell_dofs( int level, int type, int64_t mx, int64_t my, int64_t mz, int64_t* idx10 )
+{
+   const int64_t N = ho_width( level );
+   int64_t       v[4][3];
+   for ( int k = 0; k < 4; ++k )
+   {
+      v[k][0]  = mx + MICRO_CELL_VERTS[type][k][0];
+      v[k][1]  = my + MICRO_CELL_VERTS[type][k][1];
+      v[k][2]  = mz + MICRO_CELL_VERTS[type][k][2];
+      idx10[k] = cell_index_w( N, v[k][0], v[k][1], v[k][2] );
+   }
+   for ( int k = 0; k < 6; ++k )
+   {
+      int64_t   e[3];
+      const int o   = edge_between( v[FENICS_EDGE_PAIRS[k][0]], v[FENICS_EDGE_PAIRS[k][1]], e );
+      idx10[4 + k] = ho_edge_index( level, e[0], e[1], e[2], o );
+   }
+}
+
+/* P2 diffusion element matrix of a tetrahedron in FEniCS ordering (4 vertices, then the edges (2,3)(1,3)(1,2)(0,3)(0,2)(0,1)),
+ * closed form: phi_a = l_a(2 l_a - 1), phi_ab = 4 l_a l_b, int l_a l_b = V(1 + delta_ab)/20, int l_a = V/4.
+ * The reference uses the generated p2_tet_diffusion.h (forms/form_fenics_base/P2FenicsForm.cpp:160-175); pinned against it. */
+HO_API void ho_p2_tet_diffusion( double* A, const double* coords )
+{
+   double J[3][3], Ji[3][3], g[4][3];
+   for ( int r = 0; r < 3; ++r )
+      for ( int k = 0; k < 3; ++k )
+         J[r][k] = coords[3 * ( k + 1 ) + r] - coords[r];
+   const double det = J[0][0] * ( J[1][1] * J[2][2] - J[1][2] * J[2][1] ) - J[0][1] * ( J[1][0] * J[2][2] - J[1][2] * J[2][0] ) +
+                      J[0][2] * ( J[1][0] * J[2][1] - J[1][1] * J[2][0] );
+   Ji[0][0] = ( J[1][1] * J[2][2] - J[1][2] * J[2][1] ) / det;
+   Ji[0][1] = ( J[0][2] * J[2][1] - J[0][1] * J[2][2] ) / det;
+   Ji[0][2] = ( J[0][1] * J[1][2] - J[0][2] * J[1][1] ) / det;
+   Ji[1][0] = ( J[1][2] * J[2][0] - J[1][0] * J[2][2] ) / det;
+   Ji[1][1] = ( J[0][0] * J[2][2] - J[0][2] * J[2][0] ) / det;
+   Ji[1][2] = ( J[0][2] * J[1][0] - J[0][0] * J[1][2] ) / det;
+   Ji[2][0] = ( J[1][0] * J[2][1] - J[1][1] * J[2][0] ) / det;
+   Ji[2][1] = ( J[0][1] * J[2][0] - J[0][0] * J[2][1] ) / det;
+   Ji[2][2] = ( J[0][0] * J[1][1] - J[0][1] * J[1][0] ) / det;
+   for ( int r = 0; r < 3; ++r )
+   {
+      g[1][r] = Ji[0][r], g[2][r] = Ji[1][r], g[3][r] = Ji[2][r];
+      g[0][r] = -( Ji[0][r] + Ji[1][r] + Ji[2][r] );
+   }
+   const double V = fabs( det ) / 6.0;
+   double       G[4][4]; /* grad l_a . grad l_b */
+   for ( int a = 0; a < 4; ++a )
+      for ( int b = 0; b < 4; ++b )
+         G[a][b] = g[a][0] * g[b][0] + g[a][1] * g[b][1] + g[a][2] * g[b][2];
+   /* grad phi_i = sum_a c_i[a][.] : every basis gradient is a combination  sum_{a,b} C_i[a][b] l_b grad l_a  + D_i[a] grad l_a */
+   double C[10][4][4], D[10][4];
+   memset( C, 0, sizeof( C ) );
+   memset( D, 0, sizeof( D ) );
+   for ( int a = 0; a < 4; ++a )
+   {
+      C[a][a][a] = 4.0; /* grad( l_a (2 l_a - 1) ) = (4 l_a - 1) grad l_a */
+      D[a][a]    = -1.0;
+   }
+   for ( int k = 0; k < 6; ++k )
+   {
+      const int a = FENICS_EDGE_PAIRS[k][0], b = FENICS_EDGE_PAIRS[k][1];
+      C[4 + k][a][b] = 4.0; /* grad( 4 l_a l_b ) = 4 l_b grad l_a + 4 l_a grad l_b */
+      C[4 + k][b][a] = 4.0;
+   }
+   for ( int i = 0; i < 10; ++i )
+      for ( int j = 0; j < 10; ++j )
+      {
+         double s = 0.0;
+         for ( int a = 0; a < 4; ++a )
+            for ( int b = 0; b < 4; ++b )
+            {
+               /* ( sum_p C_i[a][p] l_p + D_i[a] ) ( sum_q C_j[b][q] l_q + D_j[b] ) G[a][b] integrated */
+               double t = D[i][a] * D[j][b] * V;
+               for ( int p = 0; p < 4; ++p )
+               {
+                  t += C[i][a][p] * D[j][b] * V / 4.0 + D[i][a] * C[j][b][p] * V / 4.0;
+                  for ( int q = 0; q < 4; ++q )
+                     t += C[i][a][p] * C[j][b][q] * V * ( p == q ? 2.0 : 1.0 ) / 20.0;
+               }
+               s += t * G[a][b];
+            }
+         A[10 * i + j] = s;
+      }
+}
+
+/* element matrices of the six micro-cell types of an affine macro-cell (assembleLocalElementMatrix3D,
+ * elementwiseoperators/P2ElementwiseOperator.cpp + coordinateFromIndex): elmat[6][100] */
+HO_API void ho_p2_cell_element_matrices( double* elmat, const double* cell_coords12, int level )
+{
+   for ( int t = 0; t < 6; ++t )
+   {
+      double c[12];
+      for ( int k = 0; k < 4; ++k )
+         ho_coordinate_from_index( c + 3 * k, cell_coords12, level, MICRO_CELL_VERTS[t][k][0], MICRO_CELL_VERTS[t][k][1],
+                                   MICRO_CELL_VERTS[t][k][2] );
+      ho_p2_tet_diffusion( elmat + 100 * t, c );
+   }
+}
+
+/* point class (slot 0..13, 14 inner) of the edge DoF with logical index (x,y,z) and orientation o: the macro-primitive that
+ * contains both end points */
+static const int EDGE_END_OFFSETS[7][2][3] = { { { 0, 0, 0 }, { 1, 0, 0 } }, { { 0, 0, 0 }, { 0, 1, 0 } }, { { 0, 0, 0 }, { 0, 0, 1 } },
+                                               { { 1, 0, 0 }, { 0, 1, 0 } }, { { 1, 0, 0 }, { 0, 0, 1 } }, { { 0, 1, 0 }, { 0, 0, 1 } },
+                                               { { 0, 1, 0 }, { 1, 0, 1 } } };
+static int slot_from_face_flags( int f0, int f1, int f2, int f3 )
+{
+   const int cnt = f0 + f1 + f2 + f3;
+   if ( cnt == 0 )
+      return 14;
+   if ( cnt == 1 )
+      return 6 + ( f0 ? 0 : f1 ? 1 : f2 ? 2 : 3 );
+   if ( cnt == 2 )
+   {
+      if ( f0 )
+         return f1 ? 0 : ( f2 ? 1 : 2 );
+      if ( f1 )
+         return f2 ? 3 : 4;
+      return 5;
+   }
+   if ( f0 && f1 && f2 )
+      return 10;
+   if ( f0 && f1 && f3 )
+      return 11;
+   if ( f0 && f2 && f3 )
+      return 12;
+   return 13;
+}
+HO_API int ho_edge_dof_class( int level, int64_t x, int64_t y, int64_t z, int o )
+{
+   const int64_t N = ho_width( level );
+   int           f[4] = { 1, 1, 1, 1 };
+   for ( int e = 0; e < 2; ++e )
+   {
+      const int64_t px = x + EDGE_END_OFFSETS[o][e][0], py = y + EDGE_END_OFFSETS[o][e][1], pz = z + EDGE_END_OFFSETS[o][e][2];
+      f[0] &= pz == 0, f[1] &= py == 0, f[2] &= px == 0, f[3] &= px + py + pz == N - 1;
+   }
+   return slot_from_face_flags( f[0], f[1], f[2], f[3] );
+}
+
+/* P2ElementwiseOperator::gemv on one macro-cell (P2ElementwiseOperator.cpp:110-223 with localMatrixVectorMultiply3D :66-107):
+ * every micro-cell, type by type in iterator order, adds alpha * elMat * (its ten source values) to its ten destination DoFs.
+ * Restated for the cell-centric storage: the scatter runs into zeroed temporaries (the reference zeroes dst where flagged and on
+ * the whole halo first); then every DoF whose point class is in `mask` receives its sum (update 0) or has it added (update 1). */
+HO_API void ho_p2_elementwise_apply_cell( double* dstV, double* dstE, const double* srcV, const double* srcE, int level,
+                                          const double* elmat, double alpha, int update, unsigned mask )
+{
+   const int64_t N = ho_width( level ), n = N - 1;
+   const int64_t nv = tet_size( N ), ne = ho_edge_array_size( level );
+   double*       tv = (double*) calloc( (size_t) nv, sizeof( double ) );
+   double*       te = (double*) calloc( (size_t) ( ne > 0 ? ne : 1 ), sizeof( double ) );
+   for ( int t = 0; t < 6; ++t )
+   {
+      const int64_t rows = n - MICRO_CELL_ROW_DEFICIT[t];
+      const double* M    = elmat + 100 * t;
+      for ( int64_t z = 0; z < rows; ++z )
+         for ( int64_t y = 0; y < rows - z; ++y )
+            for ( int64_t x = 0; x < rows - z - y; ++x )
+            {
+               int64_t idx[10];
+               double  old[10];
+               ho_p2_micro_cell_dofs( level, t, x, y, z, idx );
+               for ( int k = 0; k < 4; ++k )
+                  old[k] = srcV[idx[k]];
+               for ( int k = 4; k < 10; ++k )
+                  old[k] = srcE[idx[k]];
+               for ( int k = 0; k < 10; ++k )
+               {
+                  double s = 0.0;
+                  for ( int j = 0; j < 10; ++j )
+                     s = s + M[10 * k + j] * old[j];
+                  if ( k < 4 )
+                     tv[idx[k]] += alpha * s;
+                  else
+                     te[idx[k]] += alpha * s;
+               }
+            }
+   }
+   for ( int64_t z = 0; z < N; ++z )
+      for ( int64_t y = 0; y < N - z; ++y )
+         for ( int64_t x = 0; x < N - z - y; ++x )
+         {
+            const int slot = prim_slot( N, x, y, z );
+            if ( !point_selected( mask, slot ) )
+               continue;
+            const int64_t i = cell_index_w( N, x, y, z );
+            dstV[i]         = update ? dstV[i] + tv[i] : tv[i];
+         }
+   for ( int o = 0; o < 7; ++o )
+   {
+      const int64_t W = o == EO_XYZ ? n - 1 : n;
+      for ( int64_t z = 0; z < W; ++z )
+         for ( int64_t y = 0; y < W - z; ++y )
+            for ( int64_t x = 0; x < W - z - y; ++x )
+            {
+               if ( !( ( mask >> ho_edge_dof_class( level, x, y, z, o ) ) & 1u ) )
+                  continue;
+               const int64_t i = ho_edge_index( level, x, y, z, o );
+               dstE[i]         = update ? dstE[i] + te[i] : te[i];
+            }
+   }
+   free( tv );
+   free( te );
+}

@@ -72,6 +72,13 @@ def _bind(lib):
         "ho_copy_face_to_cell": (None, [_P, _P, i, i, i, i]),
         "ho_copy_cell_to_face": (None, [_P, _P, i, i, i, i, i]),
         "ho_apply_face3d": (None, [_P, _P, i, i, C.POINTER(C.c_int), _P, i]),
+        "ho_edge_array_size": (ll, [i]),
+        "ho_edge_index": (ll, [i, ll, ll, ll, i]),
+        "ho_p2_micro_cell_dofs": (None, [i, i, ll, ll, ll, C.POINTER(ll)]),
+        "ho_p2_tet_diffusion": (None, [_P, _P]),
+        "ho_p2_cell_element_matrices": (None, [_P, _P, i]),
+        "ho_edge_dof_class": (i, [i, ll, ll, ll, i]),
+        "ho_p2_elementwise_apply_cell": (None, [_P, _P, _P, _P, i, _P, d, i, C.c_uint]),
         "ho_sor_shell_cell": (None, [_P, _P, _P, i, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), _P, _P, d, C.c_uint, i]),
     }
     for name, (res, args) in sig.items():
@@ -306,6 +313,70 @@ def apply_face3d(dst, src, level, vmaps, ws, update=REPLACE):
     return dst
 
 
+# ---- P2 (vertex + edge DoFs) on one macro-cell ----
+EDGE_ORIENTATIONS = ("X", "Y", "Z", "XY", "XZ", "YZ", "XYZ")
+
+
+def edge_array_size(level): return int(lib().ho_edge_array_size(level))
+def edge_index(level, x, y, z, o): return int(lib().ho_edge_index(level, x, y, z, o))
+def edge_dof_class(level, x, y, z, o): return int(lib().ho_edge_dof_class(level, x, y, z, o))
+
+
+def edge_coords(level):
+    """(edge array size, 4) int array: x, y, z, orientation of every edge DoF in array order"""
+    n = 1 << level
+    out = []
+    for o in range(7):
+        w = n - 1 if o == 6 else n
+        for z in range(w):
+            for y in range(w - z):
+                for x in range(w - z - y):
+                    out.append((x, y, z, o))
+    return np.array(out, dtype=np.int64).reshape(-1, 4)
+
+
+def edge_classes(level):
+    return np.array([edge_dof_class(level, int(x), int(y), int(z), int(o)) for x, y, z, o in edge_coords(level)], dtype=np.int64)
+
+
+def p2_micro_cell_dofs(level, cell_type, mx, my, mz):
+    out = (C.c_int64 * 10)()
+    lib().ho_p2_micro_cell_dofs(level, cell_type, mx, my, mz, out)
+    return list(out)
+
+
+def p2_tet_diffusion(coords):
+    c = np.ascontiguousarray(coords, dtype=np.float64).reshape(12)
+    A = np.empty(100)
+    lib().ho_p2_tet_diffusion(_p(A), _p(c))
+    return A.reshape(10, 10)
+
+
+def p2_cell_element_matrices(cell_vertex_coords, level):
+    c = np.ascontiguousarray(cell_vertex_coords, dtype=np.float64).reshape(12)
+    A = np.empty(600)
+    lib().ho_p2_cell_element_matrices(_p(A), _p(c), level)
+    return A.reshape(6, 10, 10)
+
+
+def p2_elementwise_apply_cell(dst_v, dst_e, src_v, src_e, level, elmat, alpha=1.0, update=REPLACE, mask=0x7FFF):
+    em = np.ascontiguousarray(elmat, dtype=np.float64).reshape(600)
+    lib().ho_p2_elementwise_apply_cell(_p(dst_v), _p(dst_e), _p(src_v), _p(src_e), level, _p(em), float(alpha), update, mask)
+    return dst_v, dst_e
+
+
+def edge_midpoints(cell_vertex_coords, level):
+    """physical coordinates of the edge DoFs (edge midpoints) in array order"""
+    cc = np.ascontiguousarray(cell_vertex_coords, dtype=np.float64).reshape(4, 3)
+    step = 1.0 / float(1 << level)
+    ends = np.array([[[0, 0, 0], [1, 0, 0]], [[0, 0, 0], [0, 1, 0]], [[0, 0, 0], [0, 0, 1]], [[1, 0, 0], [0, 1, 0]],
+                     [[1, 0, 0], [0, 0, 1]], [[0, 1, 0], [0, 0, 1]], [[0, 1, 0], [1, 0, 1]]], dtype=np.float64)
+    ec = edge_coords(level)
+    mid = ec[:, :3].astype(np.float64) + 0.5 * (ends[ec[:, 3], 0] + ends[ec[:, 3], 1])
+    xs, ys, zs = (cc[1] - cc[0]) * step, (cc[2] - cc[0]) * step, (cc[3] - cc[0]) * step
+    return cc[0][None, :] + mid[:, 0:1] * xs[None, :] + mid[:, 1:2] * ys[None, :] + mid[:, 2:3] * zs[None, :]
+
+
 def sor_shell_cell(dst, rhs, rest, level, edge_verts, edge_w, face_verts, face_w, vertex_w, relax, mask, backwards=False):
     """vertices -> edges -> faces (reverse if backwards) of one cell; see ho_sor_shell_cell"""
     ev = np.ascontiguousarray(edge_verts, dtype=np.int32).reshape(6, 2)
@@ -353,6 +424,8 @@ def ref_fenics():
         if not so.exists():
             return None
     l = C.CDLL(str(so))
-    for n in ("ref_p1_tet_diffusion", "ref_p1_tet_mass"):
+    for n in ("ref_p1_tet_diffusion", "ref_p1_tet_mass", "ref_p2_tet_diffusion"):
+        if not hasattr(l, n):
+            continue
         getattr(l, n).restype, getattr(l, n).argtypes = None, [_P, _P]
     return l

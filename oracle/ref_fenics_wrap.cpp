@@ -10,6 +10,7 @@
 // is therefore NOT built (see DESIGN.md "Oracle").
 #include "hyteg/forms/form_fenics_generated/p1_tet_diffusion.h"
 #include "hyteg/forms/form_fenics_generated/p1_tet_mass.h"
+#include "hyteg/forms/form_fenics_generated/p2_tet_diffusion.h"
 
 extern "C" {
 
@@ -17,6 +18,14 @@ extern "C" {
 __attribute__( ( visibility( "default" ) ) ) void ref_p1_tet_diffusion( double* A, const double* coords )
 {
    p1_tet_diffusion_cell_integral_0_otherwise gen;
+   gen.tabulate_tensor( A, nullptr, coords, 0 );
+}
+
+// A: 100 doubles (10 x 10, FEniCS ordering), as P2FenicsForm::computeLocalStiffnessMatrix calls it
+// (src/hyteg/forms/form_fenics_base/P2FenicsForm.cpp:160-175)
+__attribute__( ( visibility( "default" ) ) ) void ref_p2_tet_diffusion( double* A, const double* coords )
+{
+   p2_tet_diffusion_cell_integral_0_otherwise gen;
    gen.tabulate_tensor( A, nullptr, coords, 0 );
 }
 

@@ -1,0 +1,81 @@
+"""GPU parity of the P2 elementwise operator on one macro-cell against the CPU restatement of
+P2ElementwiseOperator::gemv (oracle/p1_oracle.c ho_p2_elementwise_apply_cell), through the C-ABI."""
+import numpy as np
+import pytest
+
+from conftest import OCT_TET, REF_TET, SKEW_TET
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    from hyteg_amd import capi
+    from oracle import p1_oracle as po
+
+    assert torch.cuda.is_available()
+    capi.lib()
+    return torch, capi, po
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda")
+
+
+@pytest.mark.parametrize("level", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tet", [REF_TET, SKEW_TET])
+def test_p2_elementwise_apply_matches_the_oracle(env, level, tet):
+    torch, capi, po = env
+    nv, ne = po.cell_size(level), po.edge_array_size(level)
+    assert ne == capi.p2_edge_array_size(level)
+    em = po.p2_cell_element_matrices(np.asarray(tet, dtype=np.float64).reshape(12), level)
+    rng = np.random.default_rng(level)
+    sv, se, dv0, de0 = rng.standard_normal(nv), rng.standard_normal(ne), rng.standard_normal(nv), rng.standard_normal(ne)
+    dem = _dev(torch, em.reshape(-1))
+    for mask, update, alpha in ((0x7FFF, 0, 1.0), (1 << 14, 0, 1.0), (0x7FFF, 1, -0.5), (0x4000 | 0x2A5, 0, 2.0), (0x3FFF, 1, 1.0)):
+        wv, we = po.p2_elementwise_apply_cell(dv0.copy(), de0.copy(), sv, se, level, em, alpha, update, mask)
+        dsv, dse, ddv, dde = _dev(torch, sv), _dev(torch, se), _dev(torch, dv0), _dev(torch, de0)
+        capi.p2_elementwise_apply_cell(ddv.data_ptr(), dde.data_ptr(), dsv.data_ptr(), dse.data_ptr(), level, dem.data_ptr(), alpha, update, mask)
+        torch.cuda.synchronize()
+        gv, ge = ddv.cpu().numpy(), dde.cpu().numpy()
+        scale = max(np.abs(wv).max(), np.abs(we).max(), 1.0)
+        assert np.abs(gv - wv).max() <= 1e-13 * scale and np.abs(ge - we).max() <= 1e-13 * scale, (level, hex(mask), update)
+        # unselected DoFs are untouched
+        sel_v = ((mask >> po.slot_of_points(level)) & 1).astype(bool)
+        sel_e = ((mask >> po.edge_classes(level)) & 1).astype(bool)
+        assert np.array_equal(gv[~sel_v], dv0[~sel_v]) and np.array_equal(ge[~sel_e], de0[~sel_e])
+
+
+def test_p2_laplace_known_answers_level_6(env):
+    """energy of x^2 on the reference tetrahedron is int |grad x^2|^2 = 1/15; harmonic quadratics have zero inner residual;
+    the operator is symmetric (the properties the reference's P2 convergence tests rest on)"""
+    torch, capi, po = env
+    import hostutil as hu
+
+    level = 6
+    co = np.asarray(REF_TET, dtype=np.float64).reshape(12)
+    em = _dev(torch, po.p2_cell_element_matrices(co, level).reshape(-1))
+    pv, pe = hu.cell_points(co, level), po.edge_midpoints(co, level)
+
+    def apply(uv, ue):
+        duv, due = _dev(torch, uv), _dev(torch, ue)
+        dv, de = torch.zeros_like(duv), torch.zeros_like(due)
+        capi.p2_elementwise_apply_cell(dv.data_ptr(), de.data_ptr(), duv.data_ptr(), due.data_ptr(), level, em.data_ptr())
+        torch.cuda.synchronize()
+        return dv.cpu().numpy(), de.cpu().numpy()
+
+    uv, ue = pv[:, 0] ** 2, pe[:, 0] ** 2
+    av, ae = apply(uv, ue)
+    assert abs(uv @ av + ue @ ae - 1.0 / 15.0) < 1e-12
+    hv, he = pv[:, 0] ** 2 - pv[:, 1] ** 2 + 3 * pv[:, 2], pe[:, 0] ** 2 - pe[:, 1] ** 2 + 3 * pe[:, 2]
+    rv, re = apply(hv, he)
+    inner_v, inner_e = po.slot_of_points(level) == 14, po.edge_classes(level) == 14
+    assert np.abs(rv[inner_v]).max() < 1e-13 and np.abs(re[inner_e]).max() < 1e-13
+    rng = np.random.default_rng(1)
+    xv, xe, yv, ye = rng.standard_normal(len(pv)), rng.standard_normal(len(pe)), rng.standard_normal(len(pv)), rng.standard_normal(len(pe))
+    axv, axe = apply(xv, xe)
+    ayv, aye = apply(yv, ye)
+    lhs, rhs = yv @ axv + ye @ axe, xv @ ayv + xe @ aye
+    assert abs(lhs - rhs) < 1e-11 * abs(lhs)
