@@ -86,6 +86,21 @@ def main():
     timeit("SOR shell backward", lambda k: capi.p1_sor_shell_cell(p(B, k), p(A, k), p(Cc, k), L, T["edge_verts"], T["edge_w"], T["face_verts"],
                                                                   T["face_w"], T["vertex_w"], 1.0, 0x3FFF, True, sh),
            40 * shell_pts, shell_pts, r=max(3, reps // 10))
+    # P2 elementwise Laplace apply on one macro-cell, level 7 as in BASELINE config 4
+    from oracle import p1_oracle as po  # element matrices are kernel INPUT; the oracle's form is used to make them here
+
+    L2 = min(L, 7)
+    nv2, ne2 = capi.cell_size(L2), capi.p2_edge_array_size(L2)
+    em = torch.from_numpy(po.p2_cell_element_matrices(np.array([0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1.0]), L2).reshape(-1)).to("cuda")
+    nb2 = max(2, int(1.5 * 256 * 2**20) // (2 * (nv2 + ne2) * 8) + 1)
+    SV = [torch.rand(nv2, dtype=torch.float64, device="cuda") for _ in range(nb2)]
+    SE = [torch.rand(ne2, dtype=torch.float64, device="cuda") for _ in range(nb2)]
+    DV = [torch.zeros(nv2, dtype=torch.float64, device="cuda") for _ in range(nb2)]
+    DE = [torch.zeros(ne2, dtype=torch.float64, device="cuda") for _ in range(nb2)]
+    timeit(f"P2 elementwise Laplace apply, level {L2} ({nv2 + ne2} DoFs)",
+           lambda k: capi.p2_elementwise_apply_cell(DV[k % nb2].data_ptr(), DE[k % nb2].data_ptr(), SV[k % nb2].data_ptr(),
+                                                    SE[k % nb2].data_ptr(), L2, em.data_ptr(), 1.0, 0, 0x7FFF, sh),
+           16 * (nv2 + ne2), nv2 + ne2, r=max(3, reps // 10))
     # V-cycles through the host layer
     for mesh, lo, hi, smoother, name in (("tet_1el", 2, L, host.JACOBI, "Jacobi(2/3)"), ("tet_1el", 2, min(L, 7), host.GAUSS_SEIDEL, "GS"),
                                           ("regular_octahedron_8el", 2, min(L, 6), host.JACOBI, "Jacobi(2/3)"),
