@@ -238,9 +238,187 @@ __global__ __launch_bounds__( kThreads ) void p2_elementwise_kernel( const P2Arg
    *out        = A.update == HYTEG_HIP_ADD ? *out + acc : acc;
 }
 
+// ---- vector operations and dot product on the edge-DoF array (EdgeDoFFunction::assign / add / dotLocal on a macro-cell,
+// src/hyteg/edgedofspace/EdgeDoFFunction.cpp; generic loops in EdgeDoFMacroCell.hpp), masked by point class ----
+__device__ inline bool edge_entry( int n, int64_t i, int& x, int& y, int& z, int& o )
+{
+   const int64_t blk = tet64( n );
+   o                 = (int) ( i / blk );
+   if ( o > 6 )
+      return false;
+   const int     W = o == 6 ? n - 1 : n;
+   const int64_t r = i - (int64_t) o * blk;
+   if ( W <= 0 || r >= tet64( W ) )
+      return false;
+   int lo = 0, hi = W - 1;
+   while ( lo < hi )
+   {
+      const int mid = ( lo + hi + 1 ) >> 1;
+      if ( tet64( W ) - tet64( W - mid ) <= r )
+         lo = mid;
+      else
+         hi = mid - 1;
+   }
+   z           = lo;
+   const int j = (int) ( r - ( tet64( W ) - tet64( W - z ) ) );
+   y           = row_of( W - z, j );
+   x           = j - row_start( W - z, y );
+   return true;
+}
+__device__ inline int edge_class( int N, int x, int y, int z, int o )
+{
+   int f0 = 1, f1 = 1, f2 = 1, f3 = 1;
+#pragma unroll
+   for ( int e = 0; e < 2; ++e )
+   {
+      const int px = x + kEdgeEnds[o][e][0], py = y + kEdgeEnds[o][e][1], pz = z + kEdgeEnds[o][e][2];
+      f0 &= pz == 0, f1 &= py == 0, f2 &= px == 0, f3 &= px + py + pz == N - 1;
+   }
+   return class_from_flags( f0, f1, f2, f3 );
+}
+
+struct EdgeVecArgs
+{
+   double*       dst;
+   const double* src[HYTEG_HIP_MAX_SRCS];
+   double        c[HYTEG_HIP_MAX_SRCS];
+   int64_t       size;
+   int           N, nsrc, op; // 0 assign, 1 add, 2 mult, 3 set constant c[0]
+   unsigned      mask;
+};
+__global__ __launch_bounds__( kThreads ) void p2_edge_vector_kernel( const EdgeVecArgs A )
+{
+   const int64_t i = (int64_t) blockIdx.x * kThreads + threadIdx.x;
+   int           x, y, z, o;
+   if ( i >= A.size || !edge_entry( A.N - 1, i, x, y, z, o ) || !( ( A.mask >> edge_class( A.N, x, y, z, o ) ) & 1u ) )
+      return;
+   double tmp;
+   if ( A.op == 3 )
+      tmp = A.c[0];
+   else if ( A.op == 2 )
+   {
+      tmp = A.src[0][i];
+      for ( int k = 1; k < A.nsrc; ++k )
+         tmp *= A.src[k][i];
+   }
+   else
+   {
+      tmp = A.c[0] * A.src[0][i];
+      for ( int k = 1; k < A.nsrc; ++k )
+         tmp += A.c[k] * A.src[k][i];
+      if ( A.op == 1 )
+         tmp = A.dst[i] + tmp;
+   }
+   A.dst[i] = tmp;
+}
+
+constexpr int kEdgeDotBlocks = 1024;
+__global__ __launch_bounds__( kThreads ) void p2_edge_dot_kernel( const double* __restrict__ a, const double* __restrict__ b, int64_t size, int N,
+                                                                   unsigned mask, double* partial )
+{
+   __shared__ double sh[kThreads / 64];
+   double            acc = 0.0;
+   // fixed entry -> thread assignment: deterministic
+   for ( int64_t i = (int64_t) blockIdx.x * kThreads + threadIdx.x; i < size; i += (int64_t) gridDim.x * kThreads )
+   {
+      int x, y, z, o;
+      if ( edge_entry( N - 1, i, x, y, z, o ) && ( ( mask >> edge_class( N, x, y, z, o ) ) & 1u ) )
+         acc = fma( a[i], b[i], acc );
+   }
+#pragma unroll
+   for ( int off = 32; off > 0; off >>= 1 )
+      acc += __shfl_down( acc, off, 64 );
+   if ( ( threadIdx.x & 63 ) == 0 )
+      sh[threadIdx.x >> 6] = acc;
+   __syncthreads();
+   if ( threadIdx.x == 0 )
+   {
+      double r = 0.0;
+      for ( int k = 0; k < kThreads / 64; ++k )
+         r += sh[k];
+      partial[blockIdx.x] = r;
+   }
+}
+__global__ __launch_bounds__( kThreads ) void p2_sum_partials_kernel( const double* partial, int n, double* result )
+{
+   __shared__ double sh[kThreads / 64];
+   double            acc = 0.0;
+   for ( int k = threadIdx.x; k < n; k += kThreads )
+      acc += partial[k];
+#pragma unroll
+   for ( int off = 32; off > 0; off >>= 1 )
+      acc += __shfl_down( acc, off, 64 );
+   if ( ( threadIdx.x & 63 ) == 0 )
+      sh[threadIdx.x >> 6] = acc;
+   __syncthreads();
+   if ( threadIdx.x == 0 )
+   {
+      double r = 0.0;
+      for ( int k = 0; k < kThreads / 64; ++k )
+         r += sh[k];
+      *result = r;
+   }
+}
+
 } // namespace
 
 extern "C" {
+
+HYTEG_HIP_API int hyteg_hip_p2_edge_vector_cell_masked( int                  op,
+                                                        double*              dst,
+                                                        int                  nsrc,
+                                                        const double* const* srcs,
+                                                        const double*        scalars,
+                                                        int                  level,
+                                                        unsigned             mask,
+                                                        hyteg_hip_stream_t   stream )
+{
+   HH_REQUIRE( dst && op >= 0 && op <= 3, "p2_edge_vector_cell_masked: null dst or bad op" );
+   HH_REQUIRE( level >= 0 && level <= HYTEG_HIP_P2_MAX_LEVEL, "p2_edge_vector_cell_masked: level out of range [0,9]" );
+   HH_REQUIRE( op == 3 ? scalars != nullptr : ( nsrc >= 1 && nsrc <= HYTEG_HIP_MAX_SRCS && srcs ), "p2_edge_vector_cell_masked: bad sources" );
+   HH_REQUIRE( op == 2 || scalars, "p2_edge_vector_cell_masked: null scalars" );
+   if ( ( mask & HYTEG_HIP_MASK_ALL ) == 0 )
+      return HYTEG_HIP_OK;
+   EdgeVecArgs A{};
+   A.dst = dst, A.N = ( 1 << level ) + 1, A.nsrc = nsrc, A.op = op, A.mask = mask & HYTEG_HIP_MASK_ALL;
+   A.size = (int64_t) hyteg_hip_p2_edge_array_size( level );
+   if ( op == 3 )
+      A.c[0] = scalars[0];
+   else
+      for ( int k = 0; k < nsrc; ++k )
+      {
+         HH_REQUIRE( srcs[k], "p2_edge_vector_cell_masked: null source" );
+         A.src[k] = srcs[k];
+         A.c[k]   = scalars ? scalars[k] : 1.0;
+      }
+   if ( A.size == 0 )
+      return HYTEG_HIP_OK;
+   hipLaunchKernelGGL( p2_edge_vector_kernel, dim3( (unsigned) ( ( A.size + kThreads - 1 ) / kThreads ) ), dim3( kThreads ), 0,
+                       as_stream( stream ), A );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_p2_edge_dot_cell_masked( const double*      a,
+                                                     const double*      b,
+                                                     int                level,
+                                                     unsigned           mask,
+                                                     double*            result_dev,
+                                                     void*              workspace_dev,
+                                                     hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( a && b && result_dev && workspace_dev, "p2_edge_dot_cell_masked: null pointer" );
+   HH_REQUIRE( level >= 0 && level <= HYTEG_HIP_P2_MAX_LEVEL, "p2_edge_dot_cell_masked: level out of range [0,9]" );
+   const int64_t size   = (int64_t) hyteg_hip_p2_edge_array_size( level );
+   int64_t       blocks = ( size + kThreads - 1 ) / kThreads;
+   blocks               = blocks < 1 ? 1 : ( blocks > kEdgeDotBlocks ? kEdgeDotBlocks : blocks );
+   double* partial      = static_cast< double* >( workspace_dev );
+   hipLaunchKernelGGL( p2_edge_dot_kernel, dim3( (unsigned) blocks ), dim3( kThreads ), 0, as_stream( stream ), a, b, size, ( 1 << level ) + 1,
+                       mask & HYTEG_HIP_MASK_ALL, partial );
+   hipLaunchKernelGGL( p2_sum_partials_kernel, dim3( 1 ), dim3( kThreads ), 0, as_stream( stream ), partial, (int) blocks, result_dev );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
 
 HYTEG_HIP_API size_t hyteg_hip_p2_edge_array_size( int level )
 {

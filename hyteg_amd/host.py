@@ -63,6 +63,20 @@ SIGNATURES = {
     "hyteg_host_cg_create": (_i, [_vp, _i, _i, _i, _d, C.POINTER(_vp)]),
     "hyteg_host_solver_solve": (_i, [_vp, _vp, _vp, _vp, _i]),
     "hyteg_host_solver_destroy": (_i, [_vp]),
+    "hyteg_host_p2function_create": (_i, [_vp, C.c_char_p, _i, _i, C.POINTER(_vp)]),
+    "hyteg_host_p2function_destroy": (_i, [_vp]),
+    "hyteg_host_p2function_pointers": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp)]),
+    "hyteg_host_p2function_upload": (_i, [_vp, _i, _vp, _vp]),
+    "hyteg_host_p2function_download": (_i, [_vp, _i, _vp, _vp]),
+    "hyteg_host_p2function_interpolate_constant": (_i, [_vp, _d, _i, _i]),
+    "hyteg_host_p2function_assign": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(_vp), _i, _i]),
+    "hyteg_host_p2function_add": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(_vp), _i, _i]),
+    "hyteg_host_p2function_dot": (_i, [_vp, _vp, _i, _i, C.POINTER(_d)]),
+    "hyteg_host_p2operator_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "hyteg_host_p2operator_destroy": (_i, [_vp]),
+    "hyteg_host_p2operator_element_matrices": (_i, [_vp, _i, _vp]),
+    "hyteg_host_p2operator_apply": (_i, [_vp, _vp, _vp, _i, _i, _i]),
+    "hyteg_host_p2_cg_solve": (_i, [_vp, _vp, _vp, _vp, _i, _i, _d, C.POINTER(_i)]),
 }
 
 
@@ -331,4 +345,83 @@ class Solver:
     def close(self):
         if self.h:
             lib().hyteg_host_solver_destroy(self.h)
+            self.h = None
+
+
+# ---- P2 on a single macro-cell (first version) ----
+class P2Function:
+    """hyteg::P2Function<double>: vertex DoFs (the P1 cell array) + edge DoFs (EdgeDoFIndexing.hpp layout)"""
+
+    def __init__(self, storage: Storage, name: str, min_level: int, max_level: int):
+        self.storage = storage
+        h = _vp()
+        _ck(lib().hyteg_host_p2function_create(storage.h, name.encode(), min_level, max_level, C.byref(h)), "P2Function")
+        self.h = h
+
+    def sizes(self, level):
+        from . import capi
+
+        return cell_size(level), capi.p2_edge_array_size(level)
+
+    def upload(self, level, vertex, edge):
+        v = np.ascontiguousarray(vertex, dtype=np.float64)
+        e = np.ascontiguousarray(edge, dtype=np.float64)
+        assert (v.size, e.size) == self.sizes(level)
+        _ck(lib().hyteg_host_p2function_upload(self.h, level, v.ctypes.data, e.ctypes.data), "P2Function.upload")
+
+    def download(self, level):
+        nv, ne = self.sizes(level)
+        v, e = np.empty(nv), np.empty(max(ne, 1))
+        _ck(lib().hyteg_host_p2function_download(self.h, level, v.ctypes.data, e.ctypes.data), "P2Function.download")
+        return v, e[:ne]
+
+    def interpolate(self, value, level, flag=All):
+        _ck(lib().hyteg_host_p2function_interpolate_constant(self.h, float(value), level, flag), "P2Function.interpolate")
+
+    def _vec(self, fn, scalars, funcs, level, flag):
+        n = len(funcs)
+        sc = (_d * n)(*[float(v) for v in scalars])
+        hs = (_vp * n)(*[f.h for f in funcs])
+        _ck(fn(self.h, n, sc, hs, level, flag), "P2Function vector op")
+
+    def assign(self, scalars, funcs, level, flag=All):
+        self._vec(lib().hyteg_host_p2function_assign, scalars, funcs, level, flag)
+
+    def add(self, scalars, funcs, level, flag=All):
+        self._vec(lib().hyteg_host_p2function_add, scalars, funcs, level, flag)
+
+    def dot(self, other, level, flag=All):
+        r = _d()
+        _ck(lib().hyteg_host_p2function_dot(self.h, other.h, level, flag, C.byref(r)), "P2Function.dot")
+        return r.value
+
+    def close(self):
+        if self.h:
+            lib().hyteg_host_p2function_destroy(self.h)
+            self.h = None
+
+
+class P2ElementwiseLaplaceOperator:
+    def __init__(self, storage: Storage, min_level: int, max_level: int):
+        self.storage = storage
+        h = _vp()
+        _ck(lib().hyteg_host_p2operator_create(storage.h, min_level, max_level, C.byref(h)), "P2ElementwiseLaplaceOperator")
+        self.h = h
+
+    def element_matrices(self, level):
+        out = np.empty(600)
+        _ck(lib().hyteg_host_p2operator_element_matrices(self.h, level, out.ctypes.data), "element_matrices")
+        return out.reshape(6, 10, 10)
+
+    def apply(self, src: P2Function, dst: P2Function, level, flag, update=Replace):
+        _ck(lib().hyteg_host_p2operator_apply(self.h, src.h, dst.h, level, flag, update), "P2 apply")
+
+    def cg_solve(self, x: P2Function, b: P2Function, level, max_iter=1000, tol=1e-14):
+        it = _i()
+        _ck(lib().hyteg_host_p2_cg_solve(self.storage.h, self.h, x.h, b.h, level, max_iter, float(tol), C.byref(it)), "P2 CG")
+        return it.value
+
+    def close(self):
+        if self.h:
+            lib().hyteg_host_p2operator_destroy(self.h)
             self.h = None

@@ -1111,6 +1111,172 @@ class P1Function
 };
 
 // =====================================================================================================
+// P2Function< double >  ( src/hyteg/p2functionspace/P2Function.hpp ): a VertexDoF function plus an EdgeDoF function.
+// First version: storages with ONE macro-cell (the shared edge DoFs of several cells need their own
+// exchange plans, which do not exist yet).  Edge-DoF arrays: layout of edgedofspace/EdgeDoFIndexing.hpp:920-985.
+// =====================================================================================================
+template < typename ValueType >
+class P2Function
+{
+ public:
+   using valueType = ValueType;
+   P2Function( const std::string& name, const std::shared_ptr< PrimitiveStorage >& storage, uint_t minLevel, uint_t maxLevel )
+   : name_( name )
+   , storage_( storage )
+   , minLevel_( minLevel )
+   , maxLevel_( maxLevel )
+   , vertexDoFFunction_( name + "_VertexDoF", storage, minLevel, maxLevel )
+   {
+      if ( storage->getCells().size() != 1 || storage->numRanks() != 1 )
+         throw std::runtime_error( "P2Function: only storages with a single macro-cell are supported in this version" );
+      if ( maxLevel > HYTEG_HIP_P2_MAX_LEVEL )
+         throw std::runtime_error( "P2Function: level out of range" );
+      for ( uint_t l = minLevel; l <= maxLevel; ++l )
+      {
+         const size_t bytes = std::max< size_t >( 1, hyteg_hip_p2_edge_array_size( (int) l ) ) * sizeof( double );
+         void*        q     = nullptr;
+         hipCheck( hyteg_hip_malloc( &q, bytes ), "P2Function: malloc" );
+         hipCheck( hyteg_hip_memset_zero( q, bytes, storage->stream() ), "P2Function: memset" );
+         edge_.push_back( static_cast< double* >( q ) );
+      }
+   }
+   ~P2Function()
+   {
+      for ( double* q : edge_ )
+         hyteg_hip_free( q );
+   }
+   P2Function( const P2Function& )            = delete;
+   P2Function& operator=( const P2Function& ) = delete;
+
+   const P1Function< ValueType >&      getVertexDoFFunction() const { return vertexDoFFunction_; }
+   std::shared_ptr< PrimitiveStorage > getStorage() const { return storage_; }
+   // device pointer of the edge-DoF array of local cell c (= 0)
+   double* getEdgeCellPointer( uint_t c, uint_t level ) const
+   {
+      if ( c != 0 || level < minLevel_ || level > maxLevel_ )
+         throw std::runtime_error( "P2Function '" + name_ + "': bad cell or level" );
+      return edge_[level - minLevel_];
+   }
+   uint_t getNumberOfEdgeDoFs( uint_t level ) const { return hyteg_hip_p2_edge_array_size( (int) level ); }
+
+   void interpolate( ValueType constant, uint_t level, DoFType flag = All ) const
+   {
+      vertexDoFFunction_.interpolate( constant, level, flag );
+      hipCheck( hyteg_hip_p2_edge_vector_cell_masked( 3, getEdgeCellPointer( 0, level ), 0, nullptr, &constant, (int) level, mask( flag ),
+                                                      storage_->stream() ),
+                "P2Function::interpolate" );
+   }
+   // expression evaluated at the micro-vertices and at the edge midpoints (EdgeDoFFunction::interpolate)
+   void interpolate( const std::function< ValueType( const Point3D& ) >& expr, uint_t level, DoFType flag = All ) const
+   {
+      vertexDoFFunction_.interpolate( expr, level, flag );
+      static const int ends[7][2][3] = { { { 0, 0, 0 }, { 1, 0, 0 } }, { { 0, 0, 0 }, { 0, 1, 0 } }, { { 0, 0, 0 }, { 0, 0, 1 } },
+                                         { { 1, 0, 0 }, { 0, 1, 0 } }, { { 1, 0, 0 }, { 0, 0, 1 } }, { { 0, 1, 0 }, { 0, 0, 1 } },
+                                         { { 0, 1, 0 }, { 1, 0, 1 } } };
+      const MacroCell&      cell = storage_->getLocalCell( 0 );
+      const int64_t         n    = int64_t( 1 ) << level;
+      const double          step = 1.0 / double( n );
+      std::vector< double > host;
+      host.reserve( getNumberOfEdgeDoFs( level ) );
+      for ( int o = 0; o < 7; ++o )
+      {
+         const int64_t W = o == 6 ? n - 1 : n;
+         for ( int64_t z = 0; z < W; ++z )
+            for ( int64_t y = 0; y < W - z; ++y )
+               for ( int64_t x = 0; x < W - z - y; ++x )
+               {
+                  const double mx = double( x ) + 0.5 * ( ends[o][0][0] + ends[o][1][0] ), my = double( y ) + 0.5 * ( ends[o][0][1] + ends[o][1][1] ),
+                               mz = double( z ) + 0.5 * ( ends[o][0][2] + ends[o][1][2] );
+                  Point3D      q;
+                  for ( int r = 0; r < 3; ++r )
+                     q[r] = cell.coords[0][r] + ( cell.coords[1][r] - cell.coords[0][r] ) * step * mx +
+                            ( cell.coords[2][r] - cell.coords[0][r] ) * step * my + ( cell.coords[3][r] - cell.coords[0][r] ) * step * mz;
+                  host.push_back( expr( q ) );
+               }
+      }
+      double* tmp = storage_->acquireScratch( std::max< size_t >( 1, host.size() ) );
+      hipCheck( hyteg_hip_upload( tmp, host.data(), host.size() * sizeof( double ), storage_->stream() ), "P2Function::interpolate: upload" );
+      const double* srcs[1] = { tmp };
+      const double  one[1]  = { 1.0 };
+      hipCheck( hyteg_hip_p2_edge_vector_cell_masked( 0, getEdgeCellPointer( 0, level ), 1, srcs, one, (int) level, mask( flag ), storage_->stream() ),
+                "P2Function::interpolate: assign" );
+      hipCheck( hyteg_hip_stream_synchronize( storage_->stream() ), "P2Function::interpolate: sync" );
+      storage_->releaseScratch( std::max< size_t >( 1, host.size() ), tmp );
+   }
+   void setToZero( uint_t level ) const { interpolate( ValueType( 0 ), level, All ); }
+
+   void assign( const std::vector< ValueType >&                                           scalars,
+                const std::vector< std::reference_wrapper< const P2Function< ValueType > > >& functions,
+                uint_t                                                                    level,
+                DoFType                                                                   flag = All ) const
+   {
+      vectorOp( 0, scalars, functions, level, flag );
+   }
+   void add( const std::vector< ValueType >&                                           scalars,
+             const std::vector< std::reference_wrapper< const P2Function< ValueType > > >& functions,
+             uint_t                                                                    level,
+             DoFType                                                                   flag = All ) const
+   {
+      vectorOp( 1, scalars, functions, level, flag );
+   }
+   ValueType dotLocal( const P2Function< ValueType >& rhs, uint_t level, DoFType flag = All ) const
+   {
+      double v = vertexDoFFunction_.dotLocal( rhs.vertexDoFFunction_, level, flag );
+      hipCheck( hyteg_hip_p2_edge_dot_cell_masked( getEdgeCellPointer( 0, level ), rhs.getEdgeCellPointer( 0, level ), (int) level, mask( flag ),
+                                                   storage_->dotResult(), storage_->dotWorkspace(), storage_->stream() ),
+                "P2Function::dotLocal" );
+      double e = 0.0;
+      hipCheck( hyteg_hip_download( &e, storage_->dotResult(), sizeof( double ), storage_->stream() ), "P2Function::dotLocal: download" );
+      return v + e;
+   }
+   ValueType dotGlobal( const P2Function< ValueType >& rhs, uint_t level, DoFType flag = All ) const { return dotLocal( rhs, level, flag ); }
+
+   void copyEdgeToHost( uint_t level, double* host ) const
+   {
+      hipCheck( hyteg_hip_download( host, getEdgeCellPointer( 0, level ), getNumberOfEdgeDoFs( level ) * sizeof( double ), storage_->stream() ),
+                "P2Function::copyEdgeToHost" );
+   }
+   void copyEdgeFromHost( uint_t level, const double* host ) const
+   {
+      hipCheck( hyteg_hip_upload( getEdgeCellPointer( 0, level ), host, getNumberOfEdgeDoFs( level ) * sizeof( double ), storage_->stream() ),
+                "P2Function::copyEdgeFromHost" );
+      hipCheck( hyteg_hip_stream_synchronize( storage_->stream() ), "P2Function::copyEdgeFromHost: sync" );
+   }
+
+ private:
+   unsigned mask( DoFType flag ) const { return storage_->maskFor( storage_->getLocalCell( 0 ), flag ); }
+   void     vectorOp( int                                                                       op,
+                      const std::vector< ValueType >&                                           scalars,
+                      const std::vector< std::reference_wrapper< const P2Function< ValueType > > >& functions,
+                      uint_t                                                                    level,
+                      DoFType                                                                   flag ) const
+   {
+      if ( functions.empty() || functions.size() > HYTEG_HIP_MAX_SRCS || scalars.size() != functions.size() )
+         throw std::runtime_error( "P2Function::assign/add: bad number of functions or scalars" );
+      std::vector< std::reference_wrapper< const P1Function< ValueType > > > vs;
+      const double*                                                          es[HYTEG_HIP_MAX_SRCS];
+      for ( uint_t k = 0; k < functions.size(); ++k )
+      {
+         vs.push_back( functions[k].get().vertexDoFFunction_ );
+         es[k] = functions[k].get().getEdgeCellPointer( 0, level );
+      }
+      if ( op == 0 )
+         vertexDoFFunction_.assign( scalars, vs, level, flag );
+      else
+         vertexDoFFunction_.add( scalars, vs, level, flag );
+      hipCheck( hyteg_hip_p2_edge_vector_cell_masked( op, getEdgeCellPointer( 0, level ), (int) functions.size(), es, scalars.data(), (int) level,
+                                                      mask( flag ), storage_->stream() ),
+                "P2Function vector op" );
+   }
+
+   std::string                         name_;
+   std::shared_ptr< PrimitiveStorage > storage_;
+   uint_t                              minLevel_, maxLevel_;
+   P1Function< ValueType >             vertexDoFFunction_;
+   std::vector< double* >              edge_;
+};
+
+// =====================================================================================================
 // Forms: first row of the P1 element matrix of a tetrahedron (kernel INPUT, setup only).
 // P1FenicsForm< ..., p1_tet_diffusion_cell_integral_0_otherwise >  src/hyteg/forms/form_fenics_base/P1FenicsForm.hpp:96-124
 // -> src/hyteg/forms/form_fenics_generated/p1_tet_diffusion.h:4113-4240: K_0j = |det J|/6 grad(lambda_0).grad(lambda_j);
@@ -1748,6 +1914,141 @@ using P1ConstantLaplaceOperator = P1ConstantOperator< forms::P1LaplaceForm >; //
 using P1ConstantMassOperator    = P1ConstantOperator< forms::P1MassForm >;
 
 // =====================================================================================================
+// P2ElementwiseOperator< P2Form >  ( src/hyteg/elementwiseoperators/P2ElementwiseOperator.hpp:454, .cpp:110-223 ), affine cells:
+// the six element matrices per (cell, level) are computed once (kernel INPUT) and kept on the device.
+// =====================================================================================================
+namespace forms {
+// P2 diffusion element matrix in FEniCS ordering (vertices 0-3, edges (2,3) (1,3) (1,2) (0,3) (0,2) (0,1)); what
+// P2FenicsForm< ..., p2_tet_diffusion_cell_integral_0_otherwise >::integrateAll returns (form_fenics_base/P2FenicsForm.cpp:160-175).
+// Closed form: phi_a = l_a (2 l_a - 1), phi_ab = 4 l_a l_b; int l_a = V/4, int l_a l_b = V (1 + delta_ab) / 20.
+struct P2LaplaceForm
+{
+   static void integrateAll( const std::array< Point3D, 4 >& c, double elMat[100] )
+   {
+      double J[3][3];
+      for ( int r = 0; r < 3; ++r )
+         for ( int k = 0; k < 3; ++k )
+            J[r][k] = c[k + 1][r] - c[0][r];
+      const double det = det3( J );
+      double       Ji[3][3];
+      Ji[0][0] = ( J[1][1] * J[2][2] - J[1][2] * J[2][1] ) / det;
+      Ji[0][1] = ( J[0][2] * J[2][1] - J[0][1] * J[2][2] ) / det;
+      Ji[0][2] = ( J[0][1] * J[1][2] - J[0][2] * J[1][1] ) / det;
+      Ji[1][0] = ( J[1][2] * J[2][0] - J[1][0] * J[2][2] ) / det;
+      Ji[1][1] = ( J[0][0] * J[2][2] - J[0][2] * J[2][0] ) / det;
+      Ji[1][2] = ( J[0][2] * J[1][0] - J[0][0] * J[1][2] ) / det;
+      Ji[2][0] = ( J[1][0] * J[2][1] - J[1][1] * J[2][0] ) / det;
+      Ji[2][1] = ( J[0][1] * J[2][0] - J[0][0] * J[2][1] ) / det;
+      Ji[2][2] = ( J[0][0] * J[1][1] - J[0][1] * J[1][0] ) / det;
+      double g[4][3];
+      for ( int r = 0; r < 3; ++r )
+      {
+         g[1][r] = Ji[0][r], g[2][r] = Ji[1][r], g[3][r] = Ji[2][r];
+         g[0][r] = -( Ji[0][r] + Ji[1][r] + Ji[2][r] );
+      }
+      const double V = std::fabs( det ) / 6.0;
+      double       G[4][4];
+      for ( int a = 0; a < 4; ++a )
+         for ( int b = 0; b < 4; ++b )
+            G[a][b] = g[a][0] * g[b][0] + g[a][1] * g[b][1] + g[a][2] * g[b][2];
+      // grad phi_i = sum_a ( sum_p C[i][a][p] l_p + D[i][a] ) grad l_a
+      static const int pairs[6][2] = { { 2, 3 }, { 1, 3 }, { 1, 2 }, { 0, 3 }, { 0, 2 }, { 0, 1 } };
+      double           C[10][4][4] = {}, D[10][4] = {};
+      for ( int a = 0; a < 4; ++a )
+         C[a][a][a] = 4.0, D[a][a] = -1.0;
+      for ( int k = 0; k < 6; ++k )
+         C[4 + k][pairs[k][0]][pairs[k][1]] = 4.0, C[4 + k][pairs[k][1]][pairs[k][0]] = 4.0;
+      for ( int i = 0; i < 10; ++i )
+         for ( int j = 0; j < 10; ++j )
+         {
+            double s = 0.0;
+            for ( int a = 0; a < 4; ++a )
+               for ( int b = 0; b < 4; ++b )
+               {
+                  double t = D[i][a] * D[j][b] * V;
+                  for ( int p = 0; p < 4; ++p )
+                  {
+                     t += ( C[i][a][p] * D[j][b] + D[i][a] * C[j][b][p] ) * V / 4.0;
+                     for ( int q = 0; q < 4; ++q )
+                        t += C[i][a][p] * C[j][b][q] * V * ( p == q ? 2.0 : 1.0 ) / 20.0;
+                  }
+                  s += t * G[a][b];
+               }
+            elMat[10 * i + j] = s;
+         }
+   }
+};
+} // namespace forms
+
+template < class P2Form >
+class P2ElementwiseOperator
+{
+ public:
+   using srcType = P2Function< double >;
+   using dstType = P2Function< double >;
+   P2ElementwiseOperator( const std::shared_ptr< PrimitiveStorage >& storage, uint_t minLevel, uint_t maxLevel )
+   : storage_( storage )
+   , minLevel_( minLevel )
+   , maxLevel_( maxLevel )
+   {
+      if ( storage->getCells().size() != 1 || storage->numRanks() != 1 )
+         throw std::runtime_error( "P2ElementwiseOperator: only storages with a single macro-cell are supported in this version" );
+      // micro-cell vertex offsets of the six cell types, celldof::macrocell::getMicroVerticesFromMicroCell (CellDoFIndexing.hpp:155-198)
+      static const int verts[6][4][3] = {
+          { { 0, 0, 0 }, { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } }, { { 1, 0, 0 }, { 1, 1, 0 }, { 0, 1, 0 }, { 1, 0, 1 } },
+          { { 1, 0, 0 }, { 0, 1, 0 }, { 1, 0, 1 }, { 0, 0, 1 } }, { { 1, 1, 0 }, { 1, 1, 1 }, { 0, 1, 1 }, { 1, 0, 1 } },
+          { { 1, 0, 1 }, { 0, 1, 1 }, { 0, 0, 1 }, { 0, 1, 0 } }, { { 0, 1, 0 }, { 1, 1, 0 }, { 1, 0, 1 }, { 0, 1, 1 } } };
+      const MacroCell& cell = storage->getLocalCell( 0 );
+      for ( uint_t l = minLevel; l <= maxLevel; ++l )
+      {
+         const double          step = 1.0 / double( int64_t( 1 ) << l );
+         std::vector< double > h( 600 );
+         for ( int t = 0; t < 6; ++t )
+         {
+            std::array< Point3D, 4 > c;
+            for ( int k = 0; k < 4; ++k )
+               for ( int r = 0; r < 3; ++r )
+                  c[k][r] = cell.coords[0][r] + ( cell.coords[1][r] - cell.coords[0][r] ) * step * verts[t][k][0] +
+                            ( cell.coords[2][r] - cell.coords[0][r] ) * step * verts[t][k][1] +
+                            ( cell.coords[3][r] - cell.coords[0][r] ) * step * verts[t][k][2];
+            P2Form::integrateAll( c, h.data() + 100 * t );
+         }
+         elementMatrices_[l] = storage->uploadTable( h );
+         hostMatrices_[l]    = h;
+      }
+   }
+   std::shared_ptr< PrimitiveStorage > getStorage() const { return storage_; }
+   const std::vector< double >&        getElementMatrices( uint_t level ) const { return hostMatrices_.at( level ); }
+
+   // Operator::apply = gemv( 1, src, updateType == Replace ? 0 : 1, dst ), P2ElementwiseOperator.hpp:60-75
+   void apply( const P2Function< double >& src, const P2Function< double >& dst, uint_t level, DoFType flag, UpdateType updateType = Replace ) const
+   {
+      gemv( 1.0, src, updateType == Replace ? 0.0 : 1.0, dst, level, flag );
+   }
+   void gemv( double alpha, const P2Function< double >& src, double beta, const P2Function< double >& dst, uint_t level, DoFType flag ) const
+   {
+      if ( &src == &dst )
+         throw std::runtime_error( "P2ElementwiseOperator::gemv: src and dst must differ" );
+      if ( beta != 0.0 && beta != 1.0 )
+         dst.assign( { beta }, { dst }, level, flag );
+      const MacroCell& cell = storage_->getLocalCell( 0 );
+      hipCheck( hyteg_hip_p2_elementwise_apply_cell( dst.getVertexDoFFunction().getCellPointer( 0, level ), dst.getEdgeCellPointer( 0, level ),
+                                                     src.getVertexDoFFunction().getCellPointer( 0, level ), src.getEdgeCellPointer( 0, level ),
+                                                     (int) level, elementMatrices_.at( level ), alpha,
+                                                     beta == 0.0 ? HYTEG_HIP_REPLACE : HYTEG_HIP_ADD, storage_->maskFor( cell, flag ),
+                                                     storage_->stream() ),
+                "P2ElementwiseOperator::gemv" );
+   }
+
+ private:
+   std::shared_ptr< PrimitiveStorage >          storage_;
+   uint_t                                       minLevel_, maxLevel_;
+   std::map< uint_t, const double* >            elementMatrices_;
+   std::map< uint_t, std::vector< double > >    hostMatrices_;
+};
+using P2ElementwiseLaplaceOperator = P2ElementwiseOperator< forms::P2LaplaceForm >; // P2ElementwiseOperator.hpp:454
+
+// =====================================================================================================
 // Grid transfer ( src/hyteg/gridtransferoperators/P1toP1LinearRestriction.cpp:169-346, P1toP1LinearProlongation.cpp:194-410 )
 // =====================================================================================================
 class P1toP1LinearRestriction
@@ -1836,7 +2137,7 @@ template < class OperatorType >
 class Solver
 {
  public:
-   using FunctionType = P1Function< double >;
+   using FunctionType = typename OperatorType::srcType;
    virtual ~Solver()  = default;
    virtual void solve( const OperatorType& A, const FunctionType& x, const FunctionType& b, uint_t level ) = 0;
 };
@@ -1895,6 +2196,7 @@ template < class OperatorType >
 class CGSolver : public Solver< OperatorType >
 {
  public:
+   using FunctionType = typename OperatorType::srcType;
    CGSolver( const std::shared_ptr< PrimitiveStorage >& storage, uint_t minLevel, uint_t maxLevel, uint_t maxIter = 1000,
              double relativeTolerance = 1e-16, double absoluteTolerance = 1e-16 )
    : p_( "p", storage, minLevel, maxLevel )
@@ -1906,7 +2208,7 @@ class CGSolver : public Solver< OperatorType >
    , relTol_( relativeTolerance )
    , absTol_( absoluteTolerance )
    {}
-   void solve( const OperatorType& A, const P1Function< double >& x, const P1Function< double >& b, uint_t level ) override
+   void solve( const OperatorType& A, const FunctionType& x, const FunctionType& b, uint_t level ) override
    {
       p_.setToZero( level );
       z_.setToZero( level );
@@ -1944,7 +2246,7 @@ class CGSolver : public Solver< OperatorType >
    uint_t getIterations() const { return iterations_; }
 
  private:
-   P1Function< double > p_, z_, ap_, r_;
+   FunctionType         p_, z_, ap_, r_;
    DoFType              flag_;
    uint_t               maxIter_;
    double               relTol_, absTol_;

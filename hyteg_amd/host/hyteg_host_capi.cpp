@@ -344,4 +344,103 @@ HYTEG_HOST_API int hyteg_host_solver_destroy( hh_solver_t solver )
 {
    return guarded( [&] { delete static_cast< SolverH* >( solver ); } );
 }
+
+/* ---- P2 (single macro-cell) ---- */
+namespace {
+struct P2FunctionH
+{
+   std::shared_ptr< P2Function< double > > p;
+};
+struct P2OperatorH
+{
+   std::shared_ptr< P2ElementwiseLaplaceOperator > p;
+};
+P2Function< double >& F2( hh_p2function_t f ) { return *static_cast< P2FunctionH* >( f )->p; }
+std::vector< std::reference_wrapper< const P2Function< double > > > refs2( int n, const hh_p2function_t* fs )
+{
+   std::vector< std::reference_wrapper< const P2Function< double > > > r;
+   for ( int i = 0; i < n; ++i )
+      r.push_back( std::cref( F2( fs[i] ) ) );
+   return r;
+}
+} // namespace
+
+HYTEG_HOST_API int hyteg_host_p2function_create( hh_storage_t s, const char* name, int minL, int maxL, hh_p2function_t* out )
+{
+   return guarded( [&] {
+      *out = new P2FunctionH{ std::make_shared< P2Function< double > >( name, static_cast< StorageH* >( s )->p, (uint_t) minL, (uint_t) maxL ) };
+   } );
+}
+HYTEG_HOST_API int hyteg_host_p2function_destroy( hh_p2function_t f )
+{
+   return guarded( [&] { delete static_cast< P2FunctionH* >( f ); } );
+}
+HYTEG_HOST_API int hyteg_host_p2function_pointers( hh_p2function_t f, int level, double** vertex_dev, double** edge_dev )
+{
+   return guarded( [&] {
+      *vertex_dev = F2( f ).getVertexDoFFunction().getCellPointer( 0, (uint_t) level );
+      *edge_dev   = F2( f ).getEdgeCellPointer( 0, (uint_t) level );
+   } );
+}
+HYTEG_HOST_API int hyteg_host_p2function_upload( hh_p2function_t f, int level, const double* vertex_host, const double* edge_host )
+{
+   return guarded( [&] {
+      F2( f ).getVertexDoFFunction().copyCellFromHost( 0, (uint_t) level, vertex_host );
+      F2( f ).copyEdgeFromHost( (uint_t) level, edge_host );
+   } );
+}
+HYTEG_HOST_API int hyteg_host_p2function_download( hh_p2function_t f, int level, double* vertex_host, double* edge_host )
+{
+   return guarded( [&] {
+      F2( f ).getVertexDoFFunction().copyCellToHost( 0, (uint_t) level, vertex_host );
+      F2( f ).copyEdgeToHost( (uint_t) level, edge_host );
+   } );
+}
+HYTEG_HOST_API int hyteg_host_p2function_interpolate_constant( hh_p2function_t f, double value, int level, int flag )
+{
+   return guarded( [&] { F2( f ).interpolate( value, (uint_t) level, DoFType( flag ) ); } );
+}
+HYTEG_HOST_API int hyteg_host_p2function_assign( hh_p2function_t dst, int n, const double* scalars, const hh_p2function_t* srcs, int level, int flag )
+{
+   return guarded( [&] { F2( dst ).assign( std::vector< double >( scalars, scalars + n ), refs2( n, srcs ), (uint_t) level, DoFType( flag ) ); } );
+}
+HYTEG_HOST_API int hyteg_host_p2function_add( hh_p2function_t dst, int n, const double* scalars, const hh_p2function_t* srcs, int level, int flag )
+{
+   return guarded( [&] { F2( dst ).add( std::vector< double >( scalars, scalars + n ), refs2( n, srcs ), (uint_t) level, DoFType( flag ) ); } );
+}
+HYTEG_HOST_API int hyteg_host_p2function_dot( hh_p2function_t a, hh_p2function_t b, int level, int flag, double* result )
+{
+   return guarded( [&] { *result = F2( a ).dotGlobal( F2( b ), (uint_t) level, DoFType( flag ) ); } );
+}
+HYTEG_HOST_API int hyteg_host_p2operator_create( hh_storage_t s, int minL, int maxL, hh_p2operator_t* out )
+{
+   return guarded( [&] {
+      *out = new P2OperatorH{ std::make_shared< P2ElementwiseLaplaceOperator >( static_cast< StorageH* >( s )->p, (uint_t) minL, (uint_t) maxL ) };
+   } );
+}
+HYTEG_HOST_API int hyteg_host_p2operator_destroy( hh_p2operator_t op )
+{
+   return guarded( [&] { delete static_cast< P2OperatorH* >( op ); } );
+}
+HYTEG_HOST_API int hyteg_host_p2operator_element_matrices( hh_p2operator_t op, int level, double* out600 )
+{
+   return guarded( [&] {
+      const auto& h = static_cast< P2OperatorH* >( op )->p->getElementMatrices( (uint_t) level );
+      std::copy( h.begin(), h.end(), out600 );
+   } );
+}
+HYTEG_HOST_API int hyteg_host_p2operator_apply( hh_p2operator_t op, hh_p2function_t src, hh_p2function_t dst, int level, int flag, int update )
+{
+   return guarded( [&] { static_cast< P2OperatorH* >( op )->p->apply( F2( src ), F2( dst ), (uint_t) level, DoFType( flag ), UpdateType( update ) ); } );
+}
+HYTEG_HOST_API int hyteg_host_p2_cg_solve( hh_storage_t s, hh_p2operator_t op, hh_p2function_t x, hh_p2function_t b, int level, int maxIter,
+                                           double tol, int* iterations )
+{
+   return guarded( [&] {
+      CGSolver< P2ElementwiseLaplaceOperator > cg( static_cast< StorageH* >( s )->p, (uint_t) level, (uint_t) level, (uint_t) maxIter, tol, tol );
+      cg.solve( *static_cast< P2OperatorH* >( op )->p, F2( x ), F2( b ), (uint_t) level );
+      if ( iterations )
+         *iterations = (int) cg.getIterations();
+   } );
+}
 }

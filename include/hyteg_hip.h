@@ -411,6 +411,24 @@ HYTEG_HIP_API int hyteg_hip_p1_sor_shell_cells( int                             
  * it added (ADD); the sum over micro-cells is taken in the reference's loop order.  Levels 0..9. */
 #define HYTEG_HIP_P2_MAX_LEVEL 9
 HYTEG_HIP_API size_t hyteg_hip_p2_edge_array_size( int level );
+/* EdgeDoFFunction assign / add / multElementwise / interpolate( constant ) and dotLocal on the edge-DoF array of one
+ * macro-cell (src/hyteg/edgedofspace/EdgeDoFFunction.cpp), restricted to the DoFs whose point class is in `mask`;
+ * op and workspace as for hyteg_hip_p1_vector_cell_masked / hyteg_hip_p1_dot_cell_masked */
+HYTEG_HIP_API int hyteg_hip_p2_edge_vector_cell_masked( int                  op,
+                                                        double*              dst,
+                                                        int                  nsrc,
+                                                        const double* const* srcs,
+                                                        const double*        scalars,
+                                                        int                  level,
+                                                        unsigned             mask,
+                                                        hyteg_hip_stream_t   stream );
+HYTEG_HIP_API int hyteg_hip_p2_edge_dot_cell_masked( const double*      a,
+                                                     const double*      b,
+                                                     int                level,
+                                                     unsigned           mask,
+                                                     double*            result_dev,
+                                                     void*              workspace_dev,
+                                                     hyteg_hip_stream_t stream );
 HYTEG_HIP_API int    hyteg_hip_p2_elementwise_apply_cell( double*            dst_vertex,
                                                           double*            dst_edge,
                                                           const double*      src_vertex,

@@ -79,3 +79,43 @@ def test_p2_laplace_known_answers_level_6(env):
     ayv, aye = apply(yv, ye)
     lhs, rhs = yv @ axv + ye @ axe, xv @ ayv + xe @ aye
     assert abs(lhs - rhs) < 1e-11 * abs(lhs)
+
+
+def test_p2_host_layer_solves_a_dirichlet_problem_exactly(env):
+    """P2Function / P2ElementwiseLaplaceOperator / CGSolver through the host layer: a quadratic harmonic function is in the
+    P2 space, so with its values as Dirichlet data the discrete solution IS the function (the statement the reference's
+    P2ElementwiseCGConvergenceTest makes for the discretisation error, here with error zero up to the solver tolerance)."""
+    torch, capi, po = env
+    import hostutil as hu
+    from hyteg_amd import host
+
+    host.lib()
+    level = 3
+    st = host.Storage.from_gmsh(hu.MESHES / "tet_1el.msh")
+    gid, co, nnc = st.local_cell(0)
+    A = host.P2ElementwiseLaplaceOperator(st, level, level)
+    em = A.element_matrices(level)
+    want = po.p2_cell_element_matrices(np.asarray(co).reshape(12), level)
+    assert np.abs(em - want).max() <= 1e-14 * np.abs(want).max()
+
+    fn = lambda p: p[:, 0] ** 2 - 0.5 * p[:, 1] ** 2 - 0.5 * p[:, 2] ** 2 + p[:, 0] * p[:, 2] + 1.0  # noqa: E731  (harmonic)
+    ev, ee = fn(hu.cell_points(co, level)), fn(po.edge_midpoints(co, level))
+    inner_v, inner_e = po.slot_of_points(level) == 14, po.edge_classes(level) == 14
+    x, b, r, exact = (host.P2Function(st, n, level, level) for n in ("x", "b", "r", "exact"))
+    exact.upload(level, ev, ee)
+    x.upload(level, np.where(inner_v, 0.0, ev), np.where(inner_e, 0.0, ee))  # Dirichlet data, zero initial guess inside
+    # apply on the exact solution: zero residual on inner DoFs, nothing written elsewhere
+    r.interpolate(3.0, level)
+    A.apply(exact, r, level, host.Inner)
+    rv, re = r.download(level)
+    assert np.abs(rv[inner_v]).max() < 1e-12 and np.abs(re[inner_e]).max() < 1e-12
+    assert np.all(rv[~inner_v] == 3.0) and np.all(re[~inner_e] == 3.0)
+    its = A.cg_solve(x, b, level, 500, 1e-13)
+    xv, xe = x.download(level)
+    assert 0 < its < 500
+    assert np.abs(xv - ev).max() < 1e-10 and np.abs(xe - ee).max() < 1e-10
+    # dot product over both parts, flag-filtered
+    d = exact.dot(exact, level, host.Inner)
+    assert abs(d - ((ev[inner_v] ** 2).sum() + (ee[inner_e] ** 2).sum())) < 1e-11 * d
+    for o in (x, b, r, exact, A, st):
+        o.close()
