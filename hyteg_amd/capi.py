@@ -62,6 +62,8 @@ SIGNATURES = {
     "hyteg_hip_p1_restrict_cells": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), _i, _vp, C.POINTER(C.c_uint), _vp]),
     "hyteg_hip_p1_prolongate_cells": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), _i, _vp, C.POINTER(C.c_uint), _i, _vp]),
     "hyteg_hip_p2_edge_array_size": (C.c_size_t, [_i]),
+    "hyteg_hip_p2_operator_table_size": (C.c_size_t, []),
+    "hyteg_hip_p2_build_operator_table": (_i, [_dp, _dp]),
     "hyteg_hip_p2_edge_vector_cell_masked": (_i, [_i, _vp, _i, C.POINTER(_vp), _dp, _i, C.c_uint, _vp]),
     "hyteg_hip_p2_edge_dot_cell_masked": (_i, [_vp, _vp, _i, C.c_uint, _vp, _vp, _vp]),
     "hyteg_hip_p2_elementwise_apply_cell": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _d, _i, C.c_uint, _vp]),
@@ -271,6 +273,16 @@ def p2_edge_array_size(level):
     return int(lib().hyteg_hip_p2_edge_array_size(level))
 
 
+def p2_build_operator_table(elmat):
+    """host: element matrices [6][10][10] -> operator table (numpy array) for p2_elementwise_apply_cell"""
+    import numpy as np
+
+    em = np.ascontiguousarray(elmat, dtype=np.float64).reshape(600)
+    out = np.empty(int(lib().hyteg_hip_p2_operator_table_size()))
+    check(lib().hyteg_hip_p2_build_operator_table(em.ctypes.data_as(_dp), out.ctypes.data_as(_dp)), "p2_build_operator_table")
+    return out
+
+
 def p2_edge_vector_cell_masked(op, dst, srcs, scalars, level, mask, stream=0):
     n = len(srcs)
     sc = (C.c_double * max(1, len(scalars or [])))(*[float(v) for v in (scalars or [0.0])])
@@ -282,8 +294,8 @@ def p2_edge_dot_cell_masked(a, b, level, mask, result_dev, workspace_dev, stream
     check(lib().hyteg_hip_p2_edge_dot_cell_masked(a, b, level, mask, result_dev, workspace_dev, stream), "p2_edge_dot_cell_masked")
 
 
-def p2_elementwise_apply_cell(dst_v, dst_e, src_v, src_e, level, elmat_dev, alpha=1.0, update=REPLACE, mask=0x7FFF, stream=0):
-    check(lib().hyteg_hip_p2_elementwise_apply_cell(dst_v, dst_e, src_v, src_e, level, elmat_dev, float(alpha), update, mask, stream),
+def p2_elementwise_apply_cell(dst_v, dst_e, src_v, src_e, level, optable_dev, alpha=1.0, update=REPLACE, mask=0x7FFF, stream=0):
+    check(lib().hyteg_hip_p2_elementwise_apply_cell(dst_v, dst_e, src_v, src_e, level, optable_dev, float(alpha), update, mask, stream),
           "p2_elementwise_apply_cell")
 
 

@@ -1,0 +1,22 @@
+import sys, pathlib
+ROOT = pathlib.Path(__file__).resolve().parents[3]
+sys.path.insert(0, str(ROOT))
+import numpy as np, torch
+from hyteg_amd import capi
+from oracle import p1_oracle as po
+L = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+nv, ne = capi.cell_size(L), capi.p2_edge_array_size(L)
+em = torch.from_numpy(capi.p2_build_operator_table(po.p2_cell_element_matrices(np.array([0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1.0]), L))).to("cuda")
+sv, se = torch.rand(nv, dtype=torch.float64, device="cuda"), torch.rand(ne, dtype=torch.float64, device="cuda")
+dv, de = torch.zeros_like(sv), torch.zeros_like(se)
+st = torch.cuda.current_stream()
+for name, mask in (("all", 0x7FFF), ("inner", 0x4000), ("shell", 0x3FFF)):
+    for _ in range(3):
+        capi.p2_elementwise_apply_cell(dv.data_ptr(), de.data_ptr(), sv.data_ptr(), se.data_ptr(), L, em.data_ptr(), 1.0, 0, mask, st.cuda_stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(20):
+        capi.p2_elementwise_apply_cell(dv.data_ptr(), de.data_ptr(), sv.data_ptr(), se.data_ptr(), L, em.data_ptr(), 1.0, 0, mask, st.cuda_stream)
+    e1.record(st); torch.cuda.synchronize()
+    print(f"level {L} mask {name}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us")

@@ -11,6 +11,7 @@
 // First version: table-driven, one thread per destination DoF, direct loads.  Parity first; the roofline work
 // (row-wise register reuse as in the P1 z-march kernel) is the next step for this row.
 #include <mutex>
+#include <utility>
 
 #include "common.hpp"
 
@@ -168,6 +169,9 @@ __constant__ int kRowDeficit[6]     = { 0, 1, 1, 2, 1, 1 }; // numCellsPerRowByT
 
 __device__ inline int64_t edge_block_start( int n, int kind ) { return (int64_t) ( kind - 1 ) * tet64( n ); }
 
+// Boundary DoFs only, densely enumerated: the non-inner DoFs of a kind lie on faces of that kind's own tetrahedral array
+// (all four for vertex DoFs, two for X .. YZ edge DoFs, none for XYZ), so thread q walks the four triangular faces
+// (q -> face, (i,j)) and keeps a point at its lowest-numbered face.
 __global__ __launch_bounds__( kThreads ) void p2_elementwise_kernel( const P2Args A )
 {
    const int c = blockIdx.y; // destination kind
@@ -175,29 +179,36 @@ __global__ __launch_bounds__( kThreads ) void p2_elementwise_kernel( const P2Arg
    const int W = c == 0 ? N : ( c == 7 ? n - 1 : n );
    if ( W <= 0 )
       return;
-   const int64_t size = tet64( W );
-   const int64_t i    = (int64_t) blockIdx.x * kThreads + threadIdx.x;
-   if ( i >= size )
+   const int T = tri( W );
+   const int q = blockIdx.x * kThreads + threadIdx.x;
+   if ( q >= 4 * T )
       return;
-   // decode (x, y, z) in a tetrahedral array of width W
-   int z = 0;
+   int x, y, z;
    {
-      // largest z with slice_start(W, z) <= i
-      int lo = 0, hi = W - 1;
-      while ( lo < hi )
+      const int f = q / T, r = q - f * T;
+      const int j = row_of( W, r );
+      const int k = r - row_start( W, j );
+      switch ( f )
       {
-         const int mid = ( lo + hi + 1 ) >> 1;
-         if ( tet64( W ) - tet64( W - mid ) <= i )
-            lo = mid;
-         else
-            hi = mid - 1;
+      case 0:
+         x = k, y = j, z = 0;
+         break;
+      case 1:
+         x = k, y = 0, z = j;
+         break;
+      case 2:
+         x = 0, y = k, z = j;
+         break;
+      default:
+         x = k, y = j, z = W - 1 - k - j;
+         break;
       }
-      z = lo;
+      const int lowest = ( z == 0 ) ? 0 : ( y == 0 ) ? 1 : ( x == 0 ) ? 2 : 3;
+      if ( lowest != f )
+         return;
    }
-   const int j = (int) ( i - ( tet64( W ) - tet64( W - z ) ) );
-   const int y = row_of( W - z, j );
-   const int x = j - row_start( W - z, y );
-   int       cls;
+   const int64_t i = (int64_t) cell_index( W, x, y, z );
+   int           cls;
    if ( c == 0 )
       cls = class_from_flags( z == 0, y == 0, x == 0, x + y + z == N - 1 );
    else
@@ -360,9 +371,278 @@ __global__ __launch_bounds__( kThreads ) void p2_sum_partials_kernel( const doub
    }
 }
 
+
+// =====================================================================================================================
+// Fast path for INNER DoFs: on an affine macro-cell every inner DoF of one kind sees the same neighbourhood, so the sum
+// over its adjacent micro-cells collapses to a constant stencil  sum_q w[q] * src_{kind_q}( dof + d_q )  (what the reference's
+// P2ConstantOperator assembles into its vertex-to-vertex, edge-to-vertex, vertex-to-edge and edge-to-edge stencils).  The list
+// of (source kind, offset) pairs per destination kind is a geometric fact and is built at COMPILE time from the micro-cell
+// tables, so the kernel is straight-line code with constant offsets; the weights are summed from the element matrices on
+// the host (hyteg_hip_p2_build_operator_table) and read through scalar loads.
+// =====================================================================================================================
+struct CLocal
+{
+   int kind, ox, oy, oz;
+};
+constexpr int cMicroVerts[6][4][3] = { { { 0, 0, 0 }, { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } }, { { 1, 0, 0 }, { 1, 1, 0 }, { 0, 1, 0 }, { 1, 0, 1 } },
+                                       { { 1, 0, 0 }, { 0, 1, 0 }, { 1, 0, 1 }, { 0, 0, 1 } }, { { 1, 1, 0 }, { 1, 1, 1 }, { 0, 1, 1 }, { 1, 0, 1 } },
+                                       { { 1, 0, 1 }, { 0, 1, 1 }, { 0, 0, 1 }, { 0, 1, 0 } }, { { 0, 1, 0 }, { 1, 1, 0 }, { 1, 0, 1 }, { 0, 1, 1 } } };
+constexpr int cEdgePairs[6][2]      = { { 2, 3 }, { 1, 3 }, { 1, 2 }, { 0, 3 }, { 0, 2 }, { 0, 1 } };
+
+constexpr CLocal c_local( int t, int k )
+{
+   if ( k < 4 )
+      return CLocal{ 0, cMicroVerts[t][k][0], cMicroVerts[t][k][1], cMicroVerts[t][k][2] };
+   const int* a = cMicroVerts[t][cEdgePairs[k - 4][0]];
+   const int* b = cMicroVerts[t][cEdgePairs[k - 4][1]];
+   const int  d0 = b[0] - a[0], d1 = b[1] - a[1], d2 = b[2] - a[2];
+   if ( d1 == 0 && d2 == 0 )
+   {
+      const int* lo = a[0] < b[0] ? a : b;
+      return CLocal{ 1, lo[0], lo[1], lo[2] };
+   }
+   if ( d0 == 0 && d2 == 0 )
+   {
+      const int* lo = a[1] < b[1] ? a : b;
+      return CLocal{ 2, lo[0], lo[1], lo[2] };
+   }
+   if ( d0 == 0 && d1 == 0 )
+   {
+      const int* lo = a[2] < b[2] ? a : b;
+      return CLocal{ 3, lo[0], lo[1], lo[2] };
+   }
+   if ( d2 == 0 )
+   {
+      const int* lo = a[0] < b[0] ? a : b;
+      return CLocal{ 4, lo[0], lo[1] - 1, lo[2] };
+   }
+   if ( d1 == 0 )
+   {
+      const int* lo = a[0] < b[0] ? a : b;
+      return CLocal{ 5, lo[0], lo[1], lo[2] - 1 };
+   }
+   if ( d0 == 0 )
+   {
+      const int* lo = a[1] < b[1] ? a : b;
+      return CLocal{ 6, lo[0], lo[1], lo[2] - 1 };
+   }
+   const int* lo = a[0] < b[0] ? a : b;
+   return CLocal{ 7, lo[0], lo[1] - 1, lo[2] };
+}
+
+constexpr int kMaxStencil = 96;
+struct KindStencil
+{
+   int n;
+   int kind[kMaxStencil], dx[kMaxStencil], dy[kMaxStencil], dz[kMaxStencil];
+};
+// unique (source kind, offset) pairs of destination kind c, in first-seen order over (type, local row, local column)
+constexpr KindStencil build_kind_stencil( int c )
+{
+   KindStencil S{};
+   for ( int t = 0; t < 6; ++t )
+      for ( int k = 0; k < 10; ++k )
+      {
+         const CLocal row = c_local( t, k );
+         if ( row.kind != c )
+            continue;
+         for ( int j = 0; j < 10; ++j )
+         {
+            const CLocal col = c_local( t, j );
+            const int    dx = col.ox - row.ox, dy = col.oy - row.oy, dz = col.oz - row.oz;
+            bool         found = false;
+            for ( int q = 0; q < S.n; ++q )
+               found = found || ( S.kind[q] == col.kind && S.dx[q] == dx && S.dy[q] == dy && S.dz[q] == dz );
+            if ( !found )
+            {
+               S.kind[S.n] = col.kind, S.dx[S.n] = dx, S.dy[S.n] = dy, S.dz[S.n] = dz;
+               ++S.n;
+            }
+         }
+      }
+   return S;
+}
+template < int C >
+struct KindStencilOf
+{
+   static constexpr KindStencil value = build_kind_stencil( C );
+};
+constexpr int stencil_count( int c ) { return build_kind_stencil( c ).n; }
+constexpr int stencil_offset( int c )
+{
+   int o = 600; // the element matrices come first in the operator table
+   for ( int k = 0; k < c; ++k )
+      o += stencil_count( k );
+   return o;
+}
+constexpr int kOperatorTableSize = stencil_offset( 8 );
+
+struct P2FastArgs
+{
+   double*       dstV;
+   double*       dstE;
+   const double* srcV;
+   const double* srcE;
+   const double* table; // device: [600 element matrices | stencil weights of kind 0 | kind 1 | ... ]
+   double        alpha;
+   int           N, update;
+};
+
+// Row bases: every stencil entry of destination kind C reads source kind K at (x + dx, y + dy, z + dz) with compile-time
+// (K, dx, dy, dz); the array index of (x, y + dy, z + dz) in kind K's block is computed once per USED (K, dy, dz) and the
+// entries add dx.  32-bit index arithmetic: the largest index at level 9 is 6 tet(512) + tet(511) < 2^31.
+template < int C >
+constexpr bool row_used( int K, int dy, int dz )
+{
+   constexpr KindStencil S = KindStencilOf< C >::value;
+   for ( int q = 0; q < S.n; ++q )
+      if ( S.kind[q] == K && S.dy[q] == dy && S.dz[q] == dz )
+         return true;
+   return false;
+}
+struct RowBases
+{
+   int b[8][3][3]; // [source kind][dy + 1][dz + 1]
+};
+template < int C, int K, int DY, int DZ >
+__device__ inline void p2_row_base( RowBases& R, int N, int n, int x, int y, int z )
+{
+   if constexpr ( row_used< C >( K, DY, DZ ) )
+   {
+      const int W           = K == 0 ? N : ( K == 7 ? n - 1 : n );
+      const int block       = K == 0 ? 0 : ( K - 1 ) * (int) tet32( (unsigned) n );
+      R.b[K][DY + 1][DZ + 1] = block + cell_index( W, x, y + DY, z + DZ );
+   }
+}
+template < int C, int K >
+__device__ inline void p2_row_bases_of_kind( RowBases& R, int N, int n, int x, int y, int z )
+{
+   p2_row_base< C, K, -1, -1 >( R, N, n, x, y, z );
+   p2_row_base< C, K, 0, -1 >( R, N, n, x, y, z );
+   p2_row_base< C, K, 1, -1 >( R, N, n, x, y, z );
+   p2_row_base< C, K, -1, 0 >( R, N, n, x, y, z );
+   p2_row_base< C, K, 0, 0 >( R, N, n, x, y, z );
+   p2_row_base< C, K, 1, 0 >( R, N, n, x, y, z );
+   p2_row_base< C, K, -1, 1 >( R, N, n, x, y, z );
+   p2_row_base< C, K, 0, 1 >( R, N, n, x, y, z );
+   p2_row_base< C, K, 1, 1 >( R, N, n, x, y, z );
+}
+
+template < int C, int Q >
+__device__ inline void p2_term( const P2FastArgs& A, const double* __restrict__ w, const RowBases& R, double& acc )
+{
+   constexpr int K = KindStencilOf< C >::value.kind[Q], DX = KindStencilOf< C >::value.dx[Q], DY = KindStencilOf< C >::value.dy[Q],
+                 DZ = KindStencilOf< C >::value.dz[Q];
+   static_assert( DY >= -1 && DY <= 1 && DZ >= -1 && DZ <= 1, "stencil offsets" );
+   const int idx = R.b[K][DY + 1][DZ + 1] + DX;
+   acc           = fma( w[Q], K == 0 ? A.srcV[idx] : A.srcE[idx], acc );
+}
+
+// inner DoFs of kind C: inner vertex DoFs x,y,z >= 1, x+y+z <= N-2; inner edge DoFs by EdgeDoFIndexing.hpp:987-1020
+template < int C >
+__device__ inline bool p2_inner( int N, int x, int y, int z )
+{
+   const int n = N - 1, s = x + y + z;
+   if constexpr ( C == 0 )
+      return x >= 1 && y >= 1 && z >= 1 && s <= N - 2;
+   else if constexpr ( C == 1 )
+      return y > 0 && z > 0 && s < n;
+   else if constexpr ( C == 2 )
+      return x > 0 && z > 0 && s < n;
+   else if constexpr ( C == 3 )
+      return x > 0 && y > 0 && s < n;
+   else if constexpr ( C == 4 )
+      return z > 0 && s < n - 1;
+   else if constexpr ( C == 5 )
+      return y > 0 && s < n - 1;
+   else if constexpr ( C == 6 )
+      return x > 0 && s < n - 1;
+   else
+      return s < n - 1;
+}
+
+template < int C >
+__global__ __launch_bounds__( kThreads ) void p2_inner_kernel( const P2FastArgs A )
+{
+   constexpr int NQ  = KindStencilOf< C >::value.n; // forced constant evaluation: none of the table code may run on the device
+   constexpr int OFF = stencil_offset( C );
+   const int     N = A.N, n = N - 1;
+   const int     W = C == 0 ? N : ( C == 7 ? n - 1 : n );
+   const int64_t         i = (int64_t) blockIdx.x * kThreads + threadIdx.x;
+   if ( W <= 0 || i >= tet64( W ) )
+      return;
+   int lo = 0, hi = W - 1;
+   while ( lo < hi )
+   {
+      const int mid = ( lo + hi + 1 ) >> 1;
+      if ( tet64( W ) - tet64( W - mid ) <= i )
+         lo = mid;
+      else
+         hi = mid - 1;
+   }
+   const int z = lo;
+   const int j = (int) ( i - ( tet64( W ) - tet64( W - z ) ) );
+   const int y = row_of( W - z, j );
+   const int x = j - row_start( W - z, y );
+   if ( !p2_inner< C >( N, x, y, z ) )
+      return;
+   const double* __restrict__ w = A.table + OFF;
+   double acc                   = 0.0;
+   RowBases R;
+   [&]< int... K >( std::integer_sequence< int, K... > ) { ( p2_row_bases_of_kind< C, K >( R, N, n, x, y, z ), ... ); }
+   ( std::make_integer_sequence< int, 8 >{} );
+   [&]< int... Q >( std::integer_sequence< int, Q... > ) { ( p2_term< C, Q >( A, w, R, acc ), ... ); }
+   ( std::make_integer_sequence< int, NQ >{} );
+   acc         = A.alpha * acc;
+   double* out = C == 0 ? A.dstV + i : A.dstE + edge_block_start( n, C ) + i;
+   *out        = A.update == HYTEG_HIP_ADD ? *out + acc : acc;
+}
+
+template < int C >
+void launch_inner( const P2FastArgs& A, hipStream_t s )
+{
+   const int     n = A.N - 1;
+   const int     W = C == 0 ? A.N : ( C == 7 ? n - 1 : n );
+   const int64_t size = W > 0 ? tet64( W ) : 0;
+   if ( size > 0 )
+      hipLaunchKernelGGL( p2_inner_kernel< C >, dim3( (unsigned) ( ( size + kThreads - 1 ) / kThreads ) ), dim3( kThreads ), 0, s, A );
+}
+
 } // namespace
 
 extern "C" {
+
+HYTEG_HIP_API size_t hyteg_hip_p2_operator_table_size( void ) { return (size_t) kOperatorTableSize; }
+
+HYTEG_HIP_API int hyteg_hip_p2_build_operator_table( const double* elmat_host, double* table_host )
+{
+   HH_REQUIRE( elmat_host && table_host, "p2_build_operator_table: null pointer" );
+   for ( int k = 0; k < 600; ++k )
+      table_host[k] = elmat_host[k];
+   for ( int c = 0; c < 8; ++c )
+   {
+      const KindStencil S   = build_kind_stencil( c );
+      double*           w   = table_host + stencil_offset( c );
+      for ( int q = 0; q < S.n; ++q )
+         w[q] = 0.0;
+      for ( int t = 0; t < 6; ++t )
+         for ( int k = 0; k < 10; ++k )
+         {
+            const CLocal row = c_local( t, k );
+            if ( row.kind != c )
+               continue;
+            for ( int j = 0; j < 10; ++j )
+            {
+               const CLocal col = c_local( t, j );
+               const int    dx = col.ox - row.ox, dy = col.oy - row.oy, dz = col.oz - row.oz;
+               for ( int q = 0; q < S.n; ++q )
+                  if ( S.kind[q] == col.kind && S.dx[q] == dx && S.dy[q] == dy && S.dz[q] == dz )
+                     w[q] += elmat_host[100 * t + 10 * k + j];
+            }
+         }
+   }
+   return HYTEG_HIP_OK;
+}
 
 HYTEG_HIP_API int hyteg_hip_p2_edge_vector_cell_masked( int                  op,
                                                         double*              dst,
@@ -433,24 +713,45 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell( double*            dst_ve
                                                        const double*      src_vertex,
                                                        const double*      src_edge,
                                                        int                level,
-                                                       const double*      elmat_dev,
+                                                       const double*      optable_dev,
                                                        double             alpha,
                                                        int                update,
                                                        unsigned           mask,
                                                        hyteg_hip_stream_t stream )
 {
-   HH_REQUIRE( dst_vertex && dst_edge && src_vertex && src_edge && elmat_dev, "p2_elementwise_apply_cell: null pointer" );
+   HH_REQUIRE( dst_vertex && dst_edge && src_vertex && src_edge && optable_dev, "p2_elementwise_apply_cell: null pointer" );
    HH_REQUIRE( level >= 0 && level <= HYTEG_HIP_P2_MAX_LEVEL, "p2_elementwise_apply_cell: level out of range [0,9]" );
    HH_REQUIRE( dst_vertex != src_vertex && dst_edge != src_edge, "p2_elementwise_apply_cell: src and dst must not alias" );
    HH_REQUIRE( update == HYTEG_HIP_REPLACE || update == HYTEG_HIP_ADD, "p2_elementwise_apply_cell: bad update type" );
-   if ( ( mask & HYTEG_HIP_MASK_ALL ) == 0 )
+   mask &= HYTEG_HIP_MASK_ALL;
+   if ( mask == 0 )
       return HYTEG_HIP_OK;
-   P2Args A;
-   A.dstV = dst_vertex, A.dstE = dst_edge, A.srcV = src_vertex, A.srcE = src_edge, A.elmat = elmat_dev, A.alpha = alpha;
-   A.N = ( 1 << level ) + 1, A.update = update, A.mask = mask & HYTEG_HIP_MASK_ALL, A.T = tables();
-   const int64_t largest = tet64( A.N );
-   const dim3    grid( (unsigned) ( ( largest + kThreads - 1 ) / kThreads ), 8 );
-   hipLaunchKernelGGL( p2_elementwise_kernel, grid, dim3( kThreads ), 0, as_stream( stream ), A );
+   hipStream_t s = as_stream( stream );
+   if ( mask & HYTEG_HIP_MASK_INNER )
+   {
+      // inner DoFs: compile-time stencils, one launch per destination kind
+      P2FastArgs F;
+      F.dstV = dst_vertex, F.dstE = dst_edge, F.srcV = src_vertex, F.srcE = src_edge, F.table = optable_dev, F.alpha = alpha;
+      F.N = ( 1 << level ) + 1, F.update = update;
+      launch_inner< 0 >( F, s );
+      launch_inner< 1 >( F, s );
+      launch_inner< 2 >( F, s );
+      launch_inner< 3 >( F, s );
+      launch_inner< 4 >( F, s );
+      launch_inner< 5 >( F, s );
+      launch_inner< 6 >( F, s );
+      launch_inner< 7 >( F, s );
+   }
+   if ( mask & HYTEG_HIP_MASK_SHELL )
+   {
+      // DoFs on the macro-cell boundary: micro-cell by micro-cell gather (the adjacent cells that exist differ from DoF to DoF)
+      P2Args A;
+      A.dstV = dst_vertex, A.dstE = dst_edge, A.srcV = src_vertex, A.srcE = src_edge, A.elmat = optable_dev, A.alpha = alpha;
+      A.N = ( 1 << level ) + 1, A.update = update, A.mask = mask & HYTEG_HIP_MASK_SHELL, A.T = tables();
+      const int  faces = 4 * tri( A.N ); // candidates of the widest kind
+      const dim3 grid( (unsigned) ( ( faces + kThreads - 1 ) / kThreads ), 8 );
+      hipLaunchKernelGGL( p2_elementwise_kernel, grid, dim3( kThreads ), 0, s, A );
+   }
    HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;
 }

@@ -2013,7 +2013,9 @@ class P2ElementwiseOperator
                             ( cell.coords[3][r] - cell.coords[0][r] ) * step * verts[t][k][2];
             P2Form::integrateAll( c, h.data() + 100 * t );
          }
-         elementMatrices_[l] = storage->uploadTable( h );
+         std::vector< double > table( hyteg_hip_p2_operator_table_size() );
+         hipCheck( hyteg_hip_p2_build_operator_table( h.data(), table.data() ), "P2ElementwiseOperator: operator table" );
+         elementMatrices_[l] = storage->uploadTable( table );
          hostMatrices_[l]    = h;
       }
    }

@@ -404,13 +404,19 @@ HYTEG_HIP_API int hyteg_hip_p1_sor_shell_cells( int                             
  * P2ElementwiseOperator::gemv, src/hyteg/elementwiseoperators/P2ElementwiseOperator.cpp:110-223 (cell loop) with
  * localMatrixVectorMultiply3D (:66-107).  Arrays: the vertex-DoF array of the P1 kernels and the edge-DoF array of
  * src/hyteg/edgedofspace/EdgeDoFIndexing.hpp:920-985: blocks X, Y, Z, XY, XZ, YZ of tet(2^level) entries and XYZ of
- * tet(2^level - 1).  elmat_dev: device array [6][10][10], the element matrices of the micro-cell types WHITE_UP, BLUE_UP,
- * GREEN_UP, WHITE_DOWN, BLUE_DOWN, GREEN_DOWN (celldof::allCellTypes) in FEniCS ordering (constant on an affine cell;
- * P2Form::integrateAll, kernel INPUT).  Every DoF whose point class is in `mask` (vertex DoFs as for the P1 kernels; an
+ * tet(2^level - 1).  The operator of an affine macro-cell is given by the six 10 x 10 element matrices of the micro-cell
+ * types WHITE_UP, BLUE_UP, GREEN_UP, WHITE_DOWN, BLUE_DOWN, GREEN_DOWN (celldof::allCellTypes) in FEniCS ordering
+ * (P2Form::integrateAll, kernel INPUT): hyteg_hip_p2_build_operator_table turns elmat[6][10][10] (host) into the table the
+ * kernel reads -- the matrices themselves, used micro-cell by micro-cell for DoFs on the macro-cell boundary, followed by
+ * the constant stencils they imply for inner DoFs (hyteg_hip_p2_operator_table_size() doubles); the caller uploads it
+ * once per (cell, level).  Every DoF whose point class is in `mask` (vertex DoFs as for the P1 kernels; an
  * edge DoF belongs to the macro-primitive that contains both its end points) receives alpha * (A src) (REPLACE) or has
- * it added (ADD); the sum over micro-cells is taken in the reference's loop order.  Levels 0..9. */
+ * it added (ADD).  Boundary DoFs: the sum over micro-cells is taken in the reference's loop order; inner DoFs: in stencil order.
+ * Levels 0..9. */
 #define HYTEG_HIP_P2_MAX_LEVEL 9
 HYTEG_HIP_API size_t hyteg_hip_p2_edge_array_size( int level );
+HYTEG_HIP_API size_t hyteg_hip_p2_operator_table_size( void );
+HYTEG_HIP_API int    hyteg_hip_p2_build_operator_table( const double* elmat_host /* 600 */, double* table_host );
 /* EdgeDoFFunction assign / add / multElementwise / interpolate( constant ) and dotLocal on the edge-DoF array of one
  * macro-cell (src/hyteg/edgedofspace/EdgeDoFFunction.cpp), restricted to the DoFs whose point class is in `mask`;
  * op and workspace as for hyteg_hip_p1_vector_cell_masked / hyteg_hip_p1_dot_cell_masked */
@@ -434,7 +440,7 @@ HYTEG_HIP_API int    hyteg_hip_p2_elementwise_apply_cell( double*            dst
                                                           const double*      src_vertex,
                                                           const double*      src_edge,
                                                           int                level,
-                                                          const double*      elmat_dev,
+                                                          const double*      optable_dev,
                                                           double             alpha,
                                                           int                update,
                                                           unsigned           mask,

@@ -33,7 +33,7 @@ def test_p2_elementwise_apply_matches_the_oracle(env, level, tet):
     em = po.p2_cell_element_matrices(np.asarray(tet, dtype=np.float64).reshape(12), level)
     rng = np.random.default_rng(level)
     sv, se, dv0, de0 = rng.standard_normal(nv), rng.standard_normal(ne), rng.standard_normal(nv), rng.standard_normal(ne)
-    dem = _dev(torch, em.reshape(-1))
+    dem = _dev(torch, capi.p2_build_operator_table(em))
     for mask, update, alpha in ((0x7FFF, 0, 1.0), (1 << 14, 0, 1.0), (0x7FFF, 1, -0.5), (0x4000 | 0x2A5, 0, 2.0), (0x3FFF, 1, 1.0)):
         wv, we = po.p2_elementwise_apply_cell(dv0.copy(), de0.copy(), sv, se, level, em, alpha, update, mask)
         dsv, dse, ddv, dde = _dev(torch, sv), _dev(torch, se), _dev(torch, dv0), _dev(torch, de0)
@@ -56,7 +56,7 @@ def test_p2_laplace_known_answers_level_6(env):
 
     level = 6
     co = np.asarray(REF_TET, dtype=np.float64).reshape(12)
-    em = _dev(torch, po.p2_cell_element_matrices(co, level).reshape(-1))
+    em = _dev(torch, capi.p2_build_operator_table(po.p2_cell_element_matrices(co, level)))
     pv, pe = hu.cell_points(co, level), po.edge_midpoints(co, level)
 
     def apply(uv, ue):

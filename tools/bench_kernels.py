@@ -91,7 +91,7 @@ def main():
 
     L2 = min(L, 7)
     nv2, ne2 = capi.cell_size(L2), capi.p2_edge_array_size(L2)
-    em = torch.from_numpy(po.p2_cell_element_matrices(np.array([0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1.0]), L2).reshape(-1)).to("cuda")
+    em = torch.from_numpy(capi.p2_build_operator_table(po.p2_cell_element_matrices(np.array([0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1.0]), L2))).to("cuda")
     nb2 = max(2, int(1.5 * 256 * 2**20) // (2 * (nv2 + ne2) * 8) + 1)
     SV = [torch.rand(nv2, dtype=torch.float64, device="cuda") for _ in range(nb2)]
     SE = [torch.rand(ne2, dtype=torch.float64, device="cuda") for _ in range(nb2)]
