@@ -161,6 +161,20 @@ __device__ inline int class_from_flags( int f0, int f1, int f2, int f3 )
    return 13;
 }
 
+// slice z of entry i of a tetrahedral array of width W (largest z with slice_start(W,z) <= i): cube-root estimate + fix-up
+// (a binary search with 64-bit products was a quarter of the instructions of the inner kernels)
+__device__ inline int slice_of( int W, int64_t i )
+{
+   const int64_t rest = tet64( W ) - i; // entries from i to the end: tet(W - z) >= rest > tet(W - z - 1)
+   int           m    = (int) cbrtf( 6.0f * (float) rest );
+   m                  = m < 1 ? 1 : ( m > W ? W : m );
+   while ( m > 1 && tet64( m - 1 ) >= rest )
+      --m;
+   while ( tet64( m ) < rest )
+      ++m;
+   return W - m;
+}
+
 // end points of an edge DoF relative to its logical index, by orientation X, Y, Z, XY, XZ, YZ, XYZ
 __constant__ int kEdgeEnds[7][2][3] = { { { 0, 0, 0 }, { 1, 0, 0 } }, { { 0, 0, 0 }, { 0, 1, 0 } }, { { 0, 0, 0 }, { 0, 0, 1 } },
                                         { { 1, 0, 0 }, { 0, 1, 0 } }, { { 1, 0, 0 }, { 0, 0, 1 } }, { { 0, 1, 0 }, { 0, 0, 1 } },
@@ -172,6 +186,7 @@ __device__ inline int64_t edge_block_start( int n, int kind ) { return (int64_t)
 // Boundary DoFs only, densely enumerated: the non-inner DoFs of a kind lie on faces of that kind's own tetrahedral array
 // (all four for vertex DoFs, two for X .. YZ edge DoFs, none for XYZ), so thread q walks the four triangular faces
 // (q -> face, (i,j)) and keeps a point at its lowest-numbered face.
+template < bool LANES >
 __global__ __launch_bounds__( kThreads ) void p2_elementwise_kernel( const P2Args A )
 {
    const int c = blockIdx.y; // destination kind
@@ -179,8 +194,12 @@ __global__ __launch_bounds__( kThreads ) void p2_elementwise_kernel( const P2Arg
    const int W = c == 0 ? N : ( c == 7 ? n - 1 : n );
    if ( W <= 0 )
       return;
-   const int T = tri( W );
-   const int q = blockIdx.x * kThreads + threadIdx.x;
+   // LANES: 32 lanes per DoF, one per adjacent micro-cell (at most 24).  A thread per DoF walks its cells one memory round
+   // trip after the other: pure latency on small levels (39 vs 13 us at level 5); from level 6 on there are enough DoFs
+   // to hide it and the 32-fold redundant decode costs more (47 vs 115 us at level 7).
+   const int T    = tri( W );
+   const int lane = LANES ? ( threadIdx.x & 31 ) : 0;
+   const int q    = LANES ? blockIdx.x * ( kThreads / 32 ) + ( threadIdx.x >> 5 ) : blockIdx.x * kThreads + threadIdx.x;
    if ( q >= 4 * T )
       return;
    int x, y, z;
@@ -224,14 +243,13 @@ __global__ __launch_bounds__( kThreads ) void p2_elementwise_kernel( const P2Arg
    }
    if ( !( ( A.mask >> cls ) & 1u ) )
       return;
-   double acc = 0.0;
-   for ( int q = 0; q < A.T.nentries[c]; ++q )
-   {
-      const Entry en = A.T.entries[c][q];
+   // one adjacent micro-cell: alpha * (row of its element matrix) . (its ten source values)
+   auto contribution = [&]( int l, double& part ) -> bool {
+      const Entry en = A.T.entries[c][l];
       const int   t = en.type, mx = x - en.ox, my = y - en.oy, mz = z - en.oz;
       const int   rows = n - kRowDeficit[t];
       if ( mx < 0 || my < 0 || mz < 0 || mx + my + mz > rows - 1 )
-         continue;
+         return false;
       const double* M = A.elmat + 100 * t + 10 * en.row;
       double        s = 0.0;
 #pragma unroll
@@ -243,8 +261,35 @@ __global__ __launch_bounds__( kThreads ) void p2_elementwise_kernel( const P2Arg
                                             A.srcE[edge_block_start( n, ld.kind ) + cell_index( ld.kind == 7 ? n - 1 : n, px, py, pz )];
          s                 = s + M[k] * v;
       }
-      acc += A.alpha * s;
+      part = A.alpha * s;
+      return true;
+   };
+   double acc = 0.0;
+   if constexpr ( LANES )
+   {
+      // lane l evaluates adjacent micro-cell l; every lane of the group adds the contributions in the reference's loop order
+      double     part  = 0.0;
+      const bool valid = lane < A.T.nentries[c] && contribution( lane, part );
+      const unsigned long long vmask = __ballot( valid );
+      const int                base  = ( threadIdx.x & 63 ) & ~31; // first lane of this DoF's group inside the wave
+      for ( int l = 0; l < 24; ++l )
+      {
+         const double p = __shfl( part, base + l, 64 );
+         if ( ( vmask >> ( base + l ) ) & 1ull )
+            acc += p;
+      }
    }
+   else
+   {
+      for ( int l = 0; l < A.T.nentries[c]; ++l )
+      {
+         double part;
+         if ( contribution( l, part ) )
+            acc += part;
+      }
+   }
+   if ( lane != 0 )
+      return;
    double* out = c == 0 ? A.dstV + i : A.dstE + edge_block_start( n, c ) + i;
    *out        = A.update == HYTEG_HIP_ADD ? *out + acc : acc;
 }
@@ -261,16 +306,7 @@ __device__ inline bool edge_entry( int n, int64_t i, int& x, int& y, int& z, int
    const int64_t r = i - (int64_t) o * blk;
    if ( W <= 0 || r >= tet64( W ) )
       return false;
-   int lo = 0, hi = W - 1;
-   while ( lo < hi )
-   {
-      const int mid = ( lo + hi + 1 ) >> 1;
-      if ( tet64( W ) - tet64( W - mid ) <= r )
-         lo = mid;
-      else
-         hi = mid - 1;
-   }
-   z           = lo;
+   z           = slice_of( W, r );
    const int j = (int) ( r - ( tet64( W ) - tet64( W - z ) ) );
    y           = row_of( W - z, j );
    x           = j - row_start( W - z, y );
@@ -504,28 +540,61 @@ struct RowBases
 {
    int b[8][3][3]; // [source kind][dy + 1][dz + 1]
 };
+// index of (x, y + DY, z + DZ) from the index i0 of (x, y, z) in a tetrahedral array whose slice z has first-row length Wz:
+// (x,y,z) -> (x,y+1,z): + (Wz - y);  (x,y,z) -> (x,y,z+1): + tri(Wz) - y  (the layout algebra of the P1 kernels)
+template < int DY, int DZ >
+__device__ inline int p2_neighbour_row( int i0, int Wz, int y )
+{
+   int i = i0, w = Wz;
+   if constexpr ( DZ == 1 )
+   {
+      i += tri( w ) - y;
+      w -= 1;
+   }
+   else if constexpr ( DZ == -1 )
+   {
+      i -= tri( w + 1 ) - y;
+      w += 1;
+   }
+   if constexpr ( DY == 1 )
+      i += w - y;
+   else if constexpr ( DY == -1 )
+      i -= w - y + 1;
+   return i;
+}
 template < int C, int K, int DY, int DZ >
-__device__ inline void p2_row_base( RowBases& R, int N, int n, int x, int y, int z )
+__device__ inline void p2_row_base( RowBases& R, int i0, int Wz, int y )
 {
    if constexpr ( row_used< C >( K, DY, DZ ) )
-   {
-      const int W           = K == 0 ? N : ( K == 7 ? n - 1 : n );
-      const int block       = K == 0 ? 0 : ( K - 1 ) * (int) tet32( (unsigned) n );
-      R.b[K][DY + 1][DZ + 1] = block + cell_index( W, x, y + DY, z + DZ );
-   }
+      R.b[K][DY + 1][DZ + 1] = p2_neighbour_row< DY, DZ >( i0, Wz, y );
+}
+template < int C, int K >
+constexpr bool kind_used()
+{
+   for ( int dy = -1; dy <= 1; ++dy )
+      for ( int dz = -1; dz <= 1; ++dz )
+         if ( row_used< C >( K, dy, dz ) )
+            return true;
+   return false;
 }
 template < int C, int K >
 __device__ inline void p2_row_bases_of_kind( RowBases& R, int N, int n, int x, int y, int z )
 {
-   p2_row_base< C, K, -1, -1 >( R, N, n, x, y, z );
-   p2_row_base< C, K, 0, -1 >( R, N, n, x, y, z );
-   p2_row_base< C, K, 1, -1 >( R, N, n, x, y, z );
-   p2_row_base< C, K, -1, 0 >( R, N, n, x, y, z );
-   p2_row_base< C, K, 0, 0 >( R, N, n, x, y, z );
-   p2_row_base< C, K, 1, 0 >( R, N, n, x, y, z );
-   p2_row_base< C, K, -1, 1 >( R, N, n, x, y, z );
-   p2_row_base< C, K, 0, 1 >( R, N, n, x, y, z );
-   p2_row_base< C, K, 1, 1 >( R, N, n, x, y, z );
+   if constexpr ( kind_used< C, K >() )
+   {
+      const int W  = K == 0 ? N : ( K == 7 ? n - 1 : n );
+      const int i0 = ( K == 0 ? 0 : ( K - 1 ) * (int) tet32( (unsigned) n ) ) + cell_index( W, x, y, z );
+      const int Wz = W - z;
+      p2_row_base< C, K, -1, -1 >( R, i0, Wz, y );
+      p2_row_base< C, K, 0, -1 >( R, i0, Wz, y );
+      p2_row_base< C, K, 1, -1 >( R, i0, Wz, y );
+      p2_row_base< C, K, -1, 0 >( R, i0, Wz, y );
+      p2_row_base< C, K, 0, 0 >( R, i0, Wz, y );
+      p2_row_base< C, K, 1, 0 >( R, i0, Wz, y );
+      p2_row_base< C, K, -1, 1 >( R, i0, Wz, y );
+      p2_row_base< C, K, 0, 1 >( R, i0, Wz, y );
+      p2_row_base< C, K, 1, 1 >( R, i0, Wz, y );
+   }
 }
 
 template < int C, int Q >
@@ -562,7 +631,7 @@ __device__ inline bool p2_inner( int N, int x, int y, int z )
 }
 
 template < int C >
-__global__ __launch_bounds__( kThreads ) void p2_inner_kernel( const P2FastArgs A )
+__device__ inline void p2_inner_body( const P2FastArgs& A )
 {
    constexpr int NQ  = KindStencilOf< C >::value.n; // forced constant evaluation: none of the table code may run on the device
    constexpr int OFF = stencil_offset( C );
@@ -571,16 +640,7 @@ __global__ __launch_bounds__( kThreads ) void p2_inner_kernel( const P2FastArgs 
    const int64_t         i = (int64_t) blockIdx.x * kThreads + threadIdx.x;
    if ( W <= 0 || i >= tet64( W ) )
       return;
-   int lo = 0, hi = W - 1;
-   while ( lo < hi )
-   {
-      const int mid = ( lo + hi + 1 ) >> 1;
-      if ( tet64( W ) - tet64( W - mid ) <= i )
-         lo = mid;
-      else
-         hi = mid - 1;
-   }
-   const int z = lo;
+   const int z = slice_of( W, i );
    const int j = (int) ( i - ( tet64( W ) - tet64( W - z ) ) );
    const int y = row_of( W - z, j );
    const int x = j - row_start( W - z, y );
@@ -598,14 +658,36 @@ __global__ __launch_bounds__( kThreads ) void p2_inner_kernel( const P2FastArgs 
    *out        = A.update == HYTEG_HIP_ADD ? *out + acc : acc;
 }
 
-template < int C >
-void launch_inner( const P2FastArgs& A, hipStream_t s )
+// all eight destination kinds in one launch (blockIdx.y = kind): one ramp-up instead of eight, kinds overlap
+__global__ __launch_bounds__( kThreads ) void p2_inner_kernel( const P2FastArgs A )
 {
-   const int     n = A.N - 1;
-   const int     W = C == 0 ? A.N : ( C == 7 ? n - 1 : n );
-   const int64_t size = W > 0 ? tet64( W ) : 0;
-   if ( size > 0 )
-      hipLaunchKernelGGL( p2_inner_kernel< C >, dim3( (unsigned) ( ( size + kThreads - 1 ) / kThreads ) ), dim3( kThreads ), 0, s, A );
+   switch ( blockIdx.y )
+   {
+   case 0:
+      p2_inner_body< 0 >( A );
+      break;
+   case 1:
+      p2_inner_body< 1 >( A );
+      break;
+   case 2:
+      p2_inner_body< 2 >( A );
+      break;
+   case 3:
+      p2_inner_body< 3 >( A );
+      break;
+   case 4:
+      p2_inner_body< 4 >( A );
+      break;
+   case 5:
+      p2_inner_body< 5 >( A );
+      break;
+   case 6:
+      p2_inner_body< 6 >( A );
+      break;
+   default:
+      p2_inner_body< 7 >( A );
+      break;
+   }
 }
 
 } // namespace
@@ -729,18 +811,12 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell( double*            dst_ve
    hipStream_t s = as_stream( stream );
    if ( mask & HYTEG_HIP_MASK_INNER )
    {
-      // inner DoFs: compile-time stencils, one launch per destination kind
+      // inner DoFs: compile-time stencils, all destination kinds in one launch
       P2FastArgs F;
       F.dstV = dst_vertex, F.dstE = dst_edge, F.srcV = src_vertex, F.srcE = src_edge, F.table = optable_dev, F.alpha = alpha;
       F.N = ( 1 << level ) + 1, F.update = update;
-      launch_inner< 0 >( F, s );
-      launch_inner< 1 >( F, s );
-      launch_inner< 2 >( F, s );
-      launch_inner< 3 >( F, s );
-      launch_inner< 4 >( F, s );
-      launch_inner< 5 >( F, s );
-      launch_inner< 6 >( F, s );
-      launch_inner< 7 >( F, s );
+      const int64_t largest = tet64( F.N );
+      hipLaunchKernelGGL( p2_inner_kernel, dim3( (unsigned) ( ( largest + kThreads - 1 ) / kThreads ), 8 ), dim3( kThreads ), 0, s, F );
    }
    if ( mask & HYTEG_HIP_MASK_SHELL )
    {
@@ -748,9 +824,13 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell( double*            dst_ve
       P2Args A;
       A.dstV = dst_vertex, A.dstE = dst_edge, A.srcV = src_vertex, A.srcE = src_edge, A.elmat = optable_dev, A.alpha = alpha;
       A.N = ( 1 << level ) + 1, A.update = update, A.mask = mask & HYTEG_HIP_MASK_SHELL, A.T = tables();
-      const int  faces = 4 * tri( A.N ); // candidates of the widest kind
-      const dim3 grid( (unsigned) ( ( faces + kThreads - 1 ) / kThreads ), 8 );
-      hipLaunchKernelGGL( p2_elementwise_kernel, grid, dim3( kThreads ), 0, s, A );
+      const int faces = 4 * tri( A.N ); // candidates of the widest kind
+      if ( level <= 5 )
+         hipLaunchKernelGGL( p2_elementwise_kernel< true >, dim3( (unsigned) ( ( faces + kThreads / 32 - 1 ) / ( kThreads / 32 ) ), 8 ),
+                             dim3( kThreads ), 0, s, A );
+      else
+         hipLaunchKernelGGL( p2_elementwise_kernel< false >, dim3( (unsigned) ( ( faces + kThreads - 1 ) / kThreads ), 8 ), dim3( kThreads ), 0,
+                             s, A );
    }
    HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;
