@@ -2,11 +2,12 @@ import sys, pathlib
 ROOT = pathlib.Path(__file__).resolve().parents[3]
 sys.path.insert(0, str(ROOT))
 import numpy as np, torch
-from hyteg_amd import capi
-from oracle import p1_oracle as po
+from hyteg_amd import capi, host
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 7
 nv, ne = capi.cell_size(L), capi.p2_edge_array_size(L)
-em = torch.from_numpy(capi.p2_build_operator_table(po.p2_cell_element_matrices(np.array([0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1.0]), L))).to("cuda")
+_st = host.Storage.from_gmsh(ROOT / "tests/golden/meshes/tet_1el.msh")
+_op = host.P2ElementwiseLaplaceOperator(_st, L, L)  # the host layer's P2LaplaceForm supplies the element matrices
+em = torch.from_numpy(capi.p2_build_operator_table(_op.element_matrices(L))).to("cuda")
 sv, se = torch.rand(nv, dtype=torch.float64, device="cuda"), torch.rand(ne, dtype=torch.float64, device="cuda")
 dv, de = torch.zeros_like(sv), torch.zeros_like(se)
 st = torch.cuda.current_stream()

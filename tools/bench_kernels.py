@@ -87,11 +87,10 @@ def main():
                                                                   T["face_w"], T["vertex_w"], 1.0, 0x3FFF, True, sh),
            40 * shell_pts, shell_pts, r=max(3, reps // 10))
     # P2 elementwise Laplace apply on one macro-cell, level 7 as in BASELINE config 4
-    from oracle import p1_oracle as po  # element matrices are kernel INPUT; the oracle's form is used to make them here
-
     L2 = min(L, 7)
     nv2, ne2 = capi.cell_size(L2), capi.p2_edge_array_size(L2)
-    em = torch.from_numpy(capi.p2_build_operator_table(po.p2_cell_element_matrices(np.array([0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1.0]), L2))).to("cuda")
+    p2op = host.P2ElementwiseLaplaceOperator(st, L2, L2)  # element matrices (kernel input) from the host layer's P2LaplaceForm
+    em = torch.from_numpy(capi.p2_build_operator_table(p2op.element_matrices(L2))).to("cuda")
     nb2 = max(2, int(1.5 * 256 * 2**20) // (2 * (nv2 + ne2) * 8) + 1)
     SV = [torch.rand(nv2, dtype=torch.float64, device="cuda") for _ in range(nb2)]
     SE = [torch.rand(ne2, dtype=torch.float64, device="cuda") for _ in range(nb2)]
