@@ -844,6 +844,27 @@ int main( int argc, char** argv )
          }
          filter = "zsoff";
       }
+      if ( want( "zabl" ) )
+      {
+         filter = "";
+         printf( "shipped 4,8,F1,SOFF: full | no stores | no arithmetic | neither ; then the same with all loads first (PFALL); then 4,4\n" );
+         run( 4, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 8, 0, 2, 0, 1, false, true, 0, true > );
+         run( 4, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 8, 4, 2, 0, 1, false, true, 0, true > );
+         run( 4, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 8, 8, 2, 0, 1, false, true, 0, true > );
+         run( 4, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 8, 12, 2, 0, 1, false, true, 0, true > );
+         run( 4, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 8, 0, 2, 0, 1, true, true, 0, true > );
+         run( 4, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 8, 4, 2, 0, 1, true, true, 0, true > );
+         run( 4, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 8, 8, 2, 0, 1, true, true, 0, true > );
+         run( 4, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 8, 12, 2, 0, 1, true, true, 0, true > );
+         run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 0, 2, 0, 1, false, true, 0, true > );
+         run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 4, 2, 0, 1, false, true, 0, true > );
+         run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 8, 2, 0, 1, false, true, 0, true > );
+         run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 12, 2, 0, 1, false, true, 0, true > );
+         run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 12, 2, 0, 1, true, true, 0, true > );
+         run( 2, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 2, 4, 12, 2, 0, 1, true, true, 0, true > );
+         run( 2, 2, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 2, 2, 12, 2, 0, 1, true, true, 0, true > );
+         filter = "zabl";
+      }
       if ( want( "zaux" ) )
       {
          filter = "";
