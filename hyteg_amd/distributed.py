@@ -35,7 +35,11 @@ class DistributedContext:
             for cls in (0, 1):
                 p = storage.plan(level, cls)
                 self.plans[(level, cls)] = p
-                if len(p["peers"]) == 0:
+                # the exchange is a collective: either every rank takes part in it or none does
+                anybody = torch.tensor([1 if len(p["peers"]) else 0], dtype=torch.int32,
+                                       device=self.device if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(anybody, op=dist.ReduceOp.MAX)
+                if int(anybody.item()) == 0:
                     continue
                 send = torch.zeros(max(1, p["total_send"]), dtype=torch.float64, device=self.device)
                 recv = torch.zeros(max(1, p["total_recv"]), dtype=torch.float64, device=self.device)
@@ -45,7 +49,7 @@ class DistributedContext:
                     in_splits[int(peer)] = int(p["send_count"][k])
                     out_splits[int(peer)] = int(p["recv_count"][k])
                 self.buffers[(level, cls)] = (send, recv, in_splits, out_splits)
-                if self.device.type == "cuda":
+                if self.device.type == "cuda" and len(p["peers"]):
                     storage.register_comm_buffers(level, cls, send.data_ptr(), recv.data_ptr())
         # gloo cannot move device tensors in all_to_all: stage through pinned host memory (test / fallback transport;
         # the production transport is RCCL, which works on the device buffers directly)

@@ -1063,21 +1063,27 @@ class P1Function
       return it->second;
    }
 
+   // The hooks are called by EVERY rank for every boundary class the flag selects, also by a rank that shares nothing
+   // with anybody in that class: the transport behind them is a collective (all_to_all), and a rank that skipped the
+   // call would dead-lock the others.  The hook itself decides (globally) whether there is anything to exchange.
    void exchangeBegin( uint_t level, DoFType flag ) const
    {
       checkLevel( level );
       if ( storage_->numRanks() == 1 )
          return;
+      if ( !storage_->hooks().exchangeBegin || !storage_->hooks().exchangeEnd )
+         throw std::runtime_error( "exchange: storage is distributed but no exchange hooks are set" );
       for ( int cls = 0; cls < 2; ++cls )
       {
-         if ( !testFlag( storage_->boundaryTypeOf( cls == 1 ), flag ) || storage_->exchangePlan( (int) level, cls ).peers.empty() )
+         if ( !testFlag( storage_->boundaryTypeOf( cls == 1 ), flag ) )
             continue;
-         const auto& plan  = storage_->devicePlan( (int) level, cls );
-         double**    bases = basesFor( level, cls );
-         hipCheck( hyteg_hip_gather_entries( plan.sendBuffer, bases, plan.dSendBuf, plan.dSendOff, plan.totalSend(), storage_->stream() ),
-                   "exchange: pack" );
-         if ( !storage_->hooks().exchangeBegin || !storage_->hooks().exchangeEnd )
-            throw std::runtime_error( "exchange: storage is distributed but no exchange hooks are set" );
+         if ( !storage_->exchangePlan( (int) level, cls ).peers.empty() )
+         {
+            const auto& plan  = storage_->devicePlan( (int) level, cls );
+            double**    bases = basesFor( level, cls );
+            hipCheck( hyteg_hip_gather_entries( plan.sendBuffer, bases, plan.dSendBuf, plan.dSendOff, plan.totalSend(), storage_->stream() ),
+                      "exchange: pack" );
+         }
          storage_->hooks().exchangeBegin( storage_->hooks().user, (int) level, cls );
       }
    }
@@ -1087,12 +1093,12 @@ class P1Function
       {
          if ( !testFlag( storage_->boundaryTypeOf( cls == 1 ), flag ) )
             continue;
+         if ( storage_->numRanks() > 1 )
+            storage_->hooks().exchangeEnd( storage_->hooks().user, (int) level, cls );
          if ( storage_->exchangePlan( (int) level, cls ).ngroups() == 0 )
             continue;
          const auto& plan  = storage_->devicePlan( (int) level, cls );
          double**    bases = basesFor( level, cls );
-         if ( !plan.peers.empty() )
-            storage_->hooks().exchangeEnd( storage_->hooks().user, (int) level, cls );
          hipCheck( additive ? hyteg_hip_sum_shared( bases, plan.dGroupPtr, plan.dEntryBuf, plan.dEntryOff, plan.ngroups(),
                                                     (int) storage_->getNumberOfLocalCells(), storage_->stream() )
                             : hyteg_hip_copy_shared( bases, plan.dGroupPtr, plan.dEntryBuf, plan.dEntryOff, plan.ngroups(),

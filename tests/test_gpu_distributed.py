@@ -110,3 +110,73 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_rank_results():
         for gid, arr in swept.items():
             assert np.allclose(arr, ref_swept[gid], rtol=1e-11, atol=1e-13), f"Gauss-Seidel sweeps differ on rank {rank}, cell {gid}"
     assert cells == 8
+
+
+# ---- a rank that shares nothing with anybody must still take part in the (collective) exchange ----
+ISOLATED_V = [[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 1], [3, 0, 0], [4, 0, 0], [3, 1, 0], [3, 0, 1]]
+ISOLATED_C = [[0, 1, 2, 3], [1, 2, 3, 4], [5, 6, 7, 8]]  # cells 0 and 1 share a face, cell 2 stands alone
+
+
+def _run_isolated(host, storage, level):
+    A = host.P1ConstantOperator(storage, level, level)
+    u, r = host.P1Function(storage, "u", level, level), host.P1Function(storage, "r", level, level)
+    for c, (gid, arr) in enumerate(_fields(host, storage, level)):
+        u.upload_cell(c, level, arr)
+    u.sync_shared(level, host.All)
+    A.apply(u, r, level, host.All)
+    dot = r.dot(r, level, host.All)
+    return {storage.local_cell(c)[0]: r.download_cell(c, level) for c in range(storage.n_local_cells)}, dot
+
+
+def _worker_isolated(rank, world, port, level, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+
+    from hyteg_amd import host
+    from hyteg_amd.distributed import DistributedContext
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        st = host.Storage.from_arrays(ISOLATED_V, ISOLATED_C, rank, world)
+        st.set_boundary_type(host.NeumannBoundary)
+        st.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx = DistributedContext(st, [level], torch.device("cuda", 0))  # noqa: F841
+        q.put((rank,) + _run_isolated(host, st, level))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_rank_without_shared_points_takes_part_in_the_exchange():
+    import torch
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, str(ROOT))
+    from hyteg_amd import host
+
+    level, world = 3, 3
+    st = host.Storage.from_arrays(ISOLATED_V, ISOLATED_C)
+    st.set_boundary_type(host.NeumannBoundary)
+    st.set_stream(torch.cuda.current_stream().cuda_stream)
+    ref, ref_dot = _run_isolated(host, st, level)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_isolated, args=(r, world, port, level, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    seen = 0
+    for rank, applied, dot in results:
+        assert abs(dot - ref_dot) <= 1e-12 * abs(ref_dot)
+        for gid, arr in applied.items():
+            # one cell per rank runs the per-cell kernels, three local cells the batched ones: other summation order
+            assert np.abs(arr - ref[gid]).max() <= 1e-13 * np.abs(ref[gid]).max()
+            seen += 1
+    assert seen == 3
