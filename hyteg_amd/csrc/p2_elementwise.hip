@@ -186,7 +186,7 @@ __device__ inline int64_t edge_block_start( int n, int kind ) { return (int64_t)
 // Boundary DoFs only, densely enumerated: the non-inner DoFs of a kind lie on faces of that kind's own tetrahedral array
 // (all four for vertex DoFs, two for X .. YZ edge DoFs, none for XYZ), so thread q walks the four triangular faces
 // (q -> face, (i,j)) and keeps a point at its lowest-numbered face.
-template < bool LANES >
+template < int G >
 __global__ __launch_bounds__( kThreads ) void p2_elementwise_kernel( const P2Args A )
 {
    const int c = blockIdx.y; // destination kind
@@ -194,12 +194,13 @@ __global__ __launch_bounds__( kThreads ) void p2_elementwise_kernel( const P2Arg
    const int W = c == 0 ? N : ( c == 7 ? n - 1 : n );
    if ( W <= 0 )
       return;
-   // LANES: 32 lanes per DoF, one per adjacent micro-cell (at most 24).  A thread per DoF walks its cells one memory round
-   // trip after the other: pure latency on small levels (39 vs 13 us at level 5); from level 6 on there are enough DoFs
-   // to hide it and the 32-fold redundant decode costs more (47 vs 115 us at level 7).
-   const int T    = tri( W );
-   const int lane = LANES ? ( threadIdx.x & 31 ) : 0;
-   const int q    = LANES ? blockIdx.x * ( kThreads / 32 ) + ( threadIdx.x >> 5 ) : blockIdx.x * kThreads + threadIdx.x;
+   // G lanes per DoF share its (at most 24) adjacent micro-cells, 24 / G each.  One thread per DoF walks 24 dependent memory
+   // round trips: pure latency (39 us at level 5, 47 us at level 7); 32 lanes per DoF repeat the decode 32 times
+   // (13 us at level 5 but 115 us at level 7); G = 8 keeps three round trips and a 8-fold decode.
+   constexpr bool LANES = G > 1;
+   const int      T     = tri( W );
+   const int      lane  = threadIdx.x & ( G - 1 );
+   const int      q     = blockIdx.x * ( kThreads / G ) + (int) threadIdx.x / G;
    if ( q >= 4 * T )
       return;
    int x, y, z;
@@ -267,15 +268,24 @@ __global__ __launch_bounds__( kThreads ) void p2_elementwise_kernel( const P2Arg
    double acc = 0.0;
    if constexpr ( LANES )
    {
-      // lane l evaluates adjacent micro-cell l; every lane of the group adds the contributions in the reference's loop order
-      double     part  = 0.0;
-      const bool valid = lane < A.T.nentries[c] && contribution( lane, part );
-      const unsigned long long vmask = __ballot( valid );
-      const int                base  = ( threadIdx.x & 63 ) & ~31; // first lane of this DoF's group inside the wave
+      // lane l evaluates micro-cells l, l + G, l + 2G, ...; every lane then adds all contributions in the reference's loop order
+      constexpr int      kSlots = 24 / G;
+      double             part[kSlots];
+      unsigned long long vmask[kSlots];
+#pragma unroll
+      for ( int k = 0; k < kSlots; ++k )
+      {
+         part[k]          = 0.0;
+         const int  l     = lane + k * G;
+         const bool valid = l < A.T.nentries[c] && contribution( l, part[k] );
+         vmask[k]         = __ballot( valid );
+      }
+      const int base = ( threadIdx.x & 63 ) & ~( G - 1 ); // first lane of this DoF's group inside the wave
+#pragma unroll
       for ( int l = 0; l < 24; ++l )
       {
-         const double p = __shfl( part, base + l, 64 );
-         if ( ( vmask >> ( base + l ) ) & 1ull )
+         const double p = __shfl( part[l / G], base + ( l % G ), 64 );
+         if ( ( vmask[l / G] >> ( base + ( l % G ) ) ) & 1ull )
             acc += p;
       }
    }
@@ -824,13 +834,10 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell( double*            dst_ve
       P2Args A;
       A.dstV = dst_vertex, A.dstE = dst_edge, A.srcV = src_vertex, A.srcE = src_edge, A.elmat = optable_dev, A.alpha = alpha;
       A.N = ( 1 << level ) + 1, A.update = update, A.mask = mask & HYTEG_HIP_MASK_SHELL, A.T = tables();
-      const int faces = 4 * tri( A.N ); // candidates of the widest kind
-      if ( level <= 5 )
-         hipLaunchKernelGGL( p2_elementwise_kernel< true >, dim3( (unsigned) ( ( faces + kThreads / 32 - 1 ) / ( kThreads / 32 ) ), 8 ),
-                             dim3( kThreads ), 0, s, A );
-      else
-         hipLaunchKernelGGL( p2_elementwise_kernel< false >, dim3( (unsigned) ( ( faces + kThreads - 1 ) / kThreads ), 8 ), dim3( kThreads ), 0,
-                             s, A );
+      const int     faces = 4 * tri( A.N ); // candidates of the widest kind
+      constexpr int G     = 8;
+      hipLaunchKernelGGL( p2_elementwise_kernel< G >, dim3( (unsigned) ( ( faces + kThreads / G - 1 ) / ( kThreads / G ) ), 8 ), dim3( kThreads ), 0,
+                          s, A );
    }
    HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;
