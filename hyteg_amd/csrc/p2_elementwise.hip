@@ -521,7 +521,16 @@ constexpr int stencil_offset( int c )
       o += stencil_count( k );
    return o;
 }
-constexpr int kOperatorTableSize = stencil_offset( 8 );
+// after the inner stencils: per destination kind, 14 boundary point classes x the same entry list (weights of neighbours
+// whose micro-cells do not exist for that class are exactly zero)
+constexpr int class_offset( int c )
+{
+   int o = stencil_offset( 8 );
+   for ( int k = 0; k < c; ++k )
+      o += 14 * stencil_count( k );
+   return o;
+}
+constexpr int kOperatorTableSize = class_offset( 8 );
 
 struct P2FastArgs
 {
@@ -700,6 +709,158 @@ __global__ __launch_bounds__( kThreads ) void p2_inner_kernel( const P2FastArgs 
    }
 }
 
+// Boundary DoFs in stencil form (levels >= 2): which adjacent micro-cells exist depends only on the macro-primitive the DoF
+// lies on, so every (destination kind, point class) has its own weight row over the SAME compile-time entry list; entries
+// whose weight is zero (neighbour outside the macro-cell, or a genuinely vanishing coupling) are skipped.  Dense enumeration
+// over the four faces of each kind's tetrahedral array as in p2_elementwise_kernel.
+template < int C, int Q >
+__device__ inline void p2_term_class( const P2FastArgs& A, const double* __restrict__ w, const RowBases& R, double& acc )
+{
+   constexpr int K = KindStencilOf< C >::value.kind[Q], DX = KindStencilOf< C >::value.dx[Q], DY = KindStencilOf< C >::value.dy[Q],
+                 DZ = KindStencilOf< C >::value.dz[Q];
+   // unconditional load from a safe index instead of a branch: all loads of a thread stay in flight together
+   const double wq  = w[Q];
+   const int    idx = wq != 0.0 ? R.b[K][DY + 1][DZ + 1] + DX : 0;
+   acc              = fma( wq, K == 0 ? A.srcV[idx] : A.srcE[idx], acc );
+}
+struct P2ClassArgs
+{
+   P2FastArgs F;
+   unsigned   mask;
+};
+template < int C >
+__device__ inline void p2_boundary_body( const P2ClassArgs& B )
+{
+   constexpr int     NQ  = KindStencilOf< C >::value.n;
+   constexpr int     OFF = class_offset( C );
+   const P2FastArgs& A   = B.F;
+   const int         N = A.N, n = N - 1;
+   const int         W = C == 0 ? N : ( C == 7 ? n - 1 : n );
+   if ( W <= 0 )
+      return;
+   const int T = tri( W );
+   const int q = blockIdx.x * kThreads + threadIdx.x;
+   if ( q >= 4 * T )
+      return;
+   int x, y, z;
+   {
+      const int f = q / T, r = q - f * T;
+      const int j = row_of( W, r );
+      const int k = r - row_start( W, j );
+      switch ( f )
+      {
+      case 0:
+         x = k, y = j, z = 0;
+         break;
+      case 1:
+         x = k, y = 0, z = j;
+         break;
+      case 2:
+         x = 0, y = k, z = j;
+         break;
+      default:
+         x = k, y = j, z = W - 1 - k - j;
+         break;
+      }
+      const int lowest = ( z == 0 ) ? 0 : ( y == 0 ) ? 1 : ( x == 0 ) ? 2 : 3;
+      if ( lowest != f )
+         return;
+   }
+   int cls;
+   if constexpr ( C == 0 )
+      cls = class_from_flags( z == 0, y == 0, x == 0, x + y + z == N - 1 );
+   else
+      cls = edge_class( N, x, y, z, C - 1 );
+   if ( cls == 14 || !( ( B.mask >> cls ) & 1u ) )
+      return;
+   const double* __restrict__ w = A.table + OFF + cls * NQ;
+   double   acc                 = 0.0;
+   RowBases R;
+   [&]< int... K >( std::integer_sequence< int, K... > ) { ( p2_row_bases_of_kind< C, K >( R, N, n, x, y, z ), ... ); }
+   ( std::make_integer_sequence< int, 8 >{} );
+   [&]< int... Q >( std::integer_sequence< int, Q... > ) { ( p2_term_class< C, Q >( A, w, R, acc ), ... ); }
+   ( std::make_integer_sequence< int, NQ >{} );
+   acc            = A.alpha * acc;
+   const int i    = cell_index( W, x, y, z );
+   double*   out  = C == 0 ? A.dstV + i : A.dstE + edge_block_start( n, C ) + i;
+   *out           = A.update == HYTEG_HIP_ADD ? *out + acc : acc;
+}
+__global__ __launch_bounds__( kThreads ) void p2_boundary_kernel( const P2ClassArgs B )
+{
+   switch ( blockIdx.y )
+   {
+   case 0:
+      p2_boundary_body< 0 >( B );
+      break;
+   case 1:
+      p2_boundary_body< 1 >( B );
+      break;
+   case 2:
+      p2_boundary_body< 2 >( B );
+      break;
+   case 3:
+      p2_boundary_body< 3 >( B );
+      break;
+   case 4:
+      p2_boundary_body< 4 >( B );
+      break;
+   case 5:
+      p2_boundary_body< 5 >( B );
+      break;
+   case 6:
+      p2_boundary_body< 6 >( B );
+      break;
+   default:
+      p2_boundary_body< 7 >( B );
+      break;
+   }
+}
+
+// host: does micro-cell (type t, index m) lie inside a macro-cell of width N?
+bool micro_cell_inside( int t, int mx, int my, int mz, int N )
+{
+   for ( int v = 0; v < 4; ++v )
+   {
+      const int x = mx + cMicroVerts[t][v][0], y = my + cMicroVerts[t][v][1], z = mz + cMicroVerts[t][v][2];
+      if ( x < 0 || y < 0 || z < 0 || x + y + z > N - 1 )
+         return false;
+   }
+   return true;
+}
+int host_class_of( int c, int x, int y, int z, int N )
+{
+   static const int ends[7][2][3] = { { { 0, 0, 0 }, { 1, 0, 0 } }, { { 0, 0, 0 }, { 0, 1, 0 } }, { { 0, 0, 0 }, { 0, 0, 1 } },
+                                      { { 1, 0, 0 }, { 0, 1, 0 } }, { { 1, 0, 0 }, { 0, 0, 1 } }, { { 0, 1, 0 }, { 0, 0, 1 } },
+                                      { { 0, 1, 0 }, { 1, 0, 1 } } };
+   int f[4] = { 1, 1, 1, 1 };
+   const int npts = c == 0 ? 1 : 2;
+   for ( int e = 0; e < npts; ++e )
+   {
+      const int px = x + ( c == 0 ? 0 : ends[c - 1][e][0] ), py = y + ( c == 0 ? 0 : ends[c - 1][e][1] ), pz = z + ( c == 0 ? 0 : ends[c - 1][e][2] );
+      f[0] &= pz == 0, f[1] &= py == 0, f[2] &= px == 0, f[3] &= px + py + pz == N - 1;
+   }
+   const int cnt = f[0] + f[1] + f[2] + f[3];
+   if ( cnt == 0 )
+      return 14;
+   if ( cnt == 1 )
+      return 6 + ( f[0] ? 0 : f[1] ? 1 : f[2] ? 2 : 3 );
+   if ( cnt == 2 )
+   {
+      if ( f[0] )
+         return f[1] ? 0 : ( f[2] ? 1 : 2 );
+      if ( f[1] )
+         return f[2] ? 3 : 4;
+      return 5;
+   }
+   if ( f[0] && f[1] && f[2] )
+      return 10;
+   if ( f[0] && f[1] && f[3] )
+      return 11;
+   if ( f[0] && f[2] && f[3] )
+      return 12;
+   return 13;
+}
+
 } // namespace
 
 extern "C" {
@@ -732,6 +893,38 @@ HYTEG_HIP_API int hyteg_hip_p2_build_operator_table( const double* elmat_host, d
                      w[q] += elmat_host[100 * t + 10 * k + j];
             }
          }
+      // boundary classes: the adjacent micro-cells that exist are read off a representative DoF of that class at level 3
+      const int Nr = 9, nr = 8, Wr = c == 0 ? Nr : ( c == 7 ? nr - 1 : nr );
+      double*   wc = table_host + class_offset( c );
+      for ( int k = 0; k < 14 * S.n; ++k )
+         wc[k] = 0.0;
+      for ( int cls = 0; cls < 14; ++cls )
+      {
+         bool found = false;
+         for ( int z = 0; z < Wr && !found; ++z )
+            for ( int y = 0; y < Wr - z && !found; ++y )
+               for ( int x = 0; x < Wr - z - y && !found; ++x )
+               {
+                  if ( host_class_of( c, x, y, z, Nr ) != cls )
+                     continue;
+                  found = true;
+                  for ( int t = 0; t < 6; ++t )
+                     for ( int k = 0; k < 10; ++k )
+                     {
+                        const CLocal row = c_local( t, k );
+                        if ( row.kind != c || !micro_cell_inside( t, x - row.ox, y - row.oy, z - row.oz, Nr ) )
+                           continue;
+                        for ( int j = 0; j < 10; ++j )
+                        {
+                           const CLocal col = c_local( t, j );
+                           const int    dx = col.ox - row.ox, dy = col.oy - row.oy, dz = col.oz - row.oz;
+                           for ( int q = 0; q < S.n; ++q )
+                              if ( S.kind[q] == col.kind && S.dx[q] == dx && S.dy[q] == dy && S.dz[q] == dz )
+                                 wc[cls * S.n + q] += elmat_host[100 * t + 10 * k + j];
+                        }
+                     }
+               }
+      }
    }
    return HYTEG_HIP_OK;
 }
@@ -828,9 +1021,18 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell( double*            dst_ve
       const int64_t largest = tet64( F.N );
       hipLaunchKernelGGL( p2_inner_kernel, dim3( (unsigned) ( ( largest + kThreads - 1 ) / kThreads ), 8 ), dim3( kThreads ), 0, s, F );
    }
-   if ( mask & HYTEG_HIP_MASK_SHELL )
+   if ( ( mask & HYTEG_HIP_MASK_SHELL ) && level >= 2 )
    {
-      // DoFs on the macro-cell boundary: micro-cell by micro-cell gather (the adjacent cells that exist differ from DoF to DoF)
+      // DoFs on the macro-cell boundary: per-class constant stencils
+      P2ClassArgs B;
+      B.F.dstV = dst_vertex, B.F.dstE = dst_edge, B.F.srcV = src_vertex, B.F.srcE = src_edge, B.F.table = optable_dev, B.F.alpha = alpha;
+      B.F.N = ( 1 << level ) + 1, B.F.update = update, B.mask = mask & HYTEG_HIP_MASK_SHELL;
+      const int faces = 4 * tri( B.F.N );
+      hipLaunchKernelGGL( p2_boundary_kernel, dim3( (unsigned) ( ( faces + kThreads - 1 ) / kThreads ), 8 ), dim3( kThreads ), 0, s, B );
+   }
+   else if ( mask & HYTEG_HIP_MASK_SHELL )
+   {
+      // levels 0 and 1: a DoF can be next to several macro-faces at once; micro-cell by micro-cell gather in the reference's order
       P2Args A;
       A.dstV = dst_vertex, A.dstE = dst_edge, A.srcV = src_vertex, A.srcE = src_edge, A.elmat = optable_dev, A.alpha = alpha;
       A.N = ( 1 << level ) + 1, A.update = update, A.mask = mask & HYTEG_HIP_MASK_SHELL, A.T = tables();
