@@ -65,16 +65,16 @@ SIGNATURES = {
     "hyteg_host_solver_destroy": (_i, [_vp]),
     "hyteg_host_p2function_create": (_i, [_vp, C.c_char_p, _i, _i, C.POINTER(_vp)]),
     "hyteg_host_p2function_destroy": (_i, [_vp]),
-    "hyteg_host_p2function_pointers": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp)]),
-    "hyteg_host_p2function_upload": (_i, [_vp, _i, _vp, _vp]),
-    "hyteg_host_p2function_download": (_i, [_vp, _i, _vp, _vp]),
+    "hyteg_host_p2function_pointers": (_i, [_vp, _i, _i, C.POINTER(_vp), C.POINTER(_vp)]),
+    "hyteg_host_p2function_upload": (_i, [_vp, _i, _i, _vp, _vp]),
+    "hyteg_host_p2function_download": (_i, [_vp, _i, _i, _vp, _vp]),
     "hyteg_host_p2function_interpolate_constant": (_i, [_vp, _d, _i, _i]),
     "hyteg_host_p2function_assign": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(_vp), _i, _i]),
     "hyteg_host_p2function_add": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(_vp), _i, _i]),
     "hyteg_host_p2function_dot": (_i, [_vp, _vp, _i, _i, C.POINTER(_d)]),
     "hyteg_host_p2operator_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
     "hyteg_host_p2operator_destroy": (_i, [_vp]),
-    "hyteg_host_p2operator_element_matrices": (_i, [_vp, _i, _vp]),
+    "hyteg_host_p2operator_element_matrices": (_i, [_vp, _i, _i, _vp]),
     "hyteg_host_p2operator_apply": (_i, [_vp, _vp, _vp, _i, _i, _i]),
     "hyteg_host_p2_cg_solve": (_i, [_vp, _vp, _vp, _vp, _i, _i, _d, C.POINTER(_i)]),
 }
@@ -363,16 +363,16 @@ class P2Function:
 
         return cell_size(level), capi.p2_edge_array_size(level)
 
-    def upload(self, level, vertex, edge):
+    def upload(self, level, vertex, edge, cell=0):
         v = np.ascontiguousarray(vertex, dtype=np.float64)
         e = np.ascontiguousarray(edge, dtype=np.float64)
         assert (v.size, e.size) == self.sizes(level)
-        _ck(lib().hyteg_host_p2function_upload(self.h, level, v.ctypes.data, e.ctypes.data), "P2Function.upload")
+        _ck(lib().hyteg_host_p2function_upload(self.h, cell, level, v.ctypes.data, e.ctypes.data), "P2Function.upload")
 
-    def download(self, level):
+    def download(self, level, cell=0):
         nv, ne = self.sizes(level)
         v, e = np.empty(nv), np.empty(max(ne, 1))
-        _ck(lib().hyteg_host_p2function_download(self.h, level, v.ctypes.data, e.ctypes.data), "P2Function.download")
+        _ck(lib().hyteg_host_p2function_download(self.h, cell, level, v.ctypes.data, e.ctypes.data), "P2Function.download")
         return v, e[:ne]
 
     def interpolate(self, value, level, flag=All):
@@ -408,9 +408,9 @@ class P2ElementwiseLaplaceOperator:
         _ck(lib().hyteg_host_p2operator_create(storage.h, min_level, max_level, C.byref(h)), "P2ElementwiseLaplaceOperator")
         self.h = h
 
-    def element_matrices(self, level):
+    def element_matrices(self, level, cell=0):
         out = np.empty(600)
-        _ck(lib().hyteg_host_p2operator_element_matrices(self.h, level, out.ctypes.data), "element_matrices")
+        _ck(lib().hyteg_host_p2operator_element_matrices(self.h, cell, level, out.ctypes.data), "element_matrices")
         return out.reshape(6, 10, 10)
 
     def apply(self, src: P2Function, dst: P2Function, level, flag, update=Replace):

@@ -545,18 +545,19 @@ class PrimitiveStorage
    };
 
    // host part of the plan (no GPU needed)
-   const ExchangePlan& exchangePlan( int level, int cls ) const
+   // dofKind 0: vertex DoFs (P1 arrays); 1: edge DoFs (the edge-DoF arrays of P2 functions)
+   const ExchangePlan& exchangePlan( int level, int cls, int dofKind = 0 ) const
    {
-      auto key = std::make_pair( level, cls );
+      auto key = std::make_pair( level, cls + 2 * dofKind );
       auto it  = plans_.find( key );
       if ( it == plans_.end() )
-         it = plans_.emplace( key, buildPlan( level, cls ) ).first;
+         it = plans_.emplace( key, buildPlan( level, cls, dofKind ) ).first;
       return it->second;
    }
    // plan with its index arrays (and default communication buffers) resident on the device
-   const ExchangePlan& devicePlan( int level, int cls ) const
+   const ExchangePlan& devicePlan( int level, int cls, int dofKind = 0 ) const
    {
-      auto& P = const_cast< ExchangePlan& >( exchangePlan( level, cls ) );
+      auto& P = const_cast< ExchangePlan& >( exchangePlan( level, cls, dofKind ) );
       if ( !P.onDevice )
       {
          P.dGroupPtr = uploadVector( P.groupPtr );
@@ -621,7 +622,46 @@ class PrimitiveStorage
       return layout::cellIndex( N, bary[1], bary[2], bary[3] );
    }
 
-   ExchangePlan buildPlan( int level, int cls ) const
+   // array index in the edge-DoF array of cell `c` of the edge DoF between the points with barycentric weights wa, wb on the
+   // primitive's vertices (edgedof::calcEdgeDoFIndex / calcEdgeDoFOrientation, EdgeDoFIndexing.hpp:89-165, + macrocell::index)
+   static int64_t edgeIndexInCell( const MacroCell& c, const MacroPrimitive& p, const int* wa, const int* wb, int level )
+   {
+      int64_t a[4] = { 0, 0, 0, 0 }, b[4] = { 0, 0, 0, 0 };
+      for ( uint_t k = 0; k < p.v.size(); ++k )
+      {
+         int l = -1;
+         for ( int q = 0; q < 4; ++q )
+            if ( c.v[q] == p.v[k] )
+               l = q;
+         if ( l < 0 )
+            throw std::runtime_error( "edgeIndexInCell: primitive is not part of the cell" );
+         a[l] = wa[k], b[l] = wb[k];
+      }
+      const int64_t* A  = a + 1; // (x, y, z) = weights of cell vertices 1, 2, 3
+      const int64_t* B  = b + 1;
+      const int64_t  d0 = B[0] - A[0], d1 = B[1] - A[1], d2 = B[2] - A[2];
+      const int64_t  n  = int64_t( 1 ) << level;
+      int            o;
+      int64_t        e[3];
+      auto           lower = [&]( int axis ) { return A[axis] < B[axis] ? A : B; };
+      if ( d1 == 0 && d2 == 0 )
+         o = 0, e[0] = lower( 0 )[0], e[1] = lower( 0 )[1], e[2] = lower( 0 )[2];
+      else if ( d0 == 0 && d2 == 0 )
+         o = 1, e[0] = lower( 1 )[0], e[1] = lower( 1 )[1], e[2] = lower( 1 )[2];
+      else if ( d0 == 0 && d1 == 0 )
+         o = 2, e[0] = lower( 2 )[0], e[1] = lower( 2 )[1], e[2] = lower( 2 )[2];
+      else if ( d2 == 0 )
+         o = 3, e[0] = lower( 0 )[0], e[1] = lower( 0 )[1] - 1, e[2] = lower( 0 )[2];
+      else if ( d1 == 0 )
+         o = 4, e[0] = lower( 0 )[0], e[1] = lower( 0 )[1], e[2] = lower( 0 )[2] - 1;
+      else if ( d0 == 0 )
+         o = 5, e[0] = lower( 1 )[0], e[1] = lower( 1 )[1], e[2] = lower( 1 )[2] - 1;
+      else
+         o = 6, e[0] = lower( 0 )[0], e[1] = lower( 0 )[1] - 1, e[2] = lower( 0 )[2];
+      return o * layout::tet( n ) + layout::cellIndex( o == 6 ? n - 1 : n, e[0], e[1], e[2] );
+   }
+
+   ExchangePlan buildPlan( int level, int cls, int dofKind = 0 ) const
    {
       ExchangePlan  P;
       const int64_t N = layout::width( level ), n = N - 1;
@@ -659,15 +699,49 @@ class PrimitiveStorage
       P.recvCount.assign( P.peers.size(), 0 );
       std::vector< std::vector< int > > sendBufPer( P.peers.size() ), sendOffPer( P.peers.size() );
 
-      // enumerate the interior points of a primitive in a rank-independent order
+      // enumerate the DoFs that belong to a primitive in a rank-independent order: fn( wa, wb ) with the barycentric
+      // weights of the point (vertex DoF, wb unused) or of the two end points of the micro-edge (edge DoF)
       auto pointsOf = [&]( const MacroPrimitive& p, auto&& fn ) {
+         if ( dofKind == 1 )
+         {
+            if ( p.v.size() == 3 )
+            {
+               // micro-edges in the plane of the face whose end points do not lie on one and the same macro-edge of the face
+               auto emit = [&]( int64_t i0, int64_t j0, int64_t i1, int64_t j1 ) {
+                  const int wa[3] = { (int) ( n - i0 - j0 ), (int) i0, (int) j0 }, wb[3] = { (int) ( n - i1 - j1 ), (int) i1, (int) j1 };
+                  for ( int k = 0; k < 3; ++k )
+                     if ( wa[k] == 0 && wb[k] == 0 )
+                        return;
+                  fn( wa, wb );
+               };
+               for ( int64_t j = 0; j <= n; ++j )
+                  for ( int64_t i = 0; i + j <= n; ++i )
+                  {
+                     if ( i + j + 1 <= n )
+                     {
+                        emit( i, j, i + 1, j );
+                        emit( i, j, i, j + 1 );
+                        emit( i + 1, j, i, j + 1 );
+                     }
+                  }
+            }
+            else if ( p.v.size() == 2 )
+            {
+               for ( int64_t i = 0; i <= n - 1; ++i )
+               {
+                  const int wa[2] = { (int) ( n - i ), (int) i }, wb[2] = { (int) ( n - i - 1 ), (int) ( i + 1 ) };
+                  fn( wa, wb );
+               }
+            }
+            return;
+         }
          if ( p.v.size() == 3 )
          {
             for ( int64_t j = 1; j <= n - 2; ++j )
                for ( int64_t i = 1; i + j <= n - 1; ++i )
                {
                   const int w[3] = { (int) ( n - i - j ), (int) i, (int) j };
-                  fn( w );
+                  fn( w, w );
                }
          }
          else if ( p.v.size() == 2 )
@@ -675,13 +749,13 @@ class PrimitiveStorage
             for ( int64_t i = 1; i <= n - 1; ++i )
             {
                const int w[2] = { (int) ( n - i ), (int) i };
-               fn( w );
+               fn( w, w );
             }
          }
          else
          {
             const int w[1] = { (int) n };
-            fn( w );
+            fn( w, w );
          }
       };
 
@@ -693,13 +767,13 @@ class PrimitiveStorage
          bool local;
          if ( !involves( p, local ) || !local )
             return;
-         pointsOf( p, [&]( const int* w ) {
+         pointsOf( p, [&]( const int* w, const int* wb ) {
             for ( int c : p.cells )
             {
                const MacroCell& cell = cells_[c];
                if ( cell.rank == rank_ )
                {
-                  const int off = (int) indexInCell( cell, p, w, N );
+                  const int off = dofKind == 1 ? (int) edgeIndexInCell( cell, p, w, wb, level ) : (int) indexInCell( cell, p, w, N );
                   P.entryBuf.push_back( cell.localIndex );
                   P.entryOff.push_back( off );
                   // this value goes to every peer that shares the group
@@ -1133,44 +1207,51 @@ class P2Function
    , maxLevel_( maxLevel )
    , vertexDoFFunction_( name + "_VertexDoF", storage, minLevel, maxLevel )
    {
-      if ( storage->getCells().size() != 1 || storage->numRanks() != 1 )
-         throw std::runtime_error( "P2Function: only storages with a single macro-cell are supported in this version" );
+      if ( storage->numRanks() != 1 )
+         throw std::runtime_error( "P2Function: storages distributed over several ranks are not supported in this version" );
       if ( maxLevel > HYTEG_HIP_P2_MAX_LEVEL )
          throw std::runtime_error( "P2Function: level out of range" );
-      for ( uint_t l = minLevel; l <= maxLevel; ++l )
-      {
-         const size_t bytes = std::max< size_t >( 1, hyteg_hip_p2_edge_array_size( (int) l ) ) * sizeof( double );
-         void*        q     = nullptr;
-         hipCheck( hyteg_hip_malloc( &q, bytes ), "P2Function: malloc" );
-         hipCheck( hyteg_hip_memset_zero( q, bytes, storage->stream() ), "P2Function: memset" );
-         edge_.push_back( static_cast< double* >( q ) );
-      }
+      edge_.resize( storage->getNumberOfLocalCells() );
+      for ( auto& perCell : edge_ )
+         for ( uint_t l = minLevel; l <= maxLevel; ++l )
+         {
+            const size_t bytes = std::max< size_t >( 1, hyteg_hip_p2_edge_array_size( (int) l ) ) * sizeof( double );
+            void*        q     = nullptr;
+            hipCheck( hyteg_hip_malloc( &q, bytes ), "P2Function: malloc" );
+            hipCheck( hyteg_hip_memset_zero( q, bytes, storage->stream() ), "P2Function: memset" );
+            perCell.push_back( static_cast< double* >( q ) );
+         }
    }
    ~P2Function()
    {
-      for ( double* q : edge_ )
-         hyteg_hip_free( q );
+      for ( auto& perCell : edge_ )
+         for ( double* q : perCell )
+            hyteg_hip_free( q );
+      for ( auto& kv : edgeBases_ )
+         hyteg_hip_free( kv.second );
    }
    P2Function( const P2Function& )            = delete;
    P2Function& operator=( const P2Function& ) = delete;
 
    const P1Function< ValueType >&      getVertexDoFFunction() const { return vertexDoFFunction_; }
    std::shared_ptr< PrimitiveStorage > getStorage() const { return storage_; }
-   // device pointer of the edge-DoF array of local cell c (= 0)
+   // device pointer of the edge-DoF array of local cell c
    double* getEdgeCellPointer( uint_t c, uint_t level ) const
    {
-      if ( c != 0 || level < minLevel_ || level > maxLevel_ )
+      if ( c >= edge_.size() || level < minLevel_ || level > maxLevel_ )
          throw std::runtime_error( "P2Function '" + name_ + "': bad cell or level" );
-      return edge_[level - minLevel_];
+      return edge_[c][level - minLevel_];
    }
    uint_t getNumberOfEdgeDoFs( uint_t level ) const { return hyteg_hip_p2_edge_array_size( (int) level ); }
 
    void interpolate( ValueType constant, uint_t level, DoFType flag = All ) const
    {
       vertexDoFFunction_.interpolate( constant, level, flag );
-      hipCheck( hyteg_hip_p2_edge_vector_cell_masked( 3, getEdgeCellPointer( 0, level ), 0, nullptr, &constant, (int) level, mask( flag ),
-                                                      storage_->stream() ),
-                "P2Function::interpolate" );
+      forCells( [&]( uint_t c, const MacroCell& cell ) {
+         hipCheck( hyteg_hip_p2_edge_vector_cell_masked( 3, getEdgeCellPointer( c, level ), 0, nullptr, &constant, (int) level,
+                                                         storage_->maskFor( cell, flag ), storage_->stream() ),
+                   "P2Function::interpolate" );
+      } );
    }
    // expression evaluated at the micro-vertices and at the edge midpoints (EdgeDoFFunction::interpolate)
    void interpolate( const std::function< ValueType( const Point3D& ) >& expr, uint_t level, DoFType flag = All ) const
@@ -1179,35 +1260,46 @@ class P2Function
       static const int ends[7][2][3] = { { { 0, 0, 0 }, { 1, 0, 0 } }, { { 0, 0, 0 }, { 0, 1, 0 } }, { { 0, 0, 0 }, { 0, 0, 1 } },
                                          { { 1, 0, 0 }, { 0, 1, 0 } }, { { 1, 0, 0 }, { 0, 0, 1 } }, { { 0, 1, 0 }, { 0, 0, 1 } },
                                          { { 0, 1, 0 }, { 1, 0, 1 } } };
-      const MacroCell&      cell = storage_->getLocalCell( 0 );
-      const int64_t         n    = int64_t( 1 ) << level;
-      const double          step = 1.0 / double( n );
-      std::vector< double > host;
-      host.reserve( getNumberOfEdgeDoFs( level ) );
-      for ( int o = 0; o < 7; ++o )
-      {
-         const int64_t W = o == 6 ? n - 1 : n;
-         for ( int64_t z = 0; z < W; ++z )
-            for ( int64_t y = 0; y < W - z; ++y )
-               for ( int64_t x = 0; x < W - z - y; ++x )
-               {
-                  const double mx = double( x ) + 0.5 * ( ends[o][0][0] + ends[o][1][0] ), my = double( y ) + 0.5 * ( ends[o][0][1] + ends[o][1][1] ),
-                               mz = double( z ) + 0.5 * ( ends[o][0][2] + ends[o][1][2] );
-                  Point3D      q;
-                  for ( int r = 0; r < 3; ++r )
-                     q[r] = cell.coords[0][r] + ( cell.coords[1][r] - cell.coords[0][r] ) * step * mx +
-                            ( cell.coords[2][r] - cell.coords[0][r] ) * step * my + ( cell.coords[3][r] - cell.coords[0][r] ) * step * mz;
-                  host.push_back( expr( q ) );
-               }
-      }
-      double* tmp = storage_->acquireScratch( std::max< size_t >( 1, host.size() ) );
-      hipCheck( hyteg_hip_upload( tmp, host.data(), host.size() * sizeof( double ), storage_->stream() ), "P2Function::interpolate: upload" );
-      const double* srcs[1] = { tmp };
-      const double  one[1]  = { 1.0 };
-      hipCheck( hyteg_hip_p2_edge_vector_cell_masked( 0, getEdgeCellPointer( 0, level ), 1, srcs, one, (int) level, mask( flag ), storage_->stream() ),
-                "P2Function::interpolate: assign" );
+      const int64_t n    = int64_t( 1 ) << level;
+      const double  step = 1.0 / double( n );
+      const size_t  ne   = std::max< size_t >( 1, getNumberOfEdgeDoFs( level ) );
+      std::vector< double* > tmp;
+      forCells( [&]( uint_t, const MacroCell& cell ) {
+         std::vector< double > host;
+         host.reserve( ne );
+         for ( int o = 0; o < 7; ++o )
+         {
+            const int64_t W = o == 6 ? n - 1 : n;
+            for ( int64_t z = 0; z < W; ++z )
+               for ( int64_t y = 0; y < W - z; ++y )
+                  for ( int64_t x = 0; x < W - z - y; ++x )
+                  {
+                     const double mx = double( x ) + 0.5 * ( ends[o][0][0] + ends[o][1][0] ), my = double( y ) + 0.5 * ( ends[o][0][1] + ends[o][1][1] ),
+                                  mz = double( z ) + 0.5 * ( ends[o][0][2] + ends[o][1][2] );
+                     Point3D      q;
+                     for ( int r = 0; r < 3; ++r )
+                        q[r] = cell.coords[0][r] + ( cell.coords[1][r] - cell.coords[0][r] ) * step * mx +
+                               ( cell.coords[2][r] - cell.coords[0][r] ) * step * my + ( cell.coords[3][r] - cell.coords[0][r] ) * step * mz;
+                     host.push_back( expr( q ) );
+                  }
+         }
+         double* t = storage_->acquireScratch( ne );
+         hipCheck( hyteg_hip_upload( t, host.data(), host.size() * sizeof( double ), storage_->stream() ), "P2Function::interpolate: upload" );
+         hipCheck( hyteg_hip_stream_synchronize( storage_->stream() ), "P2Function::interpolate: sync" );
+         tmp.push_back( t );
+      } );
+      // the copies of a shared edge DoF were evaluated from different cells' coordinates: make them bit-identical
+      exchangeEdges( tmp, level, All, false );
+      forCells( [&]( uint_t c, const MacroCell& cell ) {
+         const double* srcs[1] = { tmp[c] };
+         const double  one[1]  = { 1.0 };
+         hipCheck( hyteg_hip_p2_edge_vector_cell_masked( 0, getEdgeCellPointer( c, level ), 1, srcs, one, (int) level,
+                                                         storage_->maskFor( cell, flag ), storage_->stream() ),
+                   "P2Function::interpolate: assign" );
+      } );
       hipCheck( hyteg_hip_stream_synchronize( storage_->stream() ), "P2Function::interpolate: sync" );
-      storage_->releaseScratch( std::max< size_t >( 1, host.size() ), tmp );
+      for ( double* t : tmp )
+         storage_->releaseScratch( ne, t );
    }
    void setToZero( uint_t level ) const { interpolate( ValueType( 0 ), level, All ); }
 
@@ -1225,61 +1317,109 @@ class P2Function
    {
       vectorOp( 1, scalars, functions, level, flag );
    }
+   // a shared DoF is counted by its lowest-numbered neighbour cell only
    ValueType dotLocal( const P2Function< ValueType >& rhs, uint_t level, DoFType flag = All ) const
    {
-      double v = vertexDoFFunction_.dotLocal( rhs.vertexDoFFunction_, level, flag );
-      hipCheck( hyteg_hip_p2_edge_dot_cell_masked( getEdgeCellPointer( 0, level ), rhs.getEdgeCellPointer( 0, level ), (int) level, mask( flag ),
-                                                   storage_->dotResult(), storage_->dotWorkspace(), storage_->stream() ),
-                "P2Function::dotLocal" );
-      double e = 0.0;
-      hipCheck( hyteg_hip_download( &e, storage_->dotResult(), sizeof( double ), storage_->stream() ), "P2Function::dotLocal: download" );
-      return v + e;
+      double       sum = vertexDoFFunction_.dotLocal( rhs.vertexDoFFunction_, level, flag );
+      const uint_t nl  = storage_->getNumberOfLocalCells();
+      forCells( [&]( uint_t c, const MacroCell& cell ) {
+         hipCheck( hyteg_hip_p2_edge_dot_cell_masked( getEdgeCellPointer( c, level ), rhs.getEdgeCellPointer( c, level ), (int) level,
+                                                      storage_->ownedMaskFor( cell, flag ), storage_->dotResult() + c, storage_->dotWorkspace(),
+                                                      storage_->stream() ),
+                   "P2Function::dotLocal" );
+      } );
+      std::vector< double > parts( nl, 0.0 );
+      hipCheck( hyteg_hip_download( parts.data(), storage_->dotResult(), nl * sizeof( double ), storage_->stream() ), "P2Function::dotLocal: download" );
+      for ( double v : parts )
+         sum += v;
+      return sum;
    }
    ValueType dotGlobal( const P2Function< ValueType >& rhs, uint_t level, DoFType flag = All ) const { return dotLocal( rhs, level, flag ); }
 
-   void copyEdgeToHost( uint_t level, double* host ) const
+   // every copy of a shared edge DoF := sum of all copies (communicateAdditively< Cell, Face / Edge > of the EdgeDoFFunction)
+   void sumSharedEdgeCopies( uint_t level, DoFType flag = All ) const
    {
-      hipCheck( hyteg_hip_download( host, getEdgeCellPointer( 0, level ), getNumberOfEdgeDoFs( level ) * sizeof( double ), storage_->stream() ),
+      std::vector< double* > arrays;
+      forCells( [&]( uint_t c, const MacroCell& ) { arrays.push_back( getEdgeCellPointer( c, level ) ); } );
+      exchangeEdges( arrays, level, flag, true );
+   }
+
+   void copyEdgeToHost( uint_t c, uint_t level, double* host ) const
+   {
+      hipCheck( hyteg_hip_download( host, getEdgeCellPointer( c, level ), getNumberOfEdgeDoFs( level ) * sizeof( double ), storage_->stream() ),
                 "P2Function::copyEdgeToHost" );
    }
-   void copyEdgeFromHost( uint_t level, const double* host ) const
+   void copyEdgeFromHost( uint_t c, uint_t level, const double* host ) const
    {
-      hipCheck( hyteg_hip_upload( getEdgeCellPointer( 0, level ), host, getNumberOfEdgeDoFs( level ) * sizeof( double ), storage_->stream() ),
+      hipCheck( hyteg_hip_upload( getEdgeCellPointer( c, level ), host, getNumberOfEdgeDoFs( level ) * sizeof( double ), storage_->stream() ),
                 "P2Function::copyEdgeFromHost" );
       hipCheck( hyteg_hip_stream_synchronize( storage_->stream() ), "P2Function::copyEdgeFromHost: sync" );
    }
 
  private:
-   unsigned mask( DoFType flag ) const { return storage_->maskFor( storage_->getLocalCell( 0 ), flag ); }
-   void     vectorOp( int                                                                       op,
-                      const std::vector< ValueType >&                                           scalars,
-                      const std::vector< std::reference_wrapper< const P2Function< ValueType > > >& functions,
-                      uint_t                                                                    level,
-                      DoFType                                                                   flag ) const
+   template < typename F >
+   void forCells( F&& fn ) const
+   {
+      for ( uint_t c = 0; c < storage_->getNumberOfLocalCells(); ++c )
+         fn( c, storage_->getLocalCell( c ) );
+   }
+   // additive (or copy) exchange of the shared edge DoFs held in `arrays` (one edge-DoF array per local cell)
+   void exchangeEdges( const std::vector< double* >& arrays, uint_t level, DoFType flag, bool additive ) const
+   {
+      for ( int cls = 0; cls < 2; ++cls )
+      {
+         if ( !testFlag( storage_->boundaryTypeOf( cls == 1 ), flag ) || storage_->exchangePlan( (int) level, cls, 1 ).ngroups() == 0 )
+            continue;
+         const auto& plan = storage_->devicePlan( (int) level, cls, 1 );
+         // device table of the array pointers; cached per (first pointer) because temporaries come and go
+         auto   key = std::make_pair( arrays[0], cls );
+         auto   it  = edgeBases_.find( key );
+         if ( it == edgeBases_.end() )
+         {
+            void* d = nullptr;
+            hipCheck( hyteg_hip_malloc( &d, arrays.size() * sizeof( double* ) ), "edge bases: malloc" );
+            it = edgeBases_.emplace( key, static_cast< double** >( d ) ).first;
+         }
+         hipCheck( hyteg_hip_upload( it->second, arrays.data(), arrays.size() * sizeof( double* ), storage_->stream() ), "edge bases: upload" );
+         hipCheck( hyteg_hip_stream_synchronize( storage_->stream() ), "edge bases: sync" );
+         hipCheck( additive ? hyteg_hip_sum_shared( it->second, plan.dGroupPtr, plan.dEntryBuf, plan.dEntryOff, plan.ngroups(),
+                                                    (int) arrays.size(), storage_->stream() )
+                            : hyteg_hip_copy_shared( it->second, plan.dGroupPtr, plan.dEntryBuf, plan.dEntryOff, plan.ngroups(),
+                                                     (int) arrays.size(), storage_->stream() ),
+                   "edge exchange" );
+      }
+   }
+   void vectorOp( int                                                                       op,
+                  const std::vector< ValueType >&                                           scalars,
+                  const std::vector< std::reference_wrapper< const P2Function< ValueType > > >& functions,
+                  uint_t                                                                    level,
+                  DoFType                                                                   flag ) const
    {
       if ( functions.empty() || functions.size() > HYTEG_HIP_MAX_SRCS || scalars.size() != functions.size() )
          throw std::runtime_error( "P2Function::assign/add: bad number of functions or scalars" );
       std::vector< std::reference_wrapper< const P1Function< ValueType > > > vs;
-      const double*                                                          es[HYTEG_HIP_MAX_SRCS];
       for ( uint_t k = 0; k < functions.size(); ++k )
-      {
          vs.push_back( functions[k].get().vertexDoFFunction_ );
-         es[k] = functions[k].get().getEdgeCellPointer( 0, level );
-      }
       if ( op == 0 )
          vertexDoFFunction_.assign( scalars, vs, level, flag );
       else
          vertexDoFFunction_.add( scalars, vs, level, flag );
-      hipCheck( hyteg_hip_p2_edge_vector_cell_masked( op, getEdgeCellPointer( 0, level ), (int) functions.size(), es, scalars.data(), (int) level,
-                                                      mask( flag ), storage_->stream() ),
-                "P2Function vector op" );
+      forCells( [&]( uint_t c, const MacroCell& cell ) {
+         const double* es[HYTEG_HIP_MAX_SRCS];
+         for ( uint_t k = 0; k < functions.size(); ++k )
+            es[k] = functions[k].get().getEdgeCellPointer( c, level );
+         hipCheck( hyteg_hip_p2_edge_vector_cell_masked( op, getEdgeCellPointer( c, level ), (int) functions.size(), es, scalars.data(), (int) level,
+                                                         storage_->maskFor( cell, flag ), storage_->stream() ),
+                   "P2Function vector op" );
+      } );
    }
 
-   std::string                         name_;
-   std::shared_ptr< PrimitiveStorage > storage_;
-   uint_t                              minLevel_, maxLevel_;
-   P1Function< ValueType >             vertexDoFFunction_;
-   std::vector< double* >              edge_;
+   std::string                                            name_;
+   std::shared_ptr< PrimitiveStorage >                    storage_;
+   uint_t                                                 minLevel_, maxLevel_;
+   P1Function< ValueType >                                vertexDoFFunction_;
+   std::vector< std::vector< double* > >                  edge_; // [local cell][level - minLevel]
+   mutable std::map< std::pair< double*, int >, double** > edgeBases_;
 };
 
 // =====================================================================================================
@@ -1997,62 +2137,90 @@ class P2ElementwiseOperator
    , minLevel_( minLevel )
    , maxLevel_( maxLevel )
    {
-      if ( storage->getCells().size() != 1 || storage->numRanks() != 1 )
-         throw std::runtime_error( "P2ElementwiseOperator: only storages with a single macro-cell are supported in this version" );
+      if ( storage->numRanks() != 1 )
+         throw std::runtime_error( "P2ElementwiseOperator: storages distributed over several ranks are not supported in this version" );
       // micro-cell vertex offsets of the six cell types, celldof::macrocell::getMicroVerticesFromMicroCell (CellDoFIndexing.hpp:155-198)
       static const int verts[6][4][3] = {
           { { 0, 0, 0 }, { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } }, { { 1, 0, 0 }, { 1, 1, 0 }, { 0, 1, 0 }, { 1, 0, 1 } },
           { { 1, 0, 0 }, { 0, 1, 0 }, { 1, 0, 1 }, { 0, 0, 1 } }, { { 1, 1, 0 }, { 1, 1, 1 }, { 0, 1, 1 }, { 1, 0, 1 } },
           { { 1, 0, 1 }, { 0, 1, 1 }, { 0, 0, 1 }, { 0, 1, 0 } }, { { 0, 1, 0 }, { 1, 1, 0 }, { 1, 0, 1 }, { 0, 1, 1 } } };
-      const MacroCell& cell = storage->getLocalCell( 0 );
       for ( uint_t l = minLevel; l <= maxLevel; ++l )
-      {
-         const double          step = 1.0 / double( int64_t( 1 ) << l );
-         std::vector< double > h( 600 );
-         for ( int t = 0; t < 6; ++t )
+         for ( uint_t lc = 0; lc < storage->getNumberOfLocalCells(); ++lc )
          {
-            std::array< Point3D, 4 > c;
-            for ( int k = 0; k < 4; ++k )
-               for ( int r = 0; r < 3; ++r )
-                  c[k][r] = cell.coords[0][r] + ( cell.coords[1][r] - cell.coords[0][r] ) * step * verts[t][k][0] +
-                            ( cell.coords[2][r] - cell.coords[0][r] ) * step * verts[t][k][1] +
-                            ( cell.coords[3][r] - cell.coords[0][r] ) * step * verts[t][k][2];
-            P2Form::integrateAll( c, h.data() + 100 * t );
+            const MacroCell&      cell = storage->getLocalCell( lc );
+            const double          step = 1.0 / double( int64_t( 1 ) << l );
+            std::vector< double > h( 600 );
+            for ( int t = 0; t < 6; ++t )
+            {
+               std::array< Point3D, 4 > c;
+               for ( int k = 0; k < 4; ++k )
+                  for ( int r = 0; r < 3; ++r )
+                     c[k][r] = cell.coords[0][r] + ( cell.coords[1][r] - cell.coords[0][r] ) * step * verts[t][k][0] +
+                               ( cell.coords[2][r] - cell.coords[0][r] ) * step * verts[t][k][1] +
+                               ( cell.coords[3][r] - cell.coords[0][r] ) * step * verts[t][k][2];
+               P2Form::integrateAll( c, h.data() + 100 * t );
+            }
+            std::vector< double > table( hyteg_hip_p2_operator_table_size() );
+            hipCheck( hyteg_hip_p2_build_operator_table( h.data(), table.data() ), "P2ElementwiseOperator: operator table" );
+            elementMatrices_[l].push_back( storage->uploadTable( table ) );
+            hostMatrices_[l].push_back( h );
          }
-         std::vector< double > table( hyteg_hip_p2_operator_table_size() );
-         hipCheck( hyteg_hip_p2_build_operator_table( h.data(), table.data() ), "P2ElementwiseOperator: operator table" );
-         elementMatrices_[l] = storage->uploadTable( table );
-         hostMatrices_[l]    = h;
-      }
    }
    std::shared_ptr< PrimitiveStorage > getStorage() const { return storage_; }
-   const std::vector< double >&        getElementMatrices( uint_t level ) const { return hostMatrices_.at( level ); }
+   const std::vector< double >&        getElementMatrices( uint_t level, uint_t localCell = 0 ) const { return hostMatrices_.at( level ).at( localCell ); }
 
    // Operator::apply = gemv( 1, src, updateType == Replace ? 0 : 1, dst ), P2ElementwiseOperator.hpp:60-75
    void apply( const P2Function< double >& src, const P2Function< double >& dst, uint_t level, DoFType flag, UpdateType updateType = Replace ) const
    {
       gemv( 1.0, src, updateType == Replace ? 0.0 : 1.0, dst, level, flag );
    }
+   // every cell adds the contributions of its own micro-cells; on DoFs shared by several cells these are partial sums that the
+   // additive exchange completes (communicateAdditively< Cell, ... > at the end of the reference's gemv, :225-235)
    void gemv( double alpha, const P2Function< double >& src, double beta, const P2Function< double >& dst, uint_t level, DoFType flag ) const
    {
       if ( &src == &dst )
          throw std::runtime_error( "P2ElementwiseOperator::gemv: src and dst must differ" );
-      if ( beta != 0.0 && beta != 1.0 )
-         dst.assign( { beta }, { dst }, level, flag );
-      const MacroCell& cell = storage_->getLocalCell( 0 );
-      hipCheck( hyteg_hip_p2_elementwise_apply_cell( dst.getVertexDoFFunction().getCellPointer( 0, level ), dst.getEdgeCellPointer( 0, level ),
-                                                     src.getVertexDoFFunction().getCellPointer( 0, level ), src.getEdgeCellPointer( 0, level ),
-                                                     (int) level, elementMatrices_.at( level ), alpha,
-                                                     beta == 0.0 ? HYTEG_HIP_REPLACE : HYTEG_HIP_ADD, storage_->maskFor( cell, flag ),
-                                                     storage_->stream() ),
-                "P2ElementwiseOperator::gemv" );
+      const bool shared = storage_->getNumberOfLocalCells() > 1;
+      if ( !shared )
+      {
+         if ( beta != 0.0 && beta != 1.0 )
+            dst.assign( { beta }, { dst }, level, flag );
+         launch( alpha, src, dst, level, flag, HYTEG_HIP_MASK_ALL, beta == 0.0 ? HYTEG_HIP_REPLACE : HYTEG_HIP_ADD );
+         return;
+      }
+      if ( beta == 0.0 )
+      {
+         launch( alpha, src, dst, level, flag, HYTEG_HIP_MASK_ALL, HYTEG_HIP_REPLACE );
+         dst.getVertexDoFFunction().sumSharedCopies( level, flag );
+         dst.sumSharedEdgeCopies( level, flag );
+         return;
+      }
+      // beta != 0: the summed shares of the shared DoFs are formed in a temporary and then added
+      P2Function< double > tmp( "p2_gemv_tmp", storage_, level, level );
+      launch( alpha, src, tmp, level, flag, HYTEG_HIP_MASK_ALL, HYTEG_HIP_REPLACE );
+      tmp.getVertexDoFFunction().sumSharedCopies( level, flag );
+      tmp.sumSharedEdgeCopies( level, flag );
+      dst.assign( { beta, 1.0 }, { dst, tmp }, level, flag );
    }
 
  private:
-   std::shared_ptr< PrimitiveStorage >          storage_;
-   uint_t                                       minLevel_, maxLevel_;
-   std::map< uint_t, const double* >            elementMatrices_;
-   std::map< uint_t, std::vector< double > >    hostMatrices_;
+   void launch( double alpha, const P2Function< double >& src, const P2Function< double >& dst, uint_t level, DoFType flag, unsigned keep,
+                int update ) const
+   {
+      for ( uint_t c = 0; c < storage_->getNumberOfLocalCells(); ++c )
+      {
+         const MacroCell& cell = storage_->getLocalCell( c );
+         hipCheck( hyteg_hip_p2_elementwise_apply_cell( dst.getVertexDoFFunction().getCellPointer( c, level ), dst.getEdgeCellPointer( c, level ),
+                                                        src.getVertexDoFFunction().getCellPointer( c, level ), src.getEdgeCellPointer( c, level ),
+                                                        (int) level, elementMatrices_.at( level ).at( c ), alpha, update,
+                                                        storage_->maskFor( cell, flag ) & keep, storage_->stream() ),
+                   "P2ElementwiseOperator::gemv" );
+      }
+   }
+   std::shared_ptr< PrimitiveStorage >                          storage_;
+   uint_t                                                       minLevel_, maxLevel_;
+   std::map< uint_t, std::vector< const double* > >             elementMatrices_;
+   std::map< uint_t, std::vector< std::vector< double > > >     hostMatrices_;
 };
 using P2ElementwiseLaplaceOperator = P2ElementwiseOperator< forms::P2LaplaceForm >; // P2ElementwiseOperator.hpp:454
 

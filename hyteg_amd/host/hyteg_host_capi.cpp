@@ -375,25 +375,25 @@ HYTEG_HOST_API int hyteg_host_p2function_destroy( hh_p2function_t f )
 {
    return guarded( [&] { delete static_cast< P2FunctionH* >( f ); } );
 }
-HYTEG_HOST_API int hyteg_host_p2function_pointers( hh_p2function_t f, int level, double** vertex_dev, double** edge_dev )
+HYTEG_HOST_API int hyteg_host_p2function_pointers( hh_p2function_t f, int local_cell, int level, double** vertex_dev, double** edge_dev )
 {
    return guarded( [&] {
-      *vertex_dev = F2( f ).getVertexDoFFunction().getCellPointer( 0, (uint_t) level );
-      *edge_dev   = F2( f ).getEdgeCellPointer( 0, (uint_t) level );
+      *vertex_dev = F2( f ).getVertexDoFFunction().getCellPointer( (uint_t) local_cell, (uint_t) level );
+      *edge_dev   = F2( f ).getEdgeCellPointer( (uint_t) local_cell, (uint_t) level );
    } );
 }
-HYTEG_HOST_API int hyteg_host_p2function_upload( hh_p2function_t f, int level, const double* vertex_host, const double* edge_host )
+HYTEG_HOST_API int hyteg_host_p2function_upload( hh_p2function_t f, int local_cell, int level, const double* vertex_host, const double* edge_host )
 {
    return guarded( [&] {
-      F2( f ).getVertexDoFFunction().copyCellFromHost( 0, (uint_t) level, vertex_host );
-      F2( f ).copyEdgeFromHost( (uint_t) level, edge_host );
+      F2( f ).getVertexDoFFunction().copyCellFromHost( (uint_t) local_cell, (uint_t) level, vertex_host );
+      F2( f ).copyEdgeFromHost( (uint_t) local_cell, (uint_t) level, edge_host );
    } );
 }
-HYTEG_HOST_API int hyteg_host_p2function_download( hh_p2function_t f, int level, double* vertex_host, double* edge_host )
+HYTEG_HOST_API int hyteg_host_p2function_download( hh_p2function_t f, int local_cell, int level, double* vertex_host, double* edge_host )
 {
    return guarded( [&] {
-      F2( f ).getVertexDoFFunction().copyCellToHost( 0, (uint_t) level, vertex_host );
-      F2( f ).copyEdgeToHost( (uint_t) level, edge_host );
+      F2( f ).getVertexDoFFunction().copyCellToHost( (uint_t) local_cell, (uint_t) level, vertex_host );
+      F2( f ).copyEdgeToHost( (uint_t) local_cell, (uint_t) level, edge_host );
    } );
 }
 HYTEG_HOST_API int hyteg_host_p2function_interpolate_constant( hh_p2function_t f, double value, int level, int flag )
@@ -422,10 +422,10 @@ HYTEG_HOST_API int hyteg_host_p2operator_destroy( hh_p2operator_t op )
 {
    return guarded( [&] { delete static_cast< P2OperatorH* >( op ); } );
 }
-HYTEG_HOST_API int hyteg_host_p2operator_element_matrices( hh_p2operator_t op, int level, double* out600 )
+HYTEG_HOST_API int hyteg_host_p2operator_element_matrices( hh_p2operator_t op, int local_cell, int level, double* out600 )
 {
    return guarded( [&] {
-      const auto& h = static_cast< P2OperatorH* >( op )->p->getElementMatrices( (uint_t) level );
+      const auto& h = static_cast< P2OperatorH* >( op )->p->getElementMatrices( (uint_t) level, (uint_t) local_cell );
       std::copy( h.begin(), h.end(), out600 );
    } );
 }

@@ -99,21 +99,21 @@ HYTEG_HOST_API int hyteg_host_cg_create( hh_storage_t s, int min_level, int max_
 HYTEG_HOST_API int hyteg_host_solver_solve( hh_solver_t solver, hh_operator_t laplace, hh_function_t x, hh_function_t b, int level );
 HYTEG_HOST_API int hyteg_host_solver_destroy( hh_solver_t solver );
 
-/* ---- P2Function / P2ElementwiseLaplaceOperator on storages with ONE macro-cell (first version) ----
+/* ---- P2Function / P2ElementwiseLaplaceOperator (first version): any number of macro-cells on ONE rank ----
  * vertex part: the P1 cell array; edge part: hyteg_hip_p2_edge_array_size( level ) doubles (EdgeDoFIndexing.hpp:920-985) */
 HYTEG_HOST_API int hyteg_host_p2function_create( hh_storage_t s, const char* name, int min_level, int max_level, hh_p2function_t* out );
 HYTEG_HOST_API int hyteg_host_p2function_destroy( hh_p2function_t f );
-HYTEG_HOST_API int hyteg_host_p2function_pointers( hh_p2function_t f, int level, double** vertex_dev, double** edge_dev );
-HYTEG_HOST_API int hyteg_host_p2function_upload( hh_p2function_t f, int level, const double* vertex_host, const double* edge_host );
-HYTEG_HOST_API int hyteg_host_p2function_download( hh_p2function_t f, int level, double* vertex_host, double* edge_host );
+HYTEG_HOST_API int hyteg_host_p2function_pointers( hh_p2function_t f, int local_cell, int level, double** vertex_dev, double** edge_dev );
+HYTEG_HOST_API int hyteg_host_p2function_upload( hh_p2function_t f, int local_cell, int level, const double* vertex_host, const double* edge_host );
+HYTEG_HOST_API int hyteg_host_p2function_download( hh_p2function_t f, int local_cell, int level, double* vertex_host, double* edge_host );
 HYTEG_HOST_API int hyteg_host_p2function_interpolate_constant( hh_p2function_t f, double value, int level, int flag );
 HYTEG_HOST_API int hyteg_host_p2function_assign( hh_p2function_t dst, int n, const double* scalars, const hh_p2function_t* srcs, int level, int flag );
 HYTEG_HOST_API int hyteg_host_p2function_add( hh_p2function_t dst, int n, const double* scalars, const hh_p2function_t* srcs, int level, int flag );
 HYTEG_HOST_API int hyteg_host_p2function_dot( hh_p2function_t a, hh_p2function_t b, int level, int flag, double* result );
 HYTEG_HOST_API int hyteg_host_p2operator_create( hh_storage_t s, int min_level, int max_level, hh_p2operator_t* out );
 HYTEG_HOST_API int hyteg_host_p2operator_destroy( hh_p2operator_t op );
-/* the six 10 x 10 element matrices (FEniCS ordering) of the single cell at `level` */
-HYTEG_HOST_API int hyteg_host_p2operator_element_matrices( hh_p2operator_t op, int level, double* out600 );
+/* the six 10 x 10 element matrices (FEniCS ordering) of a local cell at `level` */
+HYTEG_HOST_API int hyteg_host_p2operator_element_matrices( hh_p2operator_t op, int local_cell, int level, double* out600 );
 HYTEG_HOST_API int hyteg_host_p2operator_apply( hh_p2operator_t op, hh_p2function_t src, hh_p2function_t dst, int level, int flag, int update );
 /* CGSolver< P2ElementwiseLaplaceOperator > on one level, flags Inner | NeumannBoundary as in the reference's CGSolver */
 HYTEG_HOST_API int hyteg_host_p2_cg_solve( hh_storage_t s, hh_p2operator_t op, hh_p2function_t x, hh_p2function_t b, int level, int max_iter,

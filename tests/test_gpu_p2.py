@@ -119,3 +119,119 @@ def test_p2_host_layer_solves_a_dirichlet_problem_exactly(env):
     assert abs(d - ((ev[inner_v] ** 2).sum() + (ee[inner_e] ** 2).sum())) < 1e-11 * d
     for o in (x, b, r, exact, A, st):
         o.close()
+
+
+# ---- several macro-cells (one rank): shares of the DoFs on common faces / edges are summed by the additive exchange ----
+def _p2_fields(host, st, level, fn, po):
+    import hostutil as hu
+
+    out = []
+    for c in range(st.n_local_cells):
+        gid, co, nnc = st.local_cell(c)
+        out.append((fn(hu.cell_points(co, level)), fn(po.edge_midpoints(co, level))))
+    return out
+
+
+@pytest.mark.parametrize("mesh", ["cube_6el", "regular_octahedron_8el", "pyramid_2el"])
+def test_p2_multi_cell_apply_matches_the_cell_by_cell_oracle(env, mesh):
+    """every cell's contributions from the oracle, shared DoFs matched through global keys (end points for edge DoFs) and summed"""
+    torch, capi, po = env
+    import hostutil as hu
+    from hyteg_amd import host
+
+    level = 2
+    v, c = hu.read_msh(hu.MESHES / f"{mesh}.msh")
+    glob = hu.GlobalSweepOracle(v, c, level)  # only its global vertex numbering is used
+    st = host.Storage.from_gmsh(hu.MESHES / f"{mesh}.msh")
+    A = host.P2ElementwiseLaplaceOperator(st, level, level)
+    src, dst = host.P2Function(st, "src", level, level), host.P2Function(st, "dst", level, level)
+    rng = np.random.default_rng(5)
+    ncell, N = st.n_local_cells, (1 << level) + 1
+    ec = po.edge_coords(level)
+    ends = np.array([[[0, 0, 0], [1, 0, 0]], [[0, 0, 0], [0, 1, 0]], [[0, 0, 0], [0, 0, 1]], [[1, 0, 0], [0, 1, 0]],
+                     [[1, 0, 0], [0, 0, 1]], [[0, 1, 0], [0, 0, 1]], [[0, 1, 0], [1, 0, 1]]])
+    # global values: one random number per physical DoF
+    gv = rng.standard_normal(glob.ndof)
+    ekeys = []
+    for cell in range(ncell):
+        keys = []
+        for x, y, z, o in ec:
+            a = glob.gidx[cell][po.cell_index(level, *(np.array([x, y, z]) + ends[o][0]))]
+            b = glob.gidx[cell][po.cell_index(level, *(np.array([x, y, z]) + ends[o][1]))]
+            keys.append((min(a, b), max(a, b)))
+        ekeys.append(keys)
+    evals = {}
+    for keys in ekeys:
+        for k in keys:
+            evals.setdefault(k, rng.standard_normal())
+    for cell in range(ncell):
+        src.upload(level, gv[glob.gidx[cell]], np.array([evals[k] for k in ekeys[cell]]), cell)
+    flag = host.Inner
+    dst.interpolate(5.0, level)
+    A.apply(src, dst, level, flag)
+    # oracle: per-cell contributions, summed over copies
+    tot_v, tot_e = np.zeros(glob.ndof), {}
+    parts = []
+    for cell in range(ncell):
+        gid, co, nnc = st.local_cell(cell)
+        em = po.p2_cell_element_matrices(np.asarray(co).reshape(12), level)
+        mask = st.mask(cell, flag)
+        pv, pe = po.p2_elementwise_apply_cell(np.zeros(po.cell_size(level)), np.zeros(po.edge_array_size(level)), gv[glob.gidx[cell]],
+                                              np.array([evals[k] for k in ekeys[cell]]), level, em, 1.0, 0, mask)
+        parts.append((pv, pe, mask))
+        np.add.at(tot_v, glob.gidx[cell], pv)
+        for k, val in zip(ekeys[cell], pe):
+            tot_e[k] = tot_e.get(k, 0.0) + val
+    scale = max(np.abs(tot_v).max(), max(abs(x) for x in tot_e.values()))
+    for cell in range(ncell):
+        gv_, ge_ = dst.download(level, cell)
+        mask = parts[cell][2]
+        sel_v = ((mask >> po.slot_of_points(level)) & 1).astype(bool)
+        sel_e = ((mask >> po.edge_classes(level)) & 1).astype(bool)
+        want_v = tot_v[glob.gidx[cell]]
+        want_e = np.array([tot_e[k] for k in ekeys[cell]])
+        assert np.abs(gv_[sel_v] - want_v[sel_v]).max() <= 1e-12 * scale
+        assert np.abs(ge_[sel_e] - want_e[sel_e]).max() <= 1e-12 * scale
+        assert np.all(gv_[~sel_v] == 5.0) and np.all(ge_[~sel_e] == 5.0)
+    for o in (src, dst, A, st):
+        o.close()
+
+
+def test_p2_on_the_unit_cube_known_answers_and_cg(env):
+    """cube_6el = the unit cube: u^T A u = int |grad u|^2 (4/3 for x^2, every DoF counted once); a harmonic quadratic has zero
+    residual at every inner DoF, also on the faces between the macro-cells; CG recovers it from its boundary values"""
+    torch, capi, po = env
+    import hostutil as hu
+    from hyteg_amd import host
+
+    level = 3
+    st = host.Storage.from_gmsh(hu.MESHES / "cube_6el.msh")
+    A = host.P2ElementwiseLaplaceOperator(st, level, level)
+    u, r, x, b = (host.P2Function(st, n, level, level) for n in ("u", "r", "x", "b"))
+    # energy with every DoF in the operator (Neumann boundary type: no DoF is excluded)
+    st.set_boundary_type(host.NeumannBoundary)
+    for cell, (fv, fe) in enumerate(_p2_fields(host, st, level, lambda p: p[:, 0] ** 2, po)):
+        u.upload(level, fv, fe, cell)
+    A.apply(u, r, level, host.All)
+    assert abs(u.dot(r, level, host.All) - 4.0 / 3.0) < 1e-11
+    # Dirichlet problem
+    st.set_boundary_type(host.DirichletBoundary)
+    harmonic = lambda p: p[:, 0] ** 2 - 0.5 * p[:, 1] ** 2 - 0.5 * p[:, 2] ** 2 + p[:, 1] * p[:, 2] - p[:, 0]  # noqa: E731
+    exact = _p2_fields(host, st, level, harmonic, po)
+    for cell, (fv, fe) in enumerate(exact):
+        u.upload(level, fv, fe, cell)
+    r.interpolate(0.0, level)
+    A.apply(u, r, level, host.Inner)
+    assert r.dot(r, level, host.Inner) < 1e-22
+    for cell, (fv, fe) in enumerate(exact):
+        mask = st.mask(cell, host.Inner)
+        iv = ((mask >> po.slot_of_points(level)) & 1).astype(bool)
+        ie = ((mask >> po.edge_classes(level)) & 1).astype(bool)
+        x.upload(level, np.where(iv, 0.0, fv), np.where(ie, 0.0, fe), cell)
+    its = A.cg_solve(x, b, level, 1000, 1e-13)
+    assert 0 < its < 1000
+    for cell, (fv, fe) in enumerate(exact):
+        gv, ge = x.download(level, cell)
+        assert np.abs(gv - fv).max() < 1e-9 and np.abs(ge - fe).max() < 1e-9
+    for o in (u, r, x, b, A, st):
+        o.close()
