@@ -865,6 +865,23 @@ int main( int argc, char** argv )
          run( 2, 2, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 2, 2, 12, 2, 0, 1, true, true, 0, true > );
          filter = "zabl";
       }
+      if ( want( "zmodes2" ) )
+      {
+         filter = "";
+         printf( "SOFF kernels, EX_AUX=2: ADD 4,4 | 4,8 | 2,8 | 4,6 ; JACOBI 4,4 | 4,8 | 2,8 | 4,6 (rhs = another src buffer: partly cache-resident)\n" );
+         for ( int rep = 0; rep < 2; ++rep )
+         {
+            run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_ADD, 4, 4, 0, 2, 0, 1, false, true, 2, true > );
+            run( 4, 8, 1, p1_apply_zmarch_kernel< APPLY_ADD, 4, 8, 0, 2, 0, 1, false, true, 2, true > );
+            run( 2, 8, 1, p1_apply_zmarch_kernel< APPLY_ADD, 2, 8, 0, 2, 0, 1, false, true, 2, true > );
+            run( 4, 6, 1, p1_apply_zmarch_kernel< APPLY_ADD, 4, 6, 0, 2, 0, 1, false, true, 2, true > );
+            run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_JACOBI, 4, 4, 0, 2, 0, 1, false, true, 2, true > );
+            run( 4, 8, 1, p1_apply_zmarch_kernel< APPLY_JACOBI, 4, 8, 0, 2, 0, 1, false, true, 2, true > );
+            run( 2, 8, 1, p1_apply_zmarch_kernel< APPLY_JACOBI, 2, 8, 0, 2, 0, 1, false, true, 2, true > );
+            run( 4, 6, 1, p1_apply_zmarch_kernel< APPLY_JACOBI, 4, 6, 0, 2, 0, 1, false, true, 2, true > );
+         }
+         filter = "zmodes2";
+      }
       if ( want( "zaux" ) )
       {
          filter = "";

@@ -38,10 +38,12 @@ int launch_zmarch_lz( double* dst, const double* src, const double* rhs, const d
    int nblocks = ( bt.count + kZMarchWavesPerBlock - 1 ) / kZMarchWavesPerBlock;
    nblocks     = ( nblocks + 7 ) & ~7;
    A.xcd_chunk = nblocks / 8;
-   // nontemporal stores, plain source loads, factorised lane shifts, loads masked beyond the row end; the arrays that
-   // are read exactly once (dst of Add, rhs / inverse diagonal of Jacobi) are loaded nontemporal (Add: 18.6 -> 17.2 us)
-   // ... and scalar-offset addressing with clamped loads and a one-compare store predicate (SOFF: -15% instructions)
-   hipLaunchKernelGGL( ( p1_apply_zmarch_kernel< MODE, kBrickNY, LZ, 0, kStoreAuxDefault, 0, 1, false, true, 2, true > ),
+   // nontemporal stores, plain source loads, factorised lane shifts, scalar-offset addressing with clamped loads and a
+   // one-compare store predicate (SOFF).  dst of Add is read exactly once per element and written right after: nontemporal
+   // load (18.6 -> 17.2 us).  rhs / inverse diagonal of Jacobi are re-read by the next sweep of the smoother and stay plain
+   // (nontemporal: 12.4 -> 17.6 us when they are still in the Infinity Cache, -2% when they are not).
+   constexpr int kExAux = MODE == APPLY_ADD ? 2 : 0;
+   hipLaunchKernelGGL( ( p1_apply_zmarch_kernel< MODE, kBrickNY, LZ, 0, kStoreAuxDefault, 0, 1, false, true, kExAux, true > ),
                        dim3( nblocks ),
                        dim3( 64 * kZMarchWavesPerBlock ),
                        0,
@@ -55,8 +57,7 @@ template < int MODE >
 int launch_zmarch( double* dst, const double* src, const double* rhs, const double* invdiag, int level, const double* w,
                    double relax, hipStream_t stream )
 {
-   // Add / Jacobi stream one or two more arrays through the same registers: 4 x 4 stays best for them (level 8: 17.4 vs 19.0 us)
-   if ( MODE == APPLY_REPLACE && brick_lz( level ) == 8 )
+   if ( brick_lz( level ) == 8 )
       return launch_zmarch_lz< MODE, 8 >( dst, src, rhs, invdiag, level, w, relax, stream );
    return launch_zmarch_lz< MODE, 4 >( dst, src, rhs, invdiag, level, w, relax, stream );
 }
