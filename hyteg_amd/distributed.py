@@ -30,6 +30,7 @@ class DistributedContext:
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
         self.buffers = {}
+        self._views = {}
         self.plans = {}
         for level in levels:
             for cls in (0, 1):
@@ -48,7 +49,9 @@ class DistributedContext:
                 for k, peer in enumerate(p["peers"]):
                     in_splits[int(peer)] = int(p["send_count"][k])
                     out_splits[int(peer)] = int(p["recv_count"][k])
+                # views and split lists are built once: the hooks run once per operator application
                 self.buffers[(level, cls)] = (send, recv, in_splits, out_splits)
+                self._views[(level, cls)] = (send[:sum(in_splits)], recv[:sum(out_splits)])
                 if self.device.type == "cuda" and len(p["peers"]):
                     storage.register_comm_buffers(level, cls, send.data_ptr(), recv.data_ptr())
         # gloo cannot move device tensors in all_to_all: stage through pinned host memory (test / fallback transport;
@@ -78,7 +81,8 @@ class DistributedContext:
             work = dist.all_to_all_single(host_recv, host_send, out_splits, in_splits, async_op=True)
             self._pending[(level, cls)] = (work, host_recv, recv, n_out)
         else:
-            self._pending[(level, cls)] = dist.all_to_all_single(recv[:n_out], send[:n_in], out_splits, in_splits, async_op=True)
+            send_v, recv_v = self._views[(level, cls)]
+            self._pending[(level, cls)] = dist.all_to_all_single(recv_v, send_v, out_splits, in_splits, async_op=True)
 
     def exchange_end(self, level: int, cls: int) -> None:
         work = self._pending.pop((level, cls), None)
