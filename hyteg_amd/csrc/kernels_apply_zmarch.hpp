@@ -50,7 +50,10 @@ struct ZMarchArgs
    Stencil15        st;
 };
 
-constexpr int kZMarchWavesPerBlock = 4;
+#ifndef HYTEG_ZM_WAVES_PER_BLOCK
+#define HYTEG_ZM_WAVES_PER_BLOCK 4
+#endif
+constexpr int kZMarchWavesPerBlock = HYTEG_ZM_WAVES_PER_BLOCK; // 1, 2, 8 measured within noise of 4 at level 8
 
 typedef int zm_v2i_t __attribute__( ( ext_vector_type( 2 ) ) );
 
