@@ -415,3 +415,32 @@ def test_cg_solves_the_coarse_problem(env):
     assert np.sqrt(r.dot(r, level, host.Inner)) < 1e-10 * np.sqrt(xe.dot(xe, level, host.Inner))
     for o in (cg, x, b, r, xe, A, st):
         o.close()
+
+
+def test_w_cycle_converges_at_least_as_fast_as_the_v_cycle(env):
+    """GeometricMultigridSolver.hpp:265-275: the W-cycle visits the coarser level twice per level"""
+    torch, capi, host, po = env
+    from hostutil import MultiCellOracle, upload
+
+    def residuals(wcycle):
+        st = _storage(host, "pyramid_4el")
+        mo = MultiCellOracle(st)
+        lo, hi = 1, 4
+        A = host.P1ConstantOperator(st, lo, hi)
+        A.compute_inverse_diagonal()
+        x, b, r = (host.P1Function(st, n, lo, hi) for n in ("x", "b", "r"))
+        upload(x, mo.interpolate(lambda X, Y, Z: np.sin(7 * X) * np.cos(3 * Y) + Z, hi), hi)
+        x.interpolate(0.0, hi, host.DirichletBoundary)
+        gmg = host.Solver.gmg(st, lo, hi, smoother=host.GAUSS_SEIDEL, relax=1.0, pre=1, post=1, wcycle=wcycle)
+        out = []
+        for _ in range(3):
+            gmg.solve(A, x, b, hi)
+            A.apply(x, r, hi, host.Inner)
+            out.append(r.dot(r, hi, host.Inner))
+        for o in (gmg, x, b, r, A, st):
+            o.close()
+        return out
+
+    v, w = residuals(False), residuals(True)
+    assert all(b < a for a, b in zip(v, v[1:])) and all(b < a for a, b in zip(w, w[1:]))
+    assert w[-1] <= v[-1] * 1.0000001
