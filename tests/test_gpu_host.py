@@ -188,12 +188,14 @@ def test_laplace_annihilates_constants_and_linears_on_multi_cell_meshes(env, mes
 
 @pytest.mark.parametrize("mesh", ["regular_octahedron_8el", "pyramid_tilted_4el", "cube_6el"])
 @pytest.mark.parametrize("flag", ["Inner", "All"])
-def test_apply_matches_the_multi_cell_oracle(env, mesh, flag):
+@pytest.mark.parametrize("batch", [6, -1])
+def test_apply_matches_the_multi_cell_oracle(env, mesh, flag, batch):
     torch, capi, host, po = env
     from hostutil import MultiCellOracle, download, upload
 
     level = 3
     st = _storage(host, mesh)
+    st.set_batch_max_level(batch)  # batched launches (p1_batch.hip) / one launch per cell and kernel
     mo = MultiCellOracle(st)
     fl = getattr(host, flag)
     A = host.P1ConstantOperator(st, level, level)

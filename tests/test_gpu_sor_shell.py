@@ -95,7 +95,8 @@ def test_sor_shell_cell_rejects_bad_descriptors(env):
 @pytest.mark.parametrize("mesh,level", [("regular_octahedron_8el", 2), ("regular_octahedron_8el", 3), ("cube_6el", 3),
                                         ("pyramid_tilted_4el", 4), ("pyramid_2el", 1)])
 @pytest.mark.parametrize("backwards", [False, True])
-def test_host_smooth_sor_matches_the_global_schedule(env, mesh, level, backwards):
+@pytest.mark.parametrize("batch", [6, -1])
+def test_host_smooth_sor_matches_the_global_schedule(env, mesh, level, backwards, batch):
     torch, capi, host, po = env
     import hostutil as hu
 
@@ -104,6 +105,7 @@ def test_host_smooth_sor_matches_the_global_schedule(env, mesh, level, backwards
     rng = np.random.default_rng(level)
     u, b = rng.standard_normal(glob.ndof), rng.standard_normal(glob.ndof)
     st = host.Storage.from_gmsh(hu.MESHES / f"{mesh}.msh")
+    st.set_batch_max_level(batch)  # 6: one launch for all cells (p1_batch.hip); -1: one launch per cell and kernel
     A = host.P1ConstantOperator(st, level, level)
     x, rhs = host.P1Function(st, "x", level, level), host.P1Function(st, "b", level, level)
     for relax in (1.0, 1.2):
