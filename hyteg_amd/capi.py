@@ -37,6 +37,7 @@ SIGNATURES = {
     "hyteg_hip_p1_apply_cell": (_i, [_vp, _vp, _i, _dp, _i, _vp]),
     "hyteg_hip_p1_jacobi_cell": (_i, [_vp, _vp, _vp, _vp, _i, _dp, _d, _vp]),
     "hyteg_hip_p1_sor_cell": (_i, [_vp, _vp, _i, _dp, _d, _i, _vp]),
+    "hyteg_hip_set_sor_algorithm": (_i, [_i]),
     "hyteg_hip_p1_assign_cell": (_i, [_vp, _i, C.POINTER(_vp), _dp, _i, _vp]),
     "hyteg_hip_p1_add_cell": (_i, [_vp, _i, C.POINTER(_vp), _dp, _i, _vp]),
     "hyteg_hip_p1_mult_cell": (_i, [_vp, _i, C.POINTER(_vp), _i, _vp]),
@@ -147,6 +148,14 @@ def p1_apply_cell(dst, src, level, w, update=REPLACE, stream=0):
 def p1_jacobi_cell(dst, rhs, src, level, w, relax, invdiag=None, stream=0):
     check(lib().hyteg_hip_p1_jacobi_cell(dst, rhs, src, invdiag, level, _w15(w), float(relax), stream),
           "p1_jacobi_cell")
+
+
+SOR_AUTO, SOR_PLANES, SOR_BLOCKS, SOR_DATAFLOW = 0, 1, 2, 3
+
+
+def set_sor_algorithm(algorithm: int) -> None:
+    """hyteg_hip_set_sor_algorithm: how the cell sweeps are executed (tests / benchmarks; default SOR_AUTO)"""
+    check(lib().hyteg_hip_set_sor_algorithm(int(algorithm)), "set_sor_algorithm")
 
 
 def p1_sor_cell(u, rhs, level, w, relax, backwards=False, stream=0):

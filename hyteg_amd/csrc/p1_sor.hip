@@ -12,7 +12,10 @@
 #include <mutex>
 #include <vector>
 
+#include <atomic>
+
 #include "common.hpp"
+#include "sor_dataflow.hpp"
 
 using namespace hyteg_hip;
 
@@ -147,7 +150,18 @@ __device__ inline void sor_block_body( const SorBlockView A, const SorBlock blk 
    const int         p0 = blk.P * kB, q0 = blk.Q * kB, r0 = blk.R * kB;
    double*           u = A.u;
 
-   // stage the block and its halo: rows of constant (q,r) are contiguous in memory (x = p - q)
+   // Rows of constant (q,r) are contiguous in memory along p (x = p - q).  The array index of p = 0 of each of the
+   // 18 x 18 rows of the block + halo is computed once (a per-element index polynomial costs ~70 instructions; with
+   // 39 + 16 elements per thread that was a third of the block time); -1: the row is outside the array.
+   __shared__ int rowBase[kBH * kBH];
+   for ( int t = threadIdx.x; t < kBH * kBH; t += kB * kB )
+   {
+      const int q = q0 + t % kBH - 1, r = r0 + t / kBH - 1;
+      rowBase[t]  = ( r >= 0 && q >= r && q <= n ) ? slice_start( N, r ) + row_start( N - r, q - r ) - q : -1;
+   }
+   __syncthreads();
+
+   // stage the block and its halo
    // (constant trip counts + full unrolling: all loads of a thread are in flight together; a rolled loop waits one
    //  memory round trip per iteration, which made staging 2/3 of the block time)
    constexpr int kStageU = ( kBH * kBH * kBH + kB * kB - 1 ) / ( kB * kB );
@@ -156,11 +170,10 @@ __device__ inline void sor_block_body( const SorBlockView A, const SorBlock blk 
    for ( int it = 0; it < kStageU; ++it )
    {
       const int idx = it * ( kB * kB ) + threadIdx.x;
-      const int pl = idx % kBH - 1, ql = ( idx / kBH ) % kBH - 1, rl = idx / ( kBH * kBH ) - 1;
-      const int p = p0 + pl, q = q0 + ql, r = r0 + rl;
-      const int x = p - q, y = q - r, z = r;
-      const bool ok = idx < kBH * kBH * kBH && x >= 0 && y >= 0 && z >= 0 && p <= n;
-      stage[it]     = ok ? u[cell_index( N, x, y, z )] : 0.0;
+      const int row = idx / kBH; // (rl + 1) * kBH + (ql + 1)
+      const int p = p0 + idx % kBH - 1, q = q0 + row % kBH - 1;
+      const int base = idx < kBH * kBH * kBH ? rowBase[row] : -1;
+      stage[it]      = ( base >= 0 && p >= q && p <= n ) ? u[base + p] : 0.0;
    }
 #pragma unroll
    for ( int it = 0; it < kStageU; ++it )
@@ -172,19 +185,19 @@ __device__ inline void sor_block_body( const SorBlockView A, const SorBlock blk 
    const int ql = threadIdx.x % kB, rl = threadIdx.x / kB;
    const int q = q0 + ql, r = r0 + rl;
    const int y = q - r, z = r;
-   // interior row? (y >= 1, z >= 1, and at least x = 1 fits: 1 + y + z <= n - 1)
+   // interior row? (y >= 1, z >= 1, and at least x = 1 fits: 1 + y + z <= n - 2)
    const bool row_ok = y >= 1 && z >= 1 && y + z <= n - 2;
+   // rhs and write-back: thread handles the entries idx = it * 256 + tid of the 16^3 block: pl = tid % 16, row (tid / 16, it)
+   const int  pw = p0 + threadIdx.x % kB, qw = q0 + threadIdx.x / kB;
    {
       double stageR[kB];
 #pragma unroll
       for ( int it = 0; it < kB; ++it )
       {
-         const int idx = it * ( kB * kB ) + threadIdx.x;
-         const int pl = idx % kB, qq = ( idx / kB ) % kB, rr = idx / ( kB * kB );
-         const int p = p0 + pl, q2 = q0 + qq, r2 = r0 + rr;
-         const int x2 = p - q2, y2 = q2 - r2, z2 = r2;
-         const bool ok = x2 >= 1 && y2 >= 1 && z2 >= 1 && p <= n - 1;
-         stageR[it]    = ok ? A.rhs[cell_index( N, x2, y2, z2 )] : 0.0;
+         const int  r2   = r0 + it;
+         const int  base = rowBase[( it + 1 ) * kBH + threadIdx.x / kB + 1];
+         const bool ok   = r2 >= 1 && qw >= r2 + 1 && pw >= qw + 1 && pw <= n - 1;
+         stageR[it]      = ok ? A.rhs[base + pw] : 0.0;
       }
 #pragma unroll
       for ( int it = 0; it < kB; ++it )
@@ -235,12 +248,9 @@ __device__ inline void sor_block_body( const SorBlockView A, const SorBlock blk 
 #pragma unroll
    for ( int it = 0; it < kB; ++it )
    {
-      const int idx = it * ( kB * kB ) + threadIdx.x;
-      const int pl = idx % kB, qq = ( idx / kB ) % kB, rr = idx / ( kB * kB );
-      const int p = p0 + pl, q2 = q0 + qq, r2 = r0 + rr;
-      const int x = p - q2, y2 = q2 - r2, z2 = r2;
-      if ( x >= 1 && y2 >= 1 && z2 >= 1 && p <= n - 1 )
-         u[cell_index( N, x, y2, z2 )] = lu[lds_index( pl, qq, rr )];
+      const int r2 = r0 + it;
+      if ( r2 >= 1 && qw >= r2 + 1 && pw >= qw + 1 && pw <= n - 1 )
+         u[rowBase[( it + 1 ) * kBH + threadIdx.x / kB + 1] + pw] = lu[lds_index( threadIdx.x % kB, threadIdx.x / kB, it )];
    }
 }
 
@@ -365,9 +375,27 @@ __global__ __launch_bounds__( kSmallThreads ) void p1_sor_small_kernel( const So
       ug[i] = lu[i];
 }
 
+// which form of the cell sweep the entry points use: 0 = by level (default), 1 = one launch per hyperplane,
+// 2 = blocks (one launch per block wavefront; levels <= 5 of a batch: one workgroup per cell), 3 = dataflow (one launch)
+std::atomic< int > g_sorAlgorithm{ 0 };
+
+inline bool use_dataflow( int level )
+{
+   const int a = g_sorAlgorithm.load( std::memory_order_relaxed );
+   // opt-in only: measured slower than the blocked form at every level (p1_sor_dataflow.hip)
+   return a == HYTEG_HIP_SOR_DATAFLOW && level >= kSorDataflowMinLevel;
+}
+
 } // namespace
 
 extern "C" {
+
+HYTEG_HIP_API int hyteg_hip_set_sor_algorithm( int algorithm )
+{
+   HH_REQUIRE( algorithm >= HYTEG_HIP_SOR_AUTO && algorithm <= HYTEG_HIP_SOR_DATAFLOW, "set_sor_algorithm: unknown algorithm" );
+   g_sorAlgorithm.store( algorithm, std::memory_order_relaxed );
+   return HYTEG_HIP_OK;
+}
 
 HYTEG_HIP_API int hyteg_hip_p1_sor_cells( int                  ncells,
                                           double* const*       u,
@@ -395,7 +423,28 @@ HYTEG_HIP_API int hyteg_hip_p1_sor_cells( int                  ncells,
    if ( m == 0 )
       return HYTEG_HIP_OK;
    const int N = ( 1 << level ) + 1;
-   if ( level <= 5 )
+   if ( use_dataflow( level ) )
+   {
+      // one launch per run of consecutive selected cells (the stencil table is indexed by the position in the batch)
+      int k = 0;
+      while ( k < m )
+      {
+         int e = k;
+         while ( e + 1 < m && sel[e + 1] == sel[e] + 1 )
+            ++e;
+         double*       uu[HYTEG_HIP_MAX_BATCH];
+         const double* rr[HYTEG_HIP_MAX_BATCH];
+         for ( int j = k; j <= e; ++j )
+            uu[j - k] = u[sel[j]], rr[j - k] = rhs[sel[j]];
+         const int rc = launch_sor_dataflow( e - k + 1, uu, rr, level, stencils_dev + (size_t) sel[k] * 225, nullptr, relax, backwards,
+                                             as_stream( stream ) );
+         if ( rc != HYTEG_HIP_OK )
+            return rc;
+         k = e + 1;
+      }
+      return HYTEG_HIP_OK;
+   }
+   if ( level <= 5 && g_sorAlgorithm.load( std::memory_order_relaxed ) != HYTEG_HIP_SOR_PLANES )
    {
       // the stencil table is indexed by the position in the batch: compact batches need the original cell index,
       // so the kernel gets one launch per run of consecutive selected cells
@@ -462,6 +511,8 @@ HYTEG_HIP_API int hyteg_hip_p1_sor_cell( double*            u,
    HH_REQUIRE( level_ok( level ), "p1_sor_cell: level out of range [2,11]" );
    HH_REQUIRE( u != rhs, "p1_sor_cell: u and rhs must not alias" );
    HH_REQUIRE( w[7] != 0.0, "p1_sor_cell: zero centre weight" );
+   if ( use_dataflow( level ) )
+      return launch_sor_dataflow( 1, &u, &rhs, level, nullptr, w, relax, backwards, as_stream( stream ) );
    SorArgs A;
    A.u               = u;
    A.rhs             = rhs;
@@ -471,7 +522,7 @@ HYTEG_HIP_API int hyteg_hip_p1_sor_cell( double*            u,
    A.invc            = 1.0 / w[7];
    for ( int k = 0; k < 15; ++k )
       A.st.w[k] = w[k];
-   if ( level >= 5 )
+   if ( level >= 5 && g_sorAlgorithm.load( std::memory_order_relaxed ) != HYTEG_HIP_SOR_PLANES )
    {
       // blocked sweep: one launch per block wavefront
       const SorBlockTable* tab = nullptr;

@@ -131,6 +131,23 @@ HYTEG_HIP_API int hyteg_hip_p1_jacobi_cell( double*            dst,
                                             double             relax,
                                             hyteg_hip_stream_t stream );
 
+/* Selects how hyteg_hip_p1_sor_cell / hyteg_hip_p1_sor_cells execute the sweep.  Every form visits the points in an
+ * order that respects the reference's lexicographic (z,y,x) dependencies (sor_3D_macrocell_P1.cpp:48-88), so the results
+ * agree up to the rounding of the 15-term sum.  Process-wide; meant for tests and benchmarks.
+ *   AUTO      levels >= 5: BLOCKS; below: PLANES (batches at levels <= 5: one workgroup per cell)
+ *   PLANES    one launch per hyperplane x + 2y + 3z
+ *   BLOCKS    16^3 blocks in skewed coordinates, one launch per block wavefront
+ *   DATAFLOW  one launch; 8 x 8-row columns, one wave each, hand results over through progress words (levels >= 3);
+ *             measured slower than BLOCKS on MI355X, kept as an opt-in */
+enum hyteg_hip_sor_algorithm
+{
+   HYTEG_HIP_SOR_AUTO     = 0,
+   HYTEG_HIP_SOR_PLANES   = 1,
+   HYTEG_HIP_SOR_BLOCKS   = 2,
+   HYTEG_HIP_SOR_DATAFLOW = 3
+};
+HYTEG_HIP_API int hyteg_hip_set_sor_algorithm( int algorithm );
+
 /* ---- a3: SOR / Gauss-Seidel sweep, in place, in the reference's lexicographic order -----------------
  * replaces sor_3D_macrocell_P1, sor_3D_macrocell_P1_backwards, gaussseidel_3D_macrocell_P1 (relax = 1)
  *   src/constant_stencil_operator/P1generatedKernels/sor_3D_macrocell_P1.cpp:32-90

@@ -1,0 +1,169 @@
+"""GPU parity of the three forms of the macro-cell SOR / Gauss-Seidel sweep (hyteg_hip_set_sor_algorithm): planes,
+blocks and the one-launch dataflow form all have to reproduce the reference's sequential (z,y,x) sweep
+(sor_3D_macrocell_P1.cpp:48-88, _backwards.cpp:52-57) as restated by the oracle; an ordering or hand-over mistake changes
+values at O(1).  Tolerance 1e-12 relative L2 (fp64, north_star); entries outside the inner points must stay untouched."""
+import numpy as np
+import pytest
+
+from conftest import OCT_TET, SKEW_TET
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    from hyteg_amd import capi
+    from oracle import p1_oracle as po
+
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    capi.lib()
+    yield torch, capi, po
+    capi.set_sor_algorithm(capi.SOR_AUTO)
+
+
+@pytest.fixture(autouse=True)
+def _reset_algorithm():
+    yield
+    from hyteg_amd import capi
+
+    capi.set_sor_algorithm(capi.SOR_AUTO)
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda")
+
+
+def _rel(a, b):
+    nb = np.linalg.norm(b)
+    return np.linalg.norm(a - b) / (nb if nb > 0 else 1.0)
+
+
+@pytest.mark.parametrize("level", [3, 4, 5, 6])
+@pytest.mark.parametrize("relax,backwards", [(1.0, False), (1.0, True), (0.3, False), (1.3, True)])
+def test_dataflow_sweeps_reproduce_the_sequential_order(env, level, relax, backwards):
+    torch, capi, po = env
+    capi.set_sor_algorithm(capi.SOR_DATAFLOW)
+    rng = np.random.default_rng(17 * level + int(relax * 10) + backwards)
+    w = po.assemble_cell_stencil(SKEW_TET, level)
+    n = po.cell_size(level)
+    u_h, rhs_h = rng.random(n), rng.random(n)
+    u, rhs = _dev(torch, u_h), _dev(torch, rhs_h)
+    for _ in range(2):
+        capi.p1_sor_cell(u.data_ptr(), rhs.data_ptr(), level, w, relax, backwards, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ref = u_h.copy()
+    for _ in range(2):
+        po.sor_cell(ref, rhs_h, level, w, relax, backwards)
+    got = u.cpu().numpy()
+    m = po.inner_mask(level)
+    assert np.array_equal(got[~m], u_h[~m])
+    assert _rel(got[m], ref[m]) < 1e-12
+
+
+@pytest.mark.parametrize("level", [5, 7])
+def test_the_three_forms_agree(env, level):
+    torch, capi, po = env
+    rng = np.random.default_rng(level)
+    w = po.assemble_cell_stencil(OCT_TET, level)
+    n = po.cell_size(level)
+    u_h, rhs_h = rng.standard_normal(n), rng.standard_normal(n)
+    rhs = _dev(torch, rhs_h)
+    res = {}
+    for name in ("SOR_PLANES", "SOR_BLOCKS", "SOR_DATAFLOW", "SOR_AUTO"):
+        capi.set_sor_algorithm(getattr(capi, name))
+        u = _dev(torch, u_h)
+        capi.p1_sor_cell(u.data_ptr(), rhs.data_ptr(), level, w, 1.1, False)
+        capi.p1_sor_cell(u.data_ptr(), rhs.data_ptr(), level, w, 1.1, True)
+        torch.cuda.synchronize()
+        res[name] = u.cpu().numpy()
+    ref = u_h.copy()
+    po.sor_cell(ref, rhs_h, level, w, 1.1, False)
+    po.sor_cell(ref, rhs_h, level, w, 1.1, True)
+    for name, got in res.items():
+        assert _rel(got, ref) < 1e-12, name
+    assert np.array_equal(res["SOR_AUTO"], res["SOR_BLOCKS"])  # the default at levels >= 5
+
+
+def test_many_alternating_sweeps_stay_on_the_oracle(env):
+    """30 sweeps back to back on one stream (progress words and ticket are reset between launches by a stream-ordered
+    memset): a stale progress word or a lost hand-over would show as an O(1) difference"""
+    torch, capi, po = env
+    capi.set_sor_algorithm(capi.SOR_DATAFLOW)
+    level = 6
+    rng = np.random.default_rng(5)
+    w = po.assemble_cell_stencil(SKEW_TET, level)
+    n = po.cell_size(level)
+    u_h, rhs_h = rng.random(n), rng.random(n)
+    u, rhs = _dev(torch, u_h), _dev(torch, rhs_h)
+    ref = u_h.copy()
+    for k in range(30):
+        capi.p1_sor_cell(u.data_ptr(), rhs.data_ptr(), level, w, 1.0, k % 3 == 1)
+        po.sor_cell(ref, rhs_h, level, w, 1.0, k % 3 == 1)
+    torch.cuda.synchronize()
+    assert _rel(u.cpu().numpy(), ref) < 1e-11  # 30 sweeps: rounding differences of the 15-term sums accumulate
+
+
+@pytest.mark.parametrize("level", [3, 4, 6])
+@pytest.mark.parametrize("backwards", [False, True])
+def test_dataflow_batches(env, level, backwards):
+    """grid = columns x cells, one progress table per cell; a cell whose inner points are not selected is untouched"""
+    torch, capi, po = env
+    import hostutil as hu
+
+    capi.set_sor_algorithm(capi.SOR_DATAFLOW)
+    v, c = hu.read_msh(hu.MESHES / "regular_octahedron_8el.msh")
+    tabs = []
+    for cv in c[[0, 3, 6, 7]]:
+        co = v[cv].reshape(12)
+        tabs.append(np.vstack([po.assemble_cell_slot_stencils(co, level).reshape(14, 15), po.assemble_cell_stencil(co, level)[None, :]]))
+    tabs = np.array(tabs)
+    n = po.cell_size(level)
+    rng = np.random.default_rng(level + 40)
+    u0, b = [rng.standard_normal(n) for _ in range(4)], [rng.standard_normal(n) for _ in range(4)]
+    masks = [0x7FFF, 0x3FFF, 0x4000, 0x4001]
+    du, db, dtab = [_dev(torch, a) for a in u0], [_dev(torch, a) for a in b], _dev(torch, tabs.reshape(-1))
+    capi.p1_sor_cells([t.data_ptr() for t in du], [t.data_ptr() for t in db], level, dtab.data_ptr(), 1.15, masks, backwards)
+    torch.cuda.synchronize()
+    for k in range(4):
+        got = du[k].cpu().numpy()
+        if not masks[k] & po.MASK_INNER:
+            assert np.array_equal(got, u0[k])
+            continue
+        want = po.sor_cell(u0[k].copy(), b[k], level, tabs[k][14], 1.15, backwards)
+        assert _rel(got, want) < 1e-12
+
+
+def test_level8_forward_backward_symmetry_property(env):
+    """full size (level 8, 2.7 M inner points, 528 columns): the oracle's sequential sweep would take seconds; check it
+    once forward, and check the size-independent property that one Gauss-Seidel sweep does not increase the energy
+    norm of the error for the SPD Laplace stencil (it would with a wrong hand-over)"""
+    torch, capi, po = env
+    level = 8
+    rng = np.random.default_rng(8)
+    w = po.assemble_cell_stencil(OCT_TET, level)
+    n = po.cell_size(level)
+    m = po.inner_mask(level)
+    u_h = np.where(m, rng.standard_normal(n), 0.0)
+    rhs_h = np.zeros(n)
+    u, rhs = _dev(torch, u_h), _dev(torch, rhs_h)
+
+    def energy(x):
+        ax = np.zeros(n)
+        po.apply_cell(ax, x, level, w, 0)
+        return float(np.dot(x[m], ax[m]))
+
+    e0 = energy(u_h)
+    capi.set_sor_algorithm(capi.SOR_DATAFLOW)
+    capi.p1_sor_cell(u.data_ptr(), rhs.data_ptr(), level, w, 1.0, False)
+    torch.cuda.synchronize()
+    got = u.cpu().numpy()
+    ref = u_h.copy()
+    po.sor_cell(ref, rhs_h, level, w, 1.0, False)
+    assert _rel(got, ref) < 1e-12
+    e1 = energy(got)
+    capi.p1_sor_cell(u.data_ptr(), rhs.data_ptr(), level, w, 1.0, True)
+    torch.cuda.synchronize()
+    e2 = energy(u.cpu().numpy())
+    assert e2 < e1 < e0

@@ -71,8 +71,13 @@ def main():
     timeit("restrict (fine L -> coarse L-1)", lambda k: capi.p1_restrict_cell(p(Co, k), p(A, k), L - 1, ones, sh), 8 * (n + nc), nc)
     timeit("prolongate Replace (coarse L-1 -> fine L)", lambda k: capi.p1_prolongate_cell(p(Co, k), p(B, k), L - 1, ones, 0, sh),
            8 * (n + nc), n)
-    timeit("SOR forward sweep (hyperplane-exact)", lambda k: capi.p1_sor_cell(p(B, k), p(A, k), L, w, 1.0, False, sh), 24 * inner, inner,
-           r=max(3, reps // 40))
+    for name, alg in (("dataflow, one launch", capi.SOR_DATAFLOW), ("16^3 blocks, one launch per block wavefront", capi.SOR_BLOCKS)):
+        capi.set_sor_algorithm(alg)
+        timeit(f"SOR forward sweep ({name})", lambda k: capi.p1_sor_cell(p(B, k), p(A, k), L, w, 1.0, False, sh), 24 * inner, inner,
+               r=max(3, reps // 40))
+        timeit(f"SOR backward sweep ({name})", lambda k: capi.p1_sor_cell(p(B, k), p(A, k), L, w, 1.0, True, sh), 24 * inner, inner,
+               r=max(3, reps // 40))
+    capi.set_sor_algorithm(capi.SOR_AUTO)
     # Gauss-Seidel on the cell's macro-vertices/-edges/-faces (what a multi-cell sweep adds per cell); octahedron weights
     sys.path.insert(0, str(ROOT / "tests"))
     import hostutil as hu  # noqa: E402
