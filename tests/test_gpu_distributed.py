@@ -180,3 +180,65 @@ def test_a_rank_without_shared_points_takes_part_in_the_exchange():
             assert np.abs(arr - ref[gid]).max() <= 1e-13 * np.abs(ref[gid]).max()
             seen += 1
     assert seen == 3
+
+
+# ---- the RCCL backend itself (one rank: all this box can hold) --------------------------------------------------
+def _worker_rccl(port, level, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+
+    from hyteg_amd import host
+    from hyteg_amd.distributed import DistributedContext
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        st = host.Storage.from_gmsh(MESH, 0, 1)
+        st.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx = DistributedContext(st, [2, 3], dev)  # all_reduce(MAX) of the any-peers words on the device
+        res = _run(host, st, level, ctx)           # dotGlobal: all_reduce(SUM) of doubles through the hook
+        # the transport call of the exchange hooks with the argument types they use: split all_to_all of f64 device
+        # tensors, asynchronous, stream-ordered wait
+        send = torch.arange(1000, dtype=torch.float64, device=dev)
+        recv = torch.zeros(1000, dtype=torch.float64, device=dev)
+        work = dist.all_to_all_single(recv[:700], send[:700], [700], [700], async_op=True)
+        work.wait()
+        dist.barrier()
+        torch.cuda.synchronize()
+        ok = bool(torch.equal(recv[:700], send[:700])) and float(recv[700:].abs().sum()) == 0.0
+        q.put(res + (ok,))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_single_rank():
+    """torch.distributed's "nccl" backend is RCCL on this image.  A one-GPU box can hold one RCCL rank, so this checks
+    what can be checked here: the process group comes up on the device, the collectives the hooks and bench.py issue
+    (all_reduce MAX / SUM on device tensors, split all_to_all_single with async wait, barrier) run on it, and the
+    host layer driven through DistributedContext gives the same numbers as without it."""
+    import torch
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, str(ROOT))
+    from hyteg_amd import host
+
+    level = 3
+    st = host.Storage.from_gmsh(MESH)
+    st.set_stream(torch.cuda.current_stream().cuda_stream)
+    ref_applied, ref_dot, ref_cycled, ref_swept = _run(host, st, level)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_rccl, args=(_free_port(), level, q))
+    p.start()
+    applied, dot, cycled, swept, a2a_ok = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert a2a_ok
+    assert dot == ref_dot
+    for gid in ref_applied:
+        assert np.array_equal(applied[gid], ref_applied[gid])
+        assert np.array_equal(cycled[gid], ref_cycled[gid])
+        assert np.array_equal(swept[gid], ref_swept[gid])
