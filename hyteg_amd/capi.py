@@ -29,6 +29,11 @@ SIGNATURES = {
     "hyteg_hip_stream_create": (_i, [C.POINTER(_vp)]),
     "hyteg_hip_stream_destroy": (_i, [_vp]),
     "hyteg_hip_stream_synchronize": (_i, [_vp]),
+    "hyteg_hip_graph_begin_capture": (_i, [_vp]),
+    "hyteg_hip_graph_end_capture": (_i, [_vp, C.POINTER(_vp)]),
+    "hyteg_hip_graph_abort_capture": (_i, [_vp]),
+    "hyteg_hip_graph_launch": (_i, [_vp, _vp]),
+    "hyteg_hip_graph_destroy": (_i, [_vp]),
     "hyteg_hip_prepare_level": (_i, [_i]),
     "hyteg_hip_cell_width": (_i64, [_i]),
     "hyteg_hip_cell_size": (_i64, [_i]),

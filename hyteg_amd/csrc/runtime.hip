@@ -240,6 +240,66 @@ HYTEG_HIP_API int hyteg_hip_stream_synchronize( hyteg_hip_stream_t stream )
    return HYTEG_HIP_OK;
 }
 
+// ---- graphs -----------------------------------------------------------------------------------------
+// Launch-bound sequences (the coarse levels of a multigrid cycle: ~100 dependent launches of a few microseconds) are
+// recorded once from the stream they are issued on and replayed as ONE graph launch; every entry point of this
+// library is capturable once its lazily built tables exist (hyteg_hip_prepare_level or one ordinary call).
+HYTEG_HIP_API int hyteg_hip_graph_begin_capture( hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( stream != nullptr, "graph_begin_capture: the null stream cannot be captured" );
+   HH_CHECK_HIP( hipStreamBeginCapture( as_stream( stream ), hipStreamCaptureModeRelaxed ) );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_graph_end_capture( hyteg_hip_stream_t stream, hyteg_hip_graph_t* graph )
+{
+   HH_REQUIRE( stream != nullptr && graph != nullptr, "graph_end_capture: null argument" );
+   *graph       = nullptr;
+   hipGraph_t g = nullptr;
+   HH_CHECK_HIP( hipStreamEndCapture( as_stream( stream ), &g ) );
+   if ( g == nullptr )
+      return HYTEG_HIP_OK; // nothing was recorded
+   size_t nodes = 0;
+   HH_CHECK_HIP( hipGraphGetNodes( g, nullptr, &nodes ) );
+   if ( nodes == 0 )
+   {
+      HH_CHECK_HIP( hipGraphDestroy( g ) );
+      return HYTEG_HIP_OK;
+   }
+   hipGraphExec_t exec = nullptr;
+   hipError_t     e    = hipGraphInstantiate( &exec, g, nullptr, nullptr, 0 );
+   (void) hipGraphDestroy( g );
+   if ( e != hipSuccess )
+      return fail( HYTEG_HIP_ELAUNCH, std::string( "hipGraphInstantiate: " ) + hipGetErrorString( e ) );
+   *graph = reinterpret_cast< hyteg_hip_graph_t >( exec );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_graph_abort_capture( hyteg_hip_stream_t stream )
+{
+   hipGraph_t g = nullptr;
+   (void) hipStreamEndCapture( as_stream( stream ), &g );
+   if ( g )
+      (void) hipGraphDestroy( g );
+   (void) hipGetLastError();
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_graph_launch( hyteg_hip_graph_t graph, hyteg_hip_stream_t stream )
+{
+   if ( graph == nullptr )
+      return HYTEG_HIP_OK; // an empty recording
+   HH_CHECK_HIP( hipGraphLaunch( reinterpret_cast< hipGraphExec_t >( graph ), as_stream( stream ) ) );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_graph_destroy( hyteg_hip_graph_t graph )
+{
+   if ( graph )
+      HH_CHECK_HIP( hipGraphExecDestroy( reinterpret_cast< hipGraphExec_t >( graph ) ) );
+   return HYTEG_HIP_OK;
+}
+
 // ---- layout ---------------------------------------------------------------------------------------
 HYTEG_HIP_API int64_t hyteg_hip_cell_width( int level ) { return ( (int64_t) 1 << level ) + 1; }
 HYTEG_HIP_API int64_t hyteg_hip_cell_size( int level ) { return tet64( hyteg_hip_cell_width( level ) ); }

@@ -60,6 +60,8 @@ SIGNATURES = {
     "hyteg_host_prolongate": (_i, [_vp, _i, _i]),
     "hyteg_host_prolongate_and_add": (_i, [_vp, _i, _i]),
     "hyteg_host_gmg_create": (_i, [_vp, _i, _i, _i, _d, _i, _i, _i, _i, _d, C.POINTER(_vp)]),
+    "hyteg_host_gmg_set_use_graphs": (_i, [_vp, _i]),
+    "hyteg_host_gmg_replayed_cycles": (_i, [_vp, C.POINTER(_i)]),
     "hyteg_host_cg_create": (_i, [_vp, _i, _i, _i, _d, C.POINTER(_vp)]),
     "hyteg_host_solver_solve": (_i, [_vp, _vp, _vp, _vp, _i]),
     "hyteg_host_solver_destroy": (_i, [_vp]),
@@ -341,6 +343,16 @@ class Solver:
 
     def solve(self, laplace: P1ConstantOperator, x: P1Function, b: P1Function, level: int):
         _ck(lib().hyteg_host_solver_solve(self.h, laplace.h, x.h, b.h, level), "solve")
+
+    def set_use_graphs(self, on: bool) -> None:
+        """GeometricMultigridSolver::setUseGraphs: record the launches of a cycle once, replay them as graphs (default on)"""
+        _ck(lib().hyteg_host_gmg_set_use_graphs(self.h, int(on)), "gmg_set_use_graphs")
+
+    @property
+    def replayed_cycles(self) -> int:
+        n = _i(0)
+        _ck(lib().hyteg_host_gmg_replayed_cycles(self.h, C.byref(n)), "gmg_replayed_cycles")
+        return n.value
 
     def close(self):
         if self.h:

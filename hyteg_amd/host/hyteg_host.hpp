@@ -19,9 +19,12 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <functional>
@@ -31,6 +34,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/hyteg_hip.h"
@@ -72,6 +76,13 @@ inline void hipCheck( int rc, const char* what )
 {
    if ( rc != HYTEG_HIP_OK )
       throw std::runtime_error( std::string( what ) + ": " + hyteg_hip_last_error() );
+}
+
+// identity of functions and operators that outlives address reuse (keys of recorded launch graphs)
+inline uint64_t nextUid()
+{
+   static std::atomic< uint64_t > counter{ 1 };
+   return counter.fetch_add( 1 );
 }
 
 namespace layout {
@@ -500,6 +511,25 @@ class PrimitiveStorage
    }
    void releaseScratch( size_t doubles, double* p ) const { scratchFree_[doubles].push_back( p ); }
 
+   // device copy of a list of device pointers (the "bases" argument of the exchange kernels), cached by content: scratch
+   // functions get the same arrays from the pool again and again, so after the first cycle nothing is allocated or
+   // uploaded in the hot path (and the path can be recorded into a launch graph)
+   double** pointerTable( const std::vector< double* >& host ) const
+   {
+      auto it = pointerTables_.find( host );
+      if ( it != pointerTables_.end() )
+         return it->second;
+      void* d = nullptr;
+      hipCheck( hyteg_hip_malloc( &d, std::max< size_t >( 1, host.size() ) * sizeof( double* ) ), "bases: malloc" );
+      // on the null stream and complete on return: valid for whatever stream uses the table next, and legal while the
+      // storage's stream is being recorded into a launch graph
+      hipCheck( hyteg_hip_upload( d, host.data(), host.size() * sizeof( double* ), nullptr ), "bases: upload" );
+      hipCheck( hyteg_hip_stream_synchronize( nullptr ), "bases: sync" );
+      scratchAll_.push_back( d );
+      pointerTables_[host] = static_cast< double** >( d );
+      return static_cast< double** >( d );
+   }
+
    double* dotResult() const
    {
       if ( !dotResult_ )
@@ -819,6 +849,7 @@ class PrimitiveStorage
    mutable void *                                          dotResult_ = nullptr, *dotWorkspace_ = nullptr;
    mutable std::map< size_t, std::vector< double* > >      scratchFree_;
    mutable std::vector< void* >                            scratchAll_;
+   mutable std::map< std::vector< double* >, double** >    pointerTables_;
    mutable double*                                         nncInv_        = nullptr;
    mutable int                                             batchMaxLevel_ = -2; // -2: read HYTEG_AMD_BATCH_MAX_LEVEL on first use
    mutable std::map< std::pair< int, int >, ExchangePlan > plans_;
@@ -835,6 +866,8 @@ class P1Function
 
  public:
    using valueType = ValueType;
+
+   uint64_t uid() const { return uid_; }
 
    // scratch = true: arrays come from (and return to) the storage's scratch pool and are NOT zero-initialised
    P1Function( const std::string& name, const std::shared_ptr< PrimitiveStorage >& storage, uint_t minLevel, uint_t maxLevel,
@@ -874,8 +907,6 @@ class P1Function
             else
                hyteg_hip_free( c[l] );
          }
-      for ( auto& kv : bases_ )
-         hyteg_hip_free( kv.second );
    }
    P1Function( const P1Function& )            = delete;
    P1Function& operator=( const P1Function& ) = delete;
@@ -1111,7 +1142,6 @@ class P1Function
    double** basesFor( uint_t level, int cls ) const
    {
       const auto& plan = storage_->devicePlan( (int) level, cls );
-      auto        key  = std::make_pair( level, cls );
       std::vector< double* > host;
       for ( uint_t c = 0; c < storage_->getNumberOfLocalCells(); ++c )
          host.push_back( getCellPointer( c, level ) );
@@ -1121,20 +1151,7 @@ class P1Function
          host.push_back( seg );
          seg += plan.recvCount[s];
       }
-      auto it = bases_.find( key );
-      if ( it == bases_.end() || basesHost_[key] != host )
-      {
-         if ( it != bases_.end() )
-            hyteg_hip_free( it->second );
-         void* d = nullptr;
-         hipCheck( hyteg_hip_malloc( &d, std::max< size_t >( 1, host.size() ) * sizeof( double* ) ), "bases: malloc" );
-         hipCheck( hyteg_hip_upload( d, host.data(), host.size() * sizeof( double* ), storage_->stream() ), "bases: upload" );
-         hipCheck( hyteg_hip_stream_synchronize( storage_->stream() ), "bases: sync" );
-         bases_[key]     = static_cast< double** >( d );
-         basesHost_[key] = host;
-         return static_cast< double** >( d );
-      }
-      return it->second;
+      return storage_->pointerTable( host );
    }
 
    // The hooks are called by EVERY rank for every boundary class the flag selects, also by a rank that shares nothing
@@ -1185,9 +1202,8 @@ class P1Function
    std::shared_ptr< PrimitiveStorage >                                   storage_;
    uint_t                                                                minLevel_, maxLevel_;
    bool                                                                  scratch_ = false;
+   uint64_t                                                              uid_     = nextUid();
    std::vector< std::vector< double* > >                                 data_;
-   mutable std::map< std::pair< uint_t, int >, double** >                bases_;
-   mutable std::map< std::pair< uint_t, int >, std::vector< double* > >  basesHost_;
 };
 
 // =====================================================================================================
@@ -1606,6 +1622,7 @@ class P1ConstantOperator
    }
 
    std::shared_ptr< PrimitiveStorage > getStorage() const { return storage_; }
+   uint64_t                            uid() const { return uid_; }
    uint_t                              getMinLevel() const { return minLevel_; }
    uint_t                              getMaxLevel() const { return maxLevel_; }
    const stencil::CellStencils&        getCellStencils( int globalCellID, uint_t level ) const { return stencils_.at( level ).at( globalCellID ); }
@@ -2048,6 +2065,7 @@ class P1ConstantOperator
 
    std::shared_ptr< PrimitiveStorage >                        storage_;
    uint_t                                                     minLevel_, maxLevel_;
+   uint64_t                                                   uid_ = nextUid();
    std::map< uint_t, std::vector< stencil::CellStencils > >   stencils_;
    std::map< uint_t, std::vector< stencil::CellSorTables > >  sorTables_;
    mutable std::map< uint_t, std::unique_ptr< P1Function< double > > > sorRest_;
@@ -2268,12 +2286,12 @@ class P1toP1LinearProlongation
    }
    void prolongateAndAdd( const P1Function< double >& function, const uint_t& sourceLevel, const DoFType& flag ) const
    {
-      // the prolongated correction is formed in a temporary (Replace), summed over cells on shared points, then added
+      // the prolongated correction is formed in a temporary (Replace), summed over cells on shared points, then added.
+      // The temporary needs no initialisation: the masked kernel writes every point `flag` selects, the sum over
+      // shared copies and the add read only those.
       auto                 storage = function.getStorage();
-      P1Function< double > tmp( "prolongate_tmp", storage, sourceLevel, sourceLevel + 1, true );
-      tmp.interpolate( 0.0, sourceLevel + 1, All );
-      tmp.assign( { 1.0 }, { function }, sourceLevel, All );
-      run( tmp, tmp, sourceLevel, flag );
+      P1Function< double > tmp( "prolongate_tmp", storage, sourceLevel + 1, sourceLevel + 1, true );
+      run( function, tmp, sourceLevel, flag );
       function.add( { 1.0 }, { tmp }, sourceLevel + 1, flag );
    }
 
@@ -2457,20 +2475,147 @@ class GeometricMultigridSolver : public Solver< OperatorType >
    , restrictionOperator_( restrictionOperator )
    , prolongationOperator_( prolongationOperator )
    , tmp_( "gmg_tmp", storage, minLevel, maxLevel )
+   , storage_( storage )
    {}
+
+   ~GeometricMultigridSolver() override
+   {
+      for ( auto& kv : recordings_ )
+         kv.second.destroy();
+      if ( captureStream_ )
+         hyteg_hip_stream_destroy( captureStream_ );
+   }
+
+   // Launch graphs (no counterpart in the reference, whose cycle is host loops): the launches of a cycle -- ~20 per
+   // level, most of them a few microseconds on the coarse levels -- are recorded once per (operator, x, b, level) and
+   // replayed as one graph launch per segment between coarse-grid solves (the coarse solver reads dot products on the
+   // host and stays outside).  The first cycle with given arguments runs with ordinary launches (it creates every lazily
+   // built table and scratch array), the second records (nothing executes while recording) and replays, later cycles
+   // replay.  Same kernels, same order, same arguments: results are identical to ordinary launches.
+   // Off: setUseGraphs( false ) or HYTEG_AMD_GRAPHS=0; never used for storages distributed over several ranks (the
+   // exchange hooks are host callbacks).
+   void setUseGraphs( bool on ) { useGraphs_ = on; }
+   bool usesGraphs() const { return graphsUsable(); }
+   // number of cycles that were replayed from a recording (tests)
+   uint_t replayedCycles() const { return replayed_; }
 
    void solve( const OperatorType& A, const P1Function< double >& x, const P1Function< double >& b, uint_t level ) override
    {
       invokedLevel_ = level;
-      solveRecursively( A, x, b, level );
+      if ( !graphsUsable() )
+      {
+         solveRecursively( A, x, b, level );
+         return;
+      }
+      const Key key{ A.uid(), x.uid(), b.uid(), level };
+      auto      it = recordings_.find( key );
+      if ( it == recordings_.end() )
+      {
+         if ( recordings_.size() >= 8 )
+         {
+            for ( auto& kv : recordings_ )
+               kv.second.destroy();
+            recordings_.clear();
+         }
+         recordings_[key] = Recording{};
+         solveRecursively( A, x, b, level );
+         return;
+      }
+      Recording& rec = it->second;
+      if ( !rec.recorded && !rec.failed )
+         record( rec, A, x, b, level );
+      if ( !rec.recorded )
+      {
+         solveRecursively( A, x, b, level );
+         return;
+      }
+      for ( size_t k = 0; k < rec.segments.size(); ++k )
+      {
+         hipCheck( hyteg_hip_graph_launch( rec.segments[k], storage_->stream() ), "GeometricMultigridSolver: graph launch" );
+         if ( k + 1 < rec.segments.size() )
+            coarseSolver_->solve( A, x, b, minLevel_ );
+      }
+      ++replayed_;
    }
 
  private:
+   using Key = std::tuple< uint64_t, uint64_t, uint64_t, uint_t >;
+   struct Recording
+   {
+      std::vector< hyteg_hip_graph_t > segments; // separated by coarse-grid solves
+      bool                             recorded = false, failed = false;
+      int                              attempts = 0;
+      void                             destroy()
+      {
+         for ( auto g : segments )
+            hyteg_hip_graph_destroy( g );
+         segments.clear();
+      }
+   };
+
+   bool graphsUsable() const
+   {
+      if ( !useGraphs_ || storage_->numRanks() != 1 )
+         return false;
+      static const bool envOn = [] {
+         const char* e = std::getenv( "HYTEG_AMD_GRAPHS" );
+         return !( e && e[0] == '0' );
+      }();
+      return envOn;
+   }
+
+   void endSegment( Recording& rec )
+   {
+      hyteg_hip_graph_t g = nullptr;
+      capturing_          = false;
+      hipCheck( hyteg_hip_graph_end_capture( captureStream_, &g ), "GeometricMultigridSolver: end capture" );
+      rec.segments.push_back( g );
+   }
+   void beginSegment()
+   {
+      hipCheck( hyteg_hip_graph_begin_capture( captureStream_ ), "GeometricMultigridSolver: begin capture" );
+      capturing_ = true;
+   }
+
+   void record( Recording& rec, const OperatorType& A, const P1Function< double >& x, const P1Function< double >& b, uint_t level )
+   {
+      const hyteg_hip_stream_t user = storage_->stream();
+      try
+      {
+         if ( !captureStream_ )
+            hipCheck( hyteg_hip_stream_create( &captureStream_ ), "GeometricMultigridSolver: stream" );
+         storage_->setStream( captureStream_ );
+         recording_ = &rec;
+         beginSegment();
+         solveRecursively( A, x, b, level );
+         endSegment( rec );
+         rec.recorded = true;
+      } catch ( const std::exception& e )
+      {
+         // something in the cycle cannot be recorded: nothing has executed, fall back to ordinary launches for good
+         if ( rec.attempts >= 2 )
+            std::fprintf( stderr, "hyteg_amd: multigrid cycle not recordable (%s); using ordinary launches\n", e.what() );
+         if ( capturing_ )
+            hyteg_hip_graph_abort_capture( captureStream_ );
+         capturing_ = false;
+         rec.destroy();
+         rec.failed = ++rec.attempts >= 3; // a table built lazily in this very cycle: the next cycle tries again
+      }
+      recording_ = nullptr;
+      storage_->setStream( user );
+   }
+
    void solveRecursively( const OperatorType& A, const P1Function< double >& x, const P1Function< double >& b, uint_t level )
    {
       if ( level == minLevel_ )
       {
-         coarseSolver_->solve( A, x, b, minLevel_ );
+         if ( recording_ )
+         {
+            endSegment( *recording_ );
+            beginSegment();
+         }
+         else
+            coarseSolver_->solve( A, x, b, minLevel_ );
          return;
       }
       const uint_t pre = preSmoothSteps_ + smoothIncrement_ * ( invokedLevel_ - level );
@@ -2498,6 +2643,12 @@ class GeometricMultigridSolver : public Solver< OperatorType >
    std::shared_ptr< P1toP1LinearRestriction >   restrictionOperator_;
    std::shared_ptr< P1toP1LinearProlongation >  prolongationOperator_;
    P1Function< double >                         tmp_;
+   std::shared_ptr< PrimitiveStorage >          storage_;
+   bool                                         useGraphs_ = true, capturing_ = false;
+   hyteg_hip_stream_t                           captureStream_ = nullptr;
+   Recording*                                   recording_     = nullptr;
+   std::map< Key, Recording >                   recordings_;
+   uint_t                                       replayed_ = 0;
 };
 
 } // namespace hyteg

@@ -324,6 +324,24 @@ HYTEG_HOST_API int hyteg_host_gmg_create( hh_storage_t s, int minL, int maxL, in
           (uint_t) maxL, (uint_t) pre, (uint_t) post, 0, wcycle ? CycleType::WCYCLE : CycleType::VCYCLE ) };
    } );
 }
+HYTEG_HOST_API int hyteg_host_gmg_set_use_graphs( hh_solver_t solver, int on )
+{
+   return guarded( [&] {
+      auto g = std::dynamic_pointer_cast< GeometricMultigridSolver< P1ConstantLaplaceOperator > >( static_cast< SolverH* >( solver )->p );
+      if ( !g )
+         throw std::runtime_error( "gmg_set_use_graphs: not a geometric multigrid solver" );
+      g->setUseGraphs( on != 0 );
+   } );
+}
+HYTEG_HOST_API int hyteg_host_gmg_replayed_cycles( hh_solver_t solver, int* count )
+{
+   return guarded( [&] {
+      auto g = std::dynamic_pointer_cast< GeometricMultigridSolver< P1ConstantLaplaceOperator > >( static_cast< SolverH* >( solver )->p );
+      if ( !g )
+         throw std::runtime_error( "gmg_replayed_cycles: not a geometric multigrid solver" );
+      *count = (int) g->replayedCycles();
+   } );
+}
 HYTEG_HOST_API int hyteg_host_cg_create( hh_storage_t s, int minL, int maxL, int maxIter, double tol, hh_solver_t* out )
 {
    return guarded( [&] {

@@ -90,6 +90,18 @@ HYTEG_HIP_API int hyteg_hip_stream_create( hyteg_hip_stream_t* stream );
 HYTEG_HIP_API int hyteg_hip_stream_destroy( hyteg_hip_stream_t stream );
 HYTEG_HIP_API int hyteg_hip_stream_synchronize( hyteg_hip_stream_t stream );
 
+/* Graphs: record the launches issued on `stream` between begin and end (nothing executes while recording) and replay
+ * them with one call.  No counterpart in the reference (its kernels are host loops); this is what keeps the coarse
+ * levels of GeometricMultigridSolver::solveRecursively (GeometricMultigridSolver.hpp:180-319), ~100 dependent launches
+ * of a few microseconds, from being bound by the host's launch rate.  The null stream cannot be recorded; a recording
+ * with no launches yields a NULL graph, which launches as a no-op.  abort_capture ends a recording after an error. */
+typedef void* hyteg_hip_graph_t;
+HYTEG_HIP_API int hyteg_hip_graph_begin_capture( hyteg_hip_stream_t stream );
+HYTEG_HIP_API int hyteg_hip_graph_end_capture( hyteg_hip_stream_t stream, hyteg_hip_graph_t* graph );
+HYTEG_HIP_API int hyteg_hip_graph_abort_capture( hyteg_hip_stream_t stream );
+HYTEG_HIP_API int hyteg_hip_graph_launch( hyteg_hip_graph_t graph, hyteg_hip_stream_t stream );
+HYTEG_HIP_API int hyteg_hip_graph_destroy( hyteg_hip_graph_t graph );
+
 /* Builds and uploads the per-level launch tables (tile descriptors) so that later launches at that
  * level allocate nothing (HIP-graph capturable).  Launches do this lazily on first use otherwise. */
 HYTEG_HIP_API int hyteg_hip_prepare_level( int level );

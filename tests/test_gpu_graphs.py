@@ -1,0 +1,94 @@
+"""Launch graphs of the multigrid cycle (GeometricMultigridSolver::setUseGraphs in hyteg_amd/host/hyteg_host.hpp): the
+cycle's launches are recorded once per (operator, x, b, level) and replayed.  Recording changes how launches are
+submitted, not what is launched, so every cycle must give bit-identical results to ordinary launches."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+MESHES = ROOT / "tests" / "golden" / "meshes"
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    from hyteg_amd import capi, host
+
+    assert torch.cuda.is_available()
+    capi.lib()
+    host.lib()
+    return torch, capi, host
+
+
+def _cycles(torch, capi, host, mesh, lo, hi, smoother, graphs, wcycle=False, ncycles=4, stream=None):
+    st = host.Storage.from_gmsh(MESHES / f"{mesh}.msh")
+    st.set_stream(stream.cuda_stream if stream is not None else torch.cuda.current_stream().cuda_stream)
+    A = host.P1ConstantOperator(st, lo, hi)
+    A.compute_inverse_diagonal()
+    x, b = host.P1Function(st, "x", lo, hi), host.P1Function(st, "b", lo, hi)
+    rng = np.random.default_rng(3)
+    for c in range(st.n_local_cells):
+        x.upload_cell(c, hi, rng.random(capi.cell_size(hi)))
+    x.sync_shared(hi, host.All)
+    x.interpolate(0.0, hi, host.DirichletBoundary)
+    b.interpolate(1.0, hi, host.Inner)
+    gmg = host.Solver.gmg(st, lo, hi, smoother=smoother, relax=2.0 / 3.0, pre=2, post=2, wcycle=wcycle, cg_max_iter=200, cg_tol=1e-13)
+    gmg.set_use_graphs(graphs)
+    out = []
+    for _ in range(ncycles):
+        gmg.solve(A, x, b, hi)
+        if stream is not None:
+            stream.synchronize()
+        out.append([x.download_cell(c, hi) for c in range(st.n_local_cells)])
+    return out, gmg.replayed_cycles
+
+
+@pytest.mark.parametrize("mesh,lo,hi", [("tet_1el", 2, 5), ("regular_octahedron_8el", 0, 3), ("regular_octahedron_8el", 2, 4)])
+@pytest.mark.parametrize("smoother", ["JACOBI", "GAUSS_SEIDEL"])
+def test_replayed_cycles_are_bit_identical(env, mesh, lo, hi, smoother):
+    torch, capi, host = env
+    live, n0 = _cycles(torch, capi, host, mesh, lo, hi, getattr(host, smoother), graphs=False)
+    rec, n1 = _cycles(torch, capi, host, mesh, lo, hi, getattr(host, smoother), graphs=True)
+    assert n0 == 0
+    assert n1 == 3  # cycle 1 runs with ordinary launches, cycle 2 records and replays, cycles 3 and 4 replay
+    for a, b in zip(live, rec):
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v)
+    # the cycles do something: the iterate changes from cycle to cycle
+    assert not np.array_equal(rec[0][0], rec[3][0])
+
+
+def test_w_cycle_and_a_side_stream(env):
+    """a W-cycle has 2^(levels-1) coarse-grid solves, hence as many + 1 recorded segments; the storage's stream is a
+    torch side stream here (the recording itself always runs on a private stream of the solver)"""
+    torch, capi, host = env
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        live, _ = _cycles(torch, capi, host, "tet_1el", 2, 5, host.JACOBI, graphs=False, wcycle=True, stream=side)
+        rec, n = _cycles(torch, capi, host, "tet_1el", 2, 5, host.JACOBI, graphs=True, wcycle=True, stream=side)
+    assert n == 3
+    for a, b in zip(live, rec):
+        assert np.array_equal(a[0], b[0])
+
+
+def test_new_functions_get_their_own_recording(env):
+    torch, capi, host = env
+    st = host.Storage.from_gmsh(MESHES / "tet_1el.msh")
+    st.set_stream(torch.cuda.current_stream().cuda_stream)
+    A = host.P1ConstantOperator(st, 2, 4)
+    A.compute_inverse_diagonal()
+    gmg = host.Solver.gmg(st, 2, 4, smoother=host.JACOBI, pre=1, post=1)
+    results = []
+    for k in range(2):
+        x, b = host.P1Function(st, f"x{k}", 2, 4), host.P1Function(st, f"b{k}", 2, 4)
+        b.interpolate(1.0 + k, 4, host.Inner)
+        for _ in range(3):
+            gmg.solve(A, x, b, 4)
+        results.append(x.download_cell(0, 4))
+    assert gmg.replayed_cycles == 4
+    # the problem is linear and x starts at 0: the second right-hand side is twice the first
+    assert np.allclose(results[1], 2.0 * results[0], rtol=1e-12, atol=0)
+    assert np.abs(results[0]).max() > 0
