@@ -2334,6 +2334,13 @@ class Solver
    using FunctionType = typename OperatorType::srcType;
    virtual ~Solver()  = default;
    virtual void solve( const OperatorType& A, const FunctionType& x, const FunctionType& b, uint_t level ) = 0;
+   // `steps` consecutive solve() calls (the pre-/post-smoothing loops of GeometricMultigridSolver.hpp:228-233,300-305);
+   // a smoother may override it with something equivalent but cheaper
+   virtual void solveSteps( const OperatorType& A, const FunctionType& x, const FunctionType& b, uint_t level, uint_t steps )
+   {
+      for ( uint_t i = 0; i < steps; ++i )
+         solve( A, x, b, level );
+   }
 };
 
 // WeightedJacobiSmoother.hpp:46-62
@@ -2350,6 +2357,24 @@ class WeightedJacobiSmoother : public Solver< OperatorType >
    {
       tmp_.assign( { 1.0 }, { x }, level, All );
       A.smooth_jac( x, b, tmp_, relax_, level, flag_ );
+   }
+   // n steps with ONE copy instead of n: after tmp = x (all points) a Jacobi step may just as well write into tmp
+   // reading x, since a step only writes the points `flag_` selects and all other entries of the two functions agree.
+   // Every step computes exactly what solve() computes (same kernel, same operands): results are bit-identical.
+   void solveSteps( const OperatorType& A, const P1Function< double >& x, const P1Function< double >& b, uint_t level, uint_t steps ) override
+   {
+      if ( steps == 0 )
+         return;
+      tmp_.assign( { 1.0 }, { x }, level, All );
+      for ( uint_t i = 0; i < steps; ++i )
+      {
+         if ( i % 2 == 0 )
+            A.smooth_jac( x, b, tmp_, relax_, level, flag_ );
+         else
+            A.smooth_jac( tmp_, b, x, relax_, level, flag_ );
+      }
+      if ( steps % 2 == 0 )
+         x.assign( { 1.0 }, { tmp_ }, level, flag_ );
    }
 
  private:
@@ -2619,8 +2644,7 @@ class GeometricMultigridSolver : public Solver< OperatorType >
          return;
       }
       const uint_t pre = preSmoothSteps_ + smoothIncrement_ * ( invokedLevel_ - level );
-      for ( uint_t i = 0; i < pre; ++i )
-         smoother_->solve( A, x, b, level );
+      smoother_->solveSteps( A, x, b, level, pre );
       A.apply( x, tmp_, level, flag_ );
       tmp_.assign( { 1.0, -1.0 }, { b, tmp_ }, level, flag_ );
       restrictionOperator_->restrict( tmp_, level, flag_ );
@@ -2631,8 +2655,7 @@ class GeometricMultigridSolver : public Solver< OperatorType >
          solveRecursively( A, x, b, level - 1 );
       prolongationOperator_->prolongateAndAdd( x, level - 1, flag_ );
       const uint_t post = postSmoothSteps_ + smoothIncrement_ * ( invokedLevel_ - level );
-      for ( uint_t i = 0; i < post; ++i )
-         smoother_->solve( A, x, b, level );
+      smoother_->solveSteps( A, x, b, level, post );
    }
 
    uint_t                                       minLevel_, maxLevel_, preSmoothSteps_, postSmoothSteps_, smoothIncrement_;
