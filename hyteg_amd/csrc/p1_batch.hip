@@ -77,6 +77,7 @@ struct VecB
 {
    Cells< 1 + HYTEG_HIP_MAX_SRCS > c;
    double                          s[HYTEG_HIP_MAX_SRCS];
+   const double*                   sp[HYTEG_HIP_MAX_SRCS]; // non-null: the coefficient is read from device memory
    const Tile*                     tiles;
    int                             N, nsrc, op; // op 0 assign, 1 add, 2 mult, 3 set constant s[0]
 };
@@ -88,6 +89,10 @@ __global__ __launch_bounds__( kThreads ) void batch_vector_kernel( const VecB A 
    const int      cell = blockIdx.y;
    const unsigned mask = A.c.mask[cell];
    double*        dst  = A.c.p[0][cell];
+   double         s[NSRC];
+#pragma unroll
+   for ( int k = 0; k < NSRC; ++k )
+      s[k] = A.sp[k] ? *A.sp[k] : A.s[k];
 #pragma unroll
    for ( int u = 0; u < kPer; ++u )
    {
@@ -96,7 +101,7 @@ __global__ __launch_bounds__( kThreads ) void batch_vector_kernel( const VecB A 
          continue;
       double tmp;
       if ( A.op == 3 )
-         tmp = A.s[0];
+         tmp = s[0];
       else if ( A.op == 2 )
       {
          tmp = A.c.p[1][cell][p.i];
@@ -106,10 +111,10 @@ __global__ __launch_bounds__( kThreads ) void batch_vector_kernel( const VecB A 
       }
       else
       {
-         tmp = A.s[0] * A.c.p[1][cell][p.i];
+         tmp = s[0] * A.c.p[1][cell][p.i];
 #pragma unroll
          for ( int k = 1; k < NSRC; ++k )
-            tmp += A.s[k] * A.c.p[1 + k][cell][p.i];
+            tmp += s[k] * A.c.p[1 + k][cell][p.i];
          if ( A.op == 1 )
             tmp = dst[p.i] + tmp;
       }
@@ -335,20 +340,21 @@ extern "C" {
    HH_REQUIRE( batch_level_ok( level ), name ": level out of range [0,11]" );                                 \
    HH_REQUIRE( masks != nullptr, name ": null masks" );
 
-HYTEG_HIP_API int hyteg_hip_p1_vector_cells( int                  op,
-                                             int                  ncells,
-                                             double* const*       dst,
-                                             int                  nsrc,
-                                             const double* const* srcs,
-                                             const double*        scalars,
-                                             int                  level,
-                                             const unsigned*      masks,
-                                             hyteg_hip_stream_t   stream )
+static int launch_vector_b( int                  op,
+                            int                  ncells,
+                            double* const*       dst,
+                            int                  nsrc,
+                            const double* const* srcs,
+                            const double*        scalars,
+                            const double* const* scalar_ptrs,
+                            int                  level,
+                            const unsigned*      masks,
+                            hyteg_hip_stream_t   stream )
 {
    BATCH_CHECKS( "p1_vector_cells" );
    HH_REQUIRE( op >= 0 && op <= 3 && dst, "p1_vector_cells: bad op or null dst" );
    HH_REQUIRE( op == 3 ? scalars != nullptr : ( nsrc >= 1 && nsrc <= HYTEG_HIP_MAX_SRCS && srcs ), "p1_vector_cells: bad sources" );
-   HH_REQUIRE( op == 2 || op == 3 || scalars, "p1_vector_cells: null scalars" );
+   HH_REQUIRE( op == 2 || op == 3 || scalars || scalar_ptrs, "p1_vector_cells: null scalars" );
    TileTable tt;
    int       rc = full_tiles( level, &tt );
    if ( rc != HYTEG_HIP_OK )
@@ -374,7 +380,10 @@ HYTEG_HIP_API int hyteg_hip_p1_vector_cells( int                  op,
       A.s[0] = scalars[0];
    else
       for ( int k = 0; k < nsrc; ++k )
-         A.s[k] = scalars ? scalars[k] : 1.0;
+      {
+         A.s[k]  = scalars ? scalars[k] : 1.0;
+         A.sp[k] = scalar_ptrs ? scalar_ptrs[k] : nullptr;
+      }
    A.tiles = tt.dev, A.N = ( 1 << level ) + 1, A.nsrc = nsrc, A.op = op;
    const dim3 grid( tt.count, ncells );
    switch ( op == 3 ? 1 : nsrc )
@@ -392,6 +401,81 @@ HYTEG_HIP_API int hyteg_hip_p1_vector_cells( int                  op,
       hipLaunchKernelGGL( batch_vector_kernel< 4 >, grid, dim3( kThreads ), 0, as_stream( stream ), A );
       break;
    }
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_p1_vector_cells( int                  op,
+                                             int                  ncells,
+                                             double* const*       dst,
+                                             int                  nsrc,
+                                             const double* const* srcs,
+                                             const double*        scalars,
+                                             int                  level,
+                                             const unsigned*      masks,
+                                             hyteg_hip_stream_t   stream )
+{
+   return launch_vector_b( op, ncells, dst, nsrc, srcs, scalars, nullptr, level, masks, stream );
+}
+
+HYTEG_HIP_API int hyteg_hip_p1_vector_cells_dev( int                  op,
+                                                 int                  ncells,
+                                                 double* const*       dst,
+                                                 int                  nsrc,
+                                                 const double* const* srcs,
+                                                 const double* const* scalar_ptrs,
+                                                 int                  level,
+                                                 const unsigned*      masks,
+                                                 hyteg_hip_stream_t   stream )
+{
+   HH_REQUIRE( ( op == 0 || op == 1 ) && scalar_ptrs, "p1_vector_cells_dev: op must be 0 (assign) or 1 (add), scalar pointers non-null" );
+   for ( int k = 0; k < nsrc && k < HYTEG_HIP_MAX_SRCS; ++k )
+      HH_REQUIRE( scalar_ptrs[k], "p1_vector_cells_dev: null scalar pointer" );
+   return launch_vector_b( op, ncells, dst, nsrc, srcs, nullptr, scalar_ptrs, level, masks, stream );
+}
+
+namespace {
+// scalar recurrences of the conjugate gradient iteration (CGSolver.hpp:91-140 of the reference keeps them on the host),
+// one thread; s: HYTEG_HIP_CG_* slots
+__global__ void cg_scalars_kernel( double* s, int phase, double relTol, double absTol )
+{
+   if ( threadIdx.x != 0 || blockIdx.x != 0 )
+      return;
+   const bool done = s[HYTEG_HIP_CG_DONE] != 0.0;
+   if ( phase == 0 )
+   {
+      s[HYTEG_HIP_CG_PRSOLD]     = s[HYTEG_HIP_CG_RR];
+      s[HYTEG_HIP_CG_RES_START]  = sqrt( s[HYTEG_HIP_CG_RR] );
+      s[HYTEG_HIP_CG_DONE]       = s[HYTEG_HIP_CG_RES_START] < absTol ? 1.0 : 0.0;
+      s[HYTEG_HIP_CG_ITERATIONS] = 0.0;
+      s[HYTEG_HIP_CG_ONE]        = 1.0;
+      s[HYTEG_HIP_CG_ALPHA] = s[HYTEG_HIP_CG_NEG_ALPHA] = s[HYTEG_HIP_CG_BETA] = 0.0;
+   }
+   else if ( phase == 1 )
+   {
+      const double alpha        = done ? 0.0 : s[HYTEG_HIP_CG_PRSOLD] / s[HYTEG_HIP_CG_PAP];
+      s[HYTEG_HIP_CG_ALPHA]     = alpha;
+      s[HYTEG_HIP_CG_NEG_ALPHA] = -alpha;
+   }
+   else if ( !done )
+   {
+      const double rsnew = s[HYTEG_HIP_CG_RR], sq = sqrt( rsnew );
+      s[HYTEG_HIP_CG_ITERATIONS] += 1.0;
+      if ( sq / s[HYTEG_HIP_CG_RES_START] < relTol || sq < absTol )
+         s[HYTEG_HIP_CG_DONE] = 1.0;
+      else
+      {
+         s[HYTEG_HIP_CG_BETA]   = rsnew / s[HYTEG_HIP_CG_PRSOLD];
+         s[HYTEG_HIP_CG_PRSOLD] = rsnew;
+      }
+   }
+}
+} // namespace
+
+HYTEG_HIP_API int hyteg_hip_cg_scalars( double* s_dev, int phase, double rel_tol, double abs_tol, hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( s_dev && phase >= 0 && phase <= 2, "cg_scalars: null pointer or phase not in 0..2" );
+   hipLaunchKernelGGL( cg_scalars_kernel, dim3( 1 ), dim3( 64 ), 0, as_stream( stream ), s_dev, phase, rel_tol, abs_tol );
    HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;
 }

@@ -61,6 +61,8 @@ SIGNATURES = {
     "hyteg_host_prolongate_and_add": (_i, [_vp, _i, _i]),
     "hyteg_host_gmg_create": (_i, [_vp, _i, _i, _i, _d, _i, _i, _i, _i, _d, C.POINTER(_vp)]),
     "hyteg_host_gmg_set_use_graphs": (_i, [_vp, _i]),
+    "hyteg_host_cg_set_use_device_scalars": (_i, [_vp, _i]),
+    "hyteg_host_cg_iterations": (_i, [_vp, C.POINTER(_i)]),
     "hyteg_host_gmg_replayed_cycles": (_i, [_vp, C.POINTER(_i)]),
     "hyteg_host_cg_create": (_i, [_vp, _i, _i, _i, _d, C.POINTER(_vp)]),
     "hyteg_host_solver_solve": (_i, [_vp, _vp, _vp, _vp, _i]),
@@ -347,6 +349,16 @@ class Solver:
     def set_use_graphs(self, on: bool) -> None:
         """GeometricMultigridSolver::setUseGraphs: record the launches of a cycle once, replay them as graphs (default on)"""
         _ck(lib().hyteg_host_gmg_set_use_graphs(self.h, int(on)), "gmg_set_use_graphs")
+
+    def set_use_device_scalars(self, on: bool) -> None:
+        """CGSolver::setUseDeviceScalars (for a multigrid solver: of its coarse-grid CG)"""
+        _ck(lib().hyteg_host_cg_set_use_device_scalars(self.h, int(on)), "cg_set_use_device_scalars")
+
+    @property
+    def iterations(self) -> int:
+        n = _i(0)
+        _ck(lib().hyteg_host_cg_iterations(self.h, C.byref(n)), "cg_iterations")
+        return n.value
 
     @property
     def replayed_cycles(self) -> int:

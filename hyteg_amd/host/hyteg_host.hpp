@@ -1138,6 +1138,36 @@ class P1Function
       } );
    }
 
+ public:
+   // assign (op 0) / add (op 1) with coefficients read from device memory when the kernels run; storages of one rank
+   // with at most HYTEG_HIP_MAX_BATCH local cells (one launch)
+   void vectorOpDeviceScalars( int op, const std::vector< const double* >& scalarPtrs,
+                               const std::vector< std::reference_wrapper< const P1Function< ValueType > > >& functions, uint_t level,
+                               DoFType flag ) const
+   {
+      const int  count = (int) storage_->getNumberOfLocalCells();
+      const auto masks = storage_->masksFor( flag );
+      const auto dst   = cellPointers( level, 0, count );
+      std::vector< double* > srcs;
+      for ( const auto& f : functions )
+         for ( double* q : f.get().cellPointers( level, 0, count ) )
+            srcs.push_back( q );
+      hipCheck( hyteg_hip_p1_vector_cells_dev( op, count, dst.data(), (int) functions.size(), srcs.data(), scalarPtrs.data(), (int) level,
+                                               masks.data(), storage_->stream() ),
+                "P1Function vector op (device scalars)" );
+   }
+   // *resultDev = <this, rhs> over the points `flag` selects (each shared point counted once); no host synchronisation
+   void dotLocalToDevice( const P1Function< ValueType >& rhs, uint_t level, DoFType flag, double* resultDev ) const
+   {
+      const int  count = (int) storage_->getNumberOfLocalCells();
+      const auto masks = storage_->masksFor( flag, true );
+      const auto a = cellPointers( level, 0, count ), b = rhs.cellPointers( level, 0, count );
+      hipCheck( hyteg_hip_p1_dot_cells( count, a.data(), b.data(), (int) level, masks.data(), resultDev, storage_->dotWorkspace(),
+                                        storage_->stream() ),
+                "dotLocalToDevice" );
+   }
+
+ private:
    // device table [ local cell arrays at `level` ..., receive segment of peer 0, peer 1, ... ]
    double** basesFor( uint_t level, int cls ) const
    {
@@ -2427,8 +2457,26 @@ class CGSolver : public Solver< OperatorType >
    , relTol_( relativeTolerance )
    , absTol_( absoluteTolerance )
    {}
+   ~CGSolver() override
+   {
+      if ( scalars_ )
+         hyteg_hip_free( scalars_ );
+   }
+   // Device-resident scalars (no counterpart in the reference, whose loop reads every dot product on the host): on
+   // coarse levels a CG iteration is ~10 launches of a few microseconds, and three host round trips per iteration
+   // cost more than the launches.  alpha, beta and the convergence test are computed by a one-thread kernel
+   // (hyteg_hip_cg_scalars), the vector updates read them from device memory, and the host looks at the convergence
+   // flag every 4 iterations; iterations enqueued after convergence are exact no-ops (alpha = 0).  Same recurrences,
+   // same arithmetic as the loop below.  Used for storages of one rank, up to level 5; off: HYTEG_AMD_DEVICE_CG=0.
+   void setUseDeviceScalars( bool on ) { useDeviceScalars_ = on; }
+
    void solve( const OperatorType& A, const FunctionType& x, const FunctionType& b, uint_t level ) override
    {
+      if ( deviceScalarsUsable( x, level ) )
+      {
+         solveWithDeviceScalars( A, x, b, level );
+         return;
+      }
       p_.setToZero( level );
       z_.setToZero( level );
       ap_.setToZero( level );
@@ -2455,16 +2503,75 @@ class CGSolver : public Solver< OperatorType >
          iterations_          = i + 1;
          if ( sqrsnew / res_start < relTol_ || sqrsnew < absTol_ )
             break;
-         z_.assign( { 1.0 }, { r_ }, level, flag_ );
-         const double prsnew = r_.dotGlobal( z_, level, flag_ );
+         // identity preconditioner: z = r, so <r,z> is the <r,r> just computed (the reference copies and reduces again)
+         const double prsnew = rsnew;
          const double beta   = prsnew / prsold;
-         p_.assign( { 1.0, beta }, { z_, p_ }, level, flag_ );
+         p_.assign( { 1.0, beta }, { r_, p_ }, level, flag_ );
          prsold = prsnew;
       }
    }
    uint_t getIterations() const { return iterations_; }
 
  private:
+   template < typename F >
+   bool deviceScalarsUsable( const F&, uint_t ) const
+   {
+      return false; // P2 functions: host scalars
+   }
+   bool deviceScalarsUsable( const P1Function< double >& x, uint_t level ) const
+   {
+      static const bool envOn = [] {
+         const char* e = std::getenv( "HYTEG_AMD_DEVICE_CG" );
+         return !( e && e[0] == '0' );
+      }();
+      const auto& st = *x.getStorage();
+      return envOn && useDeviceScalars_ && st.numRanks() == 1 && level <= 5 && st.getNumberOfLocalCells() >= 1 &&
+             st.getNumberOfLocalCells() <= HYTEG_HIP_MAX_BATCH;
+   }
+   template < typename F >
+   void solveWithDeviceScalars( const OperatorType&, const F&, const F&, uint_t )
+   {}
+   void solveWithDeviceScalars( const OperatorType& A, const P1Function< double >& x, const P1Function< double >& b, uint_t level )
+   {
+      const auto& st = *x.getStorage();
+      if ( !scalars_ )
+      {
+         void* d = nullptr;
+         hipCheck( hyteg_hip_malloc( &d, HYTEG_HIP_CG_SLOTS * sizeof( double ) ), "CGSolver: scalars" );
+         scalars_ = static_cast< double* >( d );
+      }
+      double* const S = scalars_;
+      p_.setToZero( level ); // apply( p ) reads p on every point; assign below writes only the points flag_ selects
+      A.apply( x, p_, level, flag_, Replace );
+      r_.assign( { 1.0, -1.0 }, { b, p_ }, level, flag_ );
+      p_.assign( { 1.0 }, { r_ }, level, flag_ );
+      hipCheck( hyteg_hip_memset_zero( S, HYTEG_HIP_CG_SLOTS * sizeof( double ), st.stream() ), "CGSolver: scalars reset" );
+      r_.dotLocalToDevice( r_, level, flag_, S + HYTEG_HIP_CG_RR );
+      hipCheck( hyteg_hip_cg_scalars( S, 0, relTol_, absTol_, st.stream() ), "CGSolver: scalars" );
+      iterations_ = 0;
+      for ( uint_t i = 0; i < maxIter_; ++i )
+      {
+         A.apply( p_, ap_, level, flag_, Replace );
+         p_.dotLocalToDevice( ap_, level, flag_, S + HYTEG_HIP_CG_PAP );
+         hipCheck( hyteg_hip_cg_scalars( S, 1, relTol_, absTol_, st.stream() ), "CGSolver: scalars" );
+         x.vectorOpDeviceScalars( 1, { S + HYTEG_HIP_CG_ALPHA }, { p_ }, level, flag_ );
+         r_.vectorOpDeviceScalars( 1, { S + HYTEG_HIP_CG_NEG_ALPHA }, { ap_ }, level, flag_ );
+         r_.dotLocalToDevice( r_, level, flag_, S + HYTEG_HIP_CG_RR );
+         hipCheck( hyteg_hip_cg_scalars( S, 2, relTol_, absTol_, st.stream() ), "CGSolver: scalars" );
+         p_.vectorOpDeviceScalars( 0, { S + HYTEG_HIP_CG_ONE, S + HYTEG_HIP_CG_BETA }, { r_, p_ }, level, flag_ );
+         if ( ( i + 1 ) % 4 == 0 || i + 1 == maxIter_ )
+         {
+            double h[2];
+            hipCheck( hyteg_hip_download( h, S + HYTEG_HIP_CG_DONE, 2 * sizeof( double ), st.stream() ), "CGSolver: convergence flag" );
+            iterations_ = (uint_t) h[1];
+            if ( h[0] != 0.0 )
+               break;
+         }
+      }
+   }
+
+   bool                 useDeviceScalars_ = true;
+   double*              scalars_          = nullptr;
    FunctionType         p_, z_, ap_, r_;
    DoFType              flag_;
    uint_t               maxIter_;
@@ -2520,6 +2627,7 @@ class GeometricMultigridSolver : public Solver< OperatorType >
    // Off: setUseGraphs( false ) or HYTEG_AMD_GRAPHS=0; never used for storages distributed over several ranks (the
    // exchange hooks are host callbacks).
    void setUseGraphs( bool on ) { useGraphs_ = on; }
+   std::shared_ptr< Solver< OperatorType > > getCoarseSolver() const { return coarseSolver_; }
    bool usesGraphs() const { return graphsUsable(); }
    // number of cycles that were replayed from a recording (tests)
    uint_t replayedCycles() const { return replayed_; }

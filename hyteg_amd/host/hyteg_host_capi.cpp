@@ -333,6 +333,28 @@ HYTEG_HOST_API int hyteg_host_gmg_set_use_graphs( hh_solver_t solver, int on )
       g->setUseGraphs( on != 0 );
    } );
 }
+HYTEG_HOST_API int hyteg_host_cg_set_use_device_scalars( hh_solver_t solver, int on )
+{
+   return guarded( [&] {
+      using Op = P1ConstantLaplaceOperator;
+      auto sp  = static_cast< SolverH* >( solver )->p;
+      if ( auto g = std::dynamic_pointer_cast< GeometricMultigridSolver< Op > >( sp ) )
+         sp = g->getCoarseSolver();
+      auto cg = std::dynamic_pointer_cast< CGSolver< Op > >( sp );
+      if ( !cg )
+         throw std::runtime_error( "cg_set_use_device_scalars: neither a CG solver nor a multigrid solver with a CG coarse solver" );
+      cg->setUseDeviceScalars( on != 0 );
+   } );
+}
+HYTEG_HOST_API int hyteg_host_cg_iterations( hh_solver_t solver, int* iterations )
+{
+   return guarded( [&] {
+      auto cg = std::dynamic_pointer_cast< CGSolver< P1ConstantLaplaceOperator > >( static_cast< SolverH* >( solver )->p );
+      if ( !cg )
+         throw std::runtime_error( "cg_iterations: not a CG solver" );
+      *iterations = (int) cg->getIterations();
+   } );
+}
 HYTEG_HOST_API int hyteg_host_gmg_replayed_cycles( hh_solver_t solver, int* count )
 {
    return guarded( [&] {

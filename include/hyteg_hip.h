@@ -348,6 +348,41 @@ HYTEG_HIP_API int hyteg_hip_p1_vector_cells( int                  op,
                                              int                  level,
                                              const unsigned*      masks,
                                              hyteg_hip_stream_t   stream );
+/* assign / add whose coefficients are read from device memory when the kernel runs (scalar_ptrs: host array of nsrc
+ * device pointers): lets an iteration whose scalars are themselves results of device reductions proceed without a
+ * host round trip per scalar (the conjugate gradient recurrences below) */
+HYTEG_HIP_API int hyteg_hip_p1_vector_cells_dev( int                  op,
+                                                 int                  ncells,
+                                                 double* const*       dst,
+                                                 int                  nsrc,
+                                                 const double* const* srcs,
+                                                 const double* const* scalar_ptrs,
+                                                 int                  level,
+                                                 const unsigned*      masks,
+                                                 hyteg_hip_stream_t   stream );
+/* Scalar recurrences of CGSolver::solve (src/hyteg/solvers/CGSolver.hpp:91-140; identity preconditioner) on the device.
+ * s_dev: HYTEG_HIP_CG_SLOTS doubles.  The caller writes the dot products into RR / PAP (hyteg_hip_p1_dot_cells) and calls
+ *   phase 0  after RR = <r,r> of the initial residual: prsold = RR, res_start = sqrt(RR), done = res_start < abs_tol
+ *   phase 1  after PAP = <p,Ap>:  alpha = prsold / PAP, NEG_ALPHA = -alpha        (both 0 once done)
+ *   phase 2  after RR = <r,r>:    iterations += 1; done if sqrt(RR)/res_start < rel_tol or sqrt(RR) < abs_tol,
+ *                                 else beta = RR / prsold, prsold = RR            (nothing once done)
+ * With alpha = 0 the updates x += alpha p, r -= alpha Ap leave x and r as they are, so iterations enqueued beyond
+ * convergence change nothing and the host only needs to look at DONE every few iterations. */
+enum hyteg_hip_cg_slot
+{
+   HYTEG_HIP_CG_PRSOLD     = 0,
+   HYTEG_HIP_CG_PAP        = 1,
+   HYTEG_HIP_CG_RR         = 2,
+   HYTEG_HIP_CG_ALPHA      = 3,
+   HYTEG_HIP_CG_NEG_ALPHA  = 4,
+   HYTEG_HIP_CG_BETA       = 5,
+   HYTEG_HIP_CG_RES_START  = 6,
+   HYTEG_HIP_CG_DONE       = 7,
+   HYTEG_HIP_CG_ITERATIONS = 8,
+   HYTEG_HIP_CG_ONE        = 9,
+   HYTEG_HIP_CG_SLOTS      = 16
+};
+HYTEG_HIP_API int hyteg_hip_cg_scalars( double* s_dev, int phase, double rel_tol, double abs_tol, hyteg_hip_stream_t stream );
 /* *result_dev = sum over all cells and masked points of a.b (two launches); workspace: hyteg_hip_dot_workspace_bytes() */
 HYTEG_HIP_API int hyteg_hip_p1_dot_cells( int                  ncells,
                                           const double* const* a,

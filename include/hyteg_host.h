@@ -99,6 +99,11 @@ HYTEG_HOST_API int hyteg_host_gmg_create( hh_storage_t s, int min_level, int max
  * rank; replayed_cycles counts the cycles that ran from a recording */
 HYTEG_HOST_API int hyteg_host_gmg_set_use_graphs( hh_solver_t solver, int on );
 HYTEG_HOST_API int hyteg_host_gmg_replayed_cycles( hh_solver_t solver, int* count );
+/* CGSolver::setUseDeviceScalars (hyteg_host.hpp): alpha, beta and the convergence test stay on the device (default on for
+ * storages of one rank up to level 5); `solver` is a CG solver or a multigrid solver whose coarse solver is one */
+HYTEG_HOST_API int hyteg_host_cg_set_use_device_scalars( hh_solver_t solver, int on );
+/* CGSolver::getIterations of the last solve */
+HYTEG_HOST_API int hyteg_host_cg_iterations( hh_solver_t solver, int* iterations );
 HYTEG_HOST_API int hyteg_host_cg_create( hh_storage_t s, int min_level, int max_level, int max_iter, double tol, hh_solver_t* out );
 HYTEG_HOST_API int hyteg_host_solver_solve( hh_solver_t solver, hh_operator_t laplace, hh_function_t x, hh_function_t b, int level );
 HYTEG_HOST_API int hyteg_host_solver_destroy( hh_solver_t solver );

@@ -92,3 +92,41 @@ def test_new_functions_get_their_own_recording(env):
     # the problem is linear and x starts at 0: the second right-hand side is twice the first
     assert np.allclose(results[1], 2.0 * results[0], rtol=1e-12, atol=0)
     assert np.abs(results[0]).max() > 0
+
+
+@pytest.mark.parametrize("mesh,level", [("tet_1el", 3), ("regular_octahedron_8el", 2), ("regular_octahedron_8el", 4), ("cube_6el", 3)])
+def test_cg_with_device_scalars_matches_the_host_loop(env, mesh, level):
+    """CGSolver::solveWithDeviceScalars keeps alpha, beta and the convergence test on the device (hyteg_hip_cg_scalars);
+    the recurrences are the reference's (CGSolver.hpp:91-140), so iterates agree with the host loop up to the rounding
+    of the dot products (batched vs per-cell reduction order) and the iteration counts are equal"""
+    torch, capi, host = env
+    import sys
+
+    sys.path.insert(0, str(ROOT / "tests"))
+    from hostutil import cell_points
+
+    out = []
+    for dev in (False, True):
+        st = host.Storage.from_gmsh(MESHES / f"{mesh}.msh")
+        st.set_stream(torch.cuda.current_stream().cuda_stream)
+        A = host.P1ConstantOperator(st, level, level)
+        x, b, xe = (host.P1Function(st, n, level, level) for n in ("x", "b", "xe"))
+        for c in range(st.n_local_cells):
+            gid, co, nnc = st.local_cell(c)
+            P = cell_points(co, level)
+            xe.upload_cell(c, level, np.ascontiguousarray(np.sin(3 * P[:, 0]) * P[:, 1] + P[:, 2] ** 2))
+        xe.interpolate(0.0, level, host.DirichletBoundary)
+        A.apply(xe, b, level, host.Inner)
+        cg = host.Solver.cg(st, level, level, 300, 1e-13)
+        cg.set_use_device_scalars(dev)
+        cg.solve(A, x, b, level)
+        err = host.P1Function(st, "err", level, level)
+        err.assign([1.0, -1.0], [x, xe], level, host.Inner)
+        rel = np.sqrt(err.dot(err, level, host.Inner) / xe.dot(xe, level, host.Inner))
+        out.append(([x.download_cell(c, level) for c in range(st.n_local_cells)], rel, cg.iterations))
+    (xh, relh, ith), (xd, reld, itd) = out
+    assert relh < 1e-9 and reld < 1e-9
+    assert abs(ith - itd) <= 1  # a residual within rounding of the tolerance may fall on either side
+    scale = max(np.abs(a).max() for a in xh)
+    for a, b_ in zip(xh, xd):
+        assert np.abs(a - b_).max() <= 1e-9 * scale
