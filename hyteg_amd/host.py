@@ -347,7 +347,7 @@ class Solver:
         _ck(lib().hyteg_host_solver_solve(self.h, laplace.h, x.h, b.h, level), "solve")
 
     def set_use_graphs(self, on: bool) -> None:
-        """GeometricMultigridSolver::setUseGraphs: record the launches of a cycle once, replay them as graphs (default on)"""
+        """GeometricMultigridSolver::setUseGraphs: record the launches of a cycle once, replay them as graphs (default off)"""
         _ck(lib().hyteg_host_gmg_set_use_graphs(self.h, int(on)), "gmg_set_use_graphs")
 
     def set_use_device_scalars(self, on: bool) -> None:

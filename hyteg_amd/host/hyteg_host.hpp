@@ -2624,8 +2624,10 @@ class GeometricMultigridSolver : public Solver< OperatorType >
    // host and stays outside).  The first cycle with given arguments runs with ordinary launches (it creates every lazily
    // built table and scratch array), the second records (nothing executes while recording) and replays, later cycles
    // replay.  Same kernels, same order, same arguments: results are identical to ordinary launches.
-   // Off: setUseGraphs( false ) or HYTEG_AMD_GRAPHS=0; never used for storages distributed over several ranks (the
-   // exchange hooks are host callbacks).
+   // Opt-in: setUseGraphs( true ) or HYTEG_AMD_GRAPHS=1.  Measured on MI355X the replay saves only 1-8 % of a cycle (the
+   // cycle is bound by the ~3 us a dependent small kernel takes on the GPU, not by the host's launch rate), while
+   // recording and instantiating costs a few milliseconds once -- it pays for solves of many cycles only.  Never
+   // used for storages distributed over several ranks (the exchange hooks are host callbacks).
    void setUseGraphs( bool on ) { useGraphs_ = on; }
    std::shared_ptr< Solver< OperatorType > > getCoarseSolver() const { return coarseSolver_; }
    bool usesGraphs() const { return graphsUsable(); }
@@ -2688,13 +2690,11 @@ class GeometricMultigridSolver : public Solver< OperatorType >
 
    bool graphsUsable() const
    {
-      if ( !useGraphs_ || storage_->numRanks() != 1 )
-         return false;
       static const bool envOn = [] {
          const char* e = std::getenv( "HYTEG_AMD_GRAPHS" );
-         return !( e && e[0] == '0' );
+         return e && e[0] == '1';
       }();
-      return envOn;
+      return ( useGraphs_ || envOn ) && storage_->numRanks() == 1;
    }
 
    void endSegment( Recording& rec )
@@ -2775,7 +2775,7 @@ class GeometricMultigridSolver : public Solver< OperatorType >
    std::shared_ptr< P1toP1LinearProlongation >  prolongationOperator_;
    P1Function< double >                         tmp_;
    std::shared_ptr< PrimitiveStorage >          storage_;
-   bool                                         useGraphs_ = true, capturing_ = false;
+   bool                                         useGraphs_ = false, capturing_ = false;
    hyteg_hip_stream_t                           captureStream_ = nullptr;
    Recording*                                   recording_     = nullptr;
    std::map< Key, Recording >                   recordings_;

@@ -95,8 +95,8 @@ HYTEG_HOST_API int hyteg_host_prolongate_and_add( hh_function_t f, int source_le
  * smoother: 0 = weighted Jacobi (relax), 1 = Gauss-Seidel, 2 = SOR (relax).  Coarse grid: CG. */
 HYTEG_HOST_API int hyteg_host_gmg_create( hh_storage_t s, int min_level, int max_level, int smoother, double relax, int pre, int post,
                                           int wcycle, int cg_max_iter, double cg_tol, hh_solver_t* out );
-/* launch graphs of the cycle (hyteg_host.hpp, GeometricMultigridSolver::setUseGraphs): on by default for storages of one
- * rank; replayed_cycles counts the cycles that ran from a recording */
+/* launch graphs of the cycle (hyteg_host.hpp, GeometricMultigridSolver::setUseGraphs): opt-in, storages of one rank;
+ * replayed_cycles counts the cycles that ran from a recording */
 HYTEG_HOST_API int hyteg_host_gmg_set_use_graphs( hh_solver_t solver, int on );
 HYTEG_HOST_API int hyteg_host_gmg_replayed_cycles( hh_solver_t solver, int* count );
 /* CGSolver::setUseDeviceScalars (hyteg_host.hpp): alpha, beta and the convergence test stay on the device (default on for

@@ -81,6 +81,7 @@ def test_new_functions_get_their_own_recording(env):
     A = host.P1ConstantOperator(st, 2, 4)
     A.compute_inverse_diagonal()
     gmg = host.Solver.gmg(st, 2, 4, smoother=host.JACOBI, pre=1, post=1)
+    gmg.set_use_graphs(True)
     results = []
     for k in range(2):
         x, b = host.P1Function(st, f"x{k}", 2, 4), host.P1Function(st, f"b{k}", 2, 4)
