@@ -4,6 +4,9 @@
 // the per-cell kernels of the other files spend their time in launch latency: regular_octahedron_8el needed ~5,500
 // launches of 2-6 us kernels per V(3,3) cycle.  The fine levels keep the tuned per-cell kernels.
 // One thread per array entry over FULL tiles; neighbours are direct global loads (the arrays of these levels live in L2).
+#include <map>
+#include <mutex>
+
 #include "common.hpp"
 
 using namespace hyteg_hip;
@@ -129,7 +132,45 @@ struct DotB
    const Tile* tiles;
    int         N, ntiles, ncells;
    double*     partial;
+   double*     result;
+   unsigned*   counter; // zero between launches: the last workgroup to finish reduces the partial sums and resets it
+   double*     cg;      // non-null: run phase `cgPhase` of the conjugate gradient recurrences after the reduction
+   int         cgPhase;
+   double      relTol, absTol;
 };
+
+// scalar recurrences of the conjugate gradient iteration (see hyteg_hip_cg_scalars in include/hyteg_hip.h)
+__device__ inline void cg_scalars_update( double* s, int phase, double relTol, double absTol )
+{
+   const bool done = s[HYTEG_HIP_CG_DONE] != 0.0;
+   if ( phase == 0 )
+   {
+      s[HYTEG_HIP_CG_PRSOLD]     = s[HYTEG_HIP_CG_RR];
+      s[HYTEG_HIP_CG_RES_START]  = sqrt( s[HYTEG_HIP_CG_RR] );
+      s[HYTEG_HIP_CG_DONE]       = s[HYTEG_HIP_CG_RES_START] < absTol ? 1.0 : 0.0;
+      s[HYTEG_HIP_CG_ITERATIONS] = 0.0;
+      s[HYTEG_HIP_CG_ONE]        = 1.0;
+      s[HYTEG_HIP_CG_ALPHA] = s[HYTEG_HIP_CG_NEG_ALPHA] = s[HYTEG_HIP_CG_BETA] = 0.0;
+   }
+   else if ( phase == 1 )
+   {
+      const double alpha        = done ? 0.0 : s[HYTEG_HIP_CG_PRSOLD] / s[HYTEG_HIP_CG_PAP];
+      s[HYTEG_HIP_CG_ALPHA]     = alpha;
+      s[HYTEG_HIP_CG_NEG_ALPHA] = -alpha;
+   }
+   else if ( !done )
+   {
+      const double rsnew = s[HYTEG_HIP_CG_RR], sq = sqrt( rsnew );
+      s[HYTEG_HIP_CG_ITERATIONS] += 1.0;
+      if ( sq / s[HYTEG_HIP_CG_RES_START] < relTol || sq < absTol )
+         s[HYTEG_HIP_CG_DONE] = 1.0;
+      else
+      {
+         s[HYTEG_HIP_CG_BETA]   = rsnew / s[HYTEG_HIP_CG_PRSOLD];
+         s[HYTEG_HIP_CG_PRSOLD] = rsnew;
+      }
+   }
+}
 
 __device__ inline double wave_sum_b( double v )
 {
@@ -172,18 +213,30 @@ __global__ __launch_bounds__( kThreads ) void batch_dot_kernel( const DotB A )
       }
    }
    const double r = block_sum_b( acc, sh );
+   // one launch: the workgroup that finishes last reduces the partial sums, in the same fixed order whichever it is
+   __shared__ bool last;
    if ( threadIdx.x == 0 )
+   {
       A.partial[blockIdx.x] = r;
-}
-__global__ __launch_bounds__( kThreads ) void batch_dot_final_kernel( const double* partial, int n, double* result )
-{
-   __shared__ double sh[kThreads / 64];
-   double            acc = 0.0;
-   for ( int k = threadIdx.x; k < n; k += kThreads )
-      acc += partial[k];
-   const double r = block_sum_b( acc, sh );
+      __threadfence(); // the partial sum is visible device-wide (the XCDs do not share an L2) before the ticket is taken
+      last = atomicAdd( A.counter, 1u ) == gridDim.x - 1;
+   }
+   __syncthreads();
+   if ( !last )
+      return;
+   __threadfence();
+   double sum = 0.0;
+   for ( int k = threadIdx.x; k < (int) gridDim.x; k += kThreads )
+      sum += __hip_atomic_load( A.partial + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+   __syncthreads(); // sh is reused
+   const double grand = block_sum_b( sum, sh );
    if ( threadIdx.x == 0 )
-      *result = r;
+   {
+      *A.result  = grand;
+      *A.counter = 0u;
+      if ( A.cg )
+         cg_scalars_update( A.cg, A.cgPhase, A.relTol, A.absTol );
+   }
 }
 
 // ---- apply / Jacobi ------------------------------------------------------------------------------------------
@@ -439,36 +492,8 @@ namespace {
 // one thread; s: HYTEG_HIP_CG_* slots
 __global__ void cg_scalars_kernel( double* s, int phase, double relTol, double absTol )
 {
-   if ( threadIdx.x != 0 || blockIdx.x != 0 )
-      return;
-   const bool done = s[HYTEG_HIP_CG_DONE] != 0.0;
-   if ( phase == 0 )
-   {
-      s[HYTEG_HIP_CG_PRSOLD]     = s[HYTEG_HIP_CG_RR];
-      s[HYTEG_HIP_CG_RES_START]  = sqrt( s[HYTEG_HIP_CG_RR] );
-      s[HYTEG_HIP_CG_DONE]       = s[HYTEG_HIP_CG_RES_START] < absTol ? 1.0 : 0.0;
-      s[HYTEG_HIP_CG_ITERATIONS] = 0.0;
-      s[HYTEG_HIP_CG_ONE]        = 1.0;
-      s[HYTEG_HIP_CG_ALPHA] = s[HYTEG_HIP_CG_NEG_ALPHA] = s[HYTEG_HIP_CG_BETA] = 0.0;
-   }
-   else if ( phase == 1 )
-   {
-      const double alpha        = done ? 0.0 : s[HYTEG_HIP_CG_PRSOLD] / s[HYTEG_HIP_CG_PAP];
-      s[HYTEG_HIP_CG_ALPHA]     = alpha;
-      s[HYTEG_HIP_CG_NEG_ALPHA] = -alpha;
-   }
-   else if ( !done )
-   {
-      const double rsnew = s[HYTEG_HIP_CG_RR], sq = sqrt( rsnew );
-      s[HYTEG_HIP_CG_ITERATIONS] += 1.0;
-      if ( sq / s[HYTEG_HIP_CG_RES_START] < relTol || sq < absTol )
-         s[HYTEG_HIP_CG_DONE] = 1.0;
-      else
-      {
-         s[HYTEG_HIP_CG_BETA]   = rsnew / s[HYTEG_HIP_CG_PRSOLD];
-         s[HYTEG_HIP_CG_PRSOLD] = rsnew;
-      }
-   }
+   if ( threadIdx.x == 0 && blockIdx.x == 0 )
+      cg_scalars_update( s, phase, relTol, absTol );
 }
 } // namespace
 
@@ -480,14 +505,39 @@ HYTEG_HIP_API int hyteg_hip_cg_scalars( double* s_dev, int phase, double rel_tol
    return HYTEG_HIP_OK;
 }
 
-HYTEG_HIP_API int hyteg_hip_p1_dot_cells( int                  ncells,
-                                          const double* const* a,
-                                          const double* const* b,
-                                          int                  level,
-                                          const unsigned*      masks,
-                                          double*              result_dev,
-                                          void*                workspace_dev,
-                                          hyteg_hip_stream_t   stream )
+namespace {
+// ticket counter of the single-launch reduction, one per (device, stream); zero between launches
+int dot_counter( hipStream_t stream, unsigned** out )
+{
+   static std::mutex                                         mtx;
+   static std::map< std::pair< int, hipStream_t >, unsigned* > counters;
+   int                                                       dev = 0;
+   HH_CHECK_HIP( hipGetDevice( &dev ) );
+   std::lock_guard< std::mutex > lock( mtx );
+   auto                          it = counters.find( { dev, stream } );
+   if ( it == counters.end() )
+   {
+      void* p = nullptr;
+      HH_CHECK_HIP( hipMalloc( &p, sizeof( unsigned ) ) );
+      HH_CHECK_HIP( hipMemset( p, 0, sizeof( unsigned ) ) );
+      it = counters.emplace( std::make_pair( dev, stream ), static_cast< unsigned* >( p ) ).first;
+   }
+   *out = it->second;
+   return HYTEG_HIP_OK;
+}
+
+int launch_dot_b( int                  ncells,
+                  const double* const* a,
+                  const double* const* b,
+                  int                  level,
+                  const unsigned*      masks,
+                  double*              result_dev,
+                  void*                workspace_dev,
+                  double*              cg,
+                  int                  cgPhase,
+                  double               relTol,
+                  double               absTol,
+                  hyteg_hip_stream_t   stream )
 {
    BATCH_CHECKS( "p1_dot_cells" );
    HH_REQUIRE( a && b && result_dev && workspace_dev, "p1_dot_cells: null pointer" );
@@ -505,12 +555,47 @@ HYTEG_HIP_API int hyteg_hip_p1_dot_cells( int                  ncells,
    }
    A.tiles = tt.dev, A.N = ( 1 << level ) + 1, A.ntiles = tt.count, A.ncells = ncells;
    A.partial = static_cast< double* >( workspace_dev );
+   A.result  = result_dev;
+   A.cg = cg, A.cgPhase = cgPhase, A.relTol = relTol, A.absTol = absTol;
+   rc = dot_counter( as_stream( stream ), &A.counter );
+   if ( rc != HYTEG_HIP_OK )
+      return rc;
    const int total  = tt.count * ncells;
    const int blocks = total < 1024 ? ( total > 0 ? total : 1 ) : 1024; // workspace holds 1024 + 256 doubles
    hipLaunchKernelGGL( batch_dot_kernel, dim3( blocks ), dim3( kThreads ), 0, as_stream( stream ), A );
-   hipLaunchKernelGGL( batch_dot_final_kernel, dim3( 1 ), dim3( kThreads ), 0, as_stream( stream ), A.partial, blocks, result_dev );
    HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;
+}
+} // namespace
+
+HYTEG_HIP_API int hyteg_hip_p1_dot_cells( int                  ncells,
+                                          const double* const* a,
+                                          const double* const* b,
+                                          int                  level,
+                                          const unsigned*      masks,
+                                          double*              result_dev,
+                                          void*                workspace_dev,
+                                          hyteg_hip_stream_t   stream )
+{
+   return launch_dot_b( ncells, a, b, level, masks, result_dev, workspace_dev, nullptr, 0, 0.0, 0.0, stream );
+}
+
+HYTEG_HIP_API int hyteg_hip_p1_dot_cells_cg( int                  ncells,
+                                             const double* const* a,
+                                             const double* const* b,
+                                             int                  level,
+                                             const unsigned*      masks,
+                                             double*              s_dev,
+                                             int                  slot,
+                                             int                  phase,
+                                             double               rel_tol,
+                                             double               abs_tol,
+                                             void*                workspace_dev,
+                                             hyteg_hip_stream_t   stream )
+{
+   HH_REQUIRE( s_dev && ( slot == HYTEG_HIP_CG_PAP || slot == HYTEG_HIP_CG_RR ) && phase >= 0 && phase <= 2,
+               "p1_dot_cells_cg: slot must be PAP or RR, phase 0..2" );
+   return launch_dot_b( ncells, a, b, level, masks, s_dev + slot, workspace_dev, s_dev, phase, rel_tol, abs_tol, stream );
 }
 
 static int launch_apply_b( int                  mode,

@@ -1156,15 +1156,17 @@ class P1Function
                                                masks.data(), storage_->stream() ),
                 "P1Function vector op (device scalars)" );
    }
-   // *resultDev = <this, rhs> over the points `flag` selects (each shared point counted once); no host synchronisation
-   void dotLocalToDevice( const P1Function< ValueType >& rhs, uint_t level, DoFType flag, double* resultDev ) const
+   // cgScalars[slot] = <this, rhs> over the points `flag` selects (each shared point counted once), then phase `phase` of
+   // the conjugate gradient recurrences (hyteg_hip_cg_scalars), in one launch; no host synchronisation
+   void dotLocalToCgScalars( const P1Function< ValueType >& rhs, uint_t level, DoFType flag, double* cgScalars, int slot, int phase,
+                             double relTol, double absTol ) const
    {
       const int  count = (int) storage_->getNumberOfLocalCells();
       const auto masks = storage_->masksFor( flag, true );
       const auto a = cellPointers( level, 0, count ), b = rhs.cellPointers( level, 0, count );
-      hipCheck( hyteg_hip_p1_dot_cells( count, a.data(), b.data(), (int) level, masks.data(), resultDev, storage_->dotWorkspace(),
-                                        storage_->stream() ),
-                "dotLocalToDevice" );
+      hipCheck( hyteg_hip_p1_dot_cells_cg( count, a.data(), b.data(), (int) level, masks.data(), cgScalars, slot, phase, relTol, absTol,
+                                           storage_->dotWorkspace(), storage_->stream() ),
+                "dotLocalToCgScalars" );
    }
 
  private:
@@ -2546,18 +2548,15 @@ class CGSolver : public Solver< OperatorType >
       r_.assign( { 1.0, -1.0 }, { b, p_ }, level, flag_ );
       p_.assign( { 1.0 }, { r_ }, level, flag_ );
       hipCheck( hyteg_hip_memset_zero( S, HYTEG_HIP_CG_SLOTS * sizeof( double ), st.stream() ), "CGSolver: scalars reset" );
-      r_.dotLocalToDevice( r_, level, flag_, S + HYTEG_HIP_CG_RR );
-      hipCheck( hyteg_hip_cg_scalars( S, 0, relTol_, absTol_, st.stream() ), "CGSolver: scalars" );
+      r_.dotLocalToCgScalars( r_, level, flag_, S, HYTEG_HIP_CG_RR, 0, relTol_, absTol_ );
       iterations_ = 0;
       for ( uint_t i = 0; i < maxIter_; ++i )
       {
          A.apply( p_, ap_, level, flag_, Replace );
-         p_.dotLocalToDevice( ap_, level, flag_, S + HYTEG_HIP_CG_PAP );
-         hipCheck( hyteg_hip_cg_scalars( S, 1, relTol_, absTol_, st.stream() ), "CGSolver: scalars" );
+         p_.dotLocalToCgScalars( ap_, level, flag_, S, HYTEG_HIP_CG_PAP, 1, relTol_, absTol_ );
          x.vectorOpDeviceScalars( 1, { S + HYTEG_HIP_CG_ALPHA }, { p_ }, level, flag_ );
          r_.vectorOpDeviceScalars( 1, { S + HYTEG_HIP_CG_NEG_ALPHA }, { ap_ }, level, flag_ );
-         r_.dotLocalToDevice( r_, level, flag_, S + HYTEG_HIP_CG_RR );
-         hipCheck( hyteg_hip_cg_scalars( S, 2, relTol_, absTol_, st.stream() ), "CGSolver: scalars" );
+         r_.dotLocalToCgScalars( r_, level, flag_, S, HYTEG_HIP_CG_RR, 2, relTol_, absTol_ );
          p_.vectorOpDeviceScalars( 0, { S + HYTEG_HIP_CG_ONE, S + HYTEG_HIP_CG_BETA }, { r_, p_ }, level, flag_ );
          if ( ( i + 1 ) % 4 == 0 || i + 1 == maxIter_ )
          {

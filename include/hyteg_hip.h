@@ -383,7 +383,22 @@ enum hyteg_hip_cg_slot
    HYTEG_HIP_CG_SLOTS      = 16
 };
 HYTEG_HIP_API int hyteg_hip_cg_scalars( double* s_dev, int phase, double rel_tol, double abs_tol, hyteg_hip_stream_t stream );
-/* *result_dev = sum over all cells and masked points of a.b (two launches); workspace: hyteg_hip_dot_workspace_bytes() */
+/* hyteg_hip_p1_dot_cells into s_dev[slot] (slot = HYTEG_HIP_CG_PAP or HYTEG_HIP_CG_RR) followed by hyteg_hip_cg_scalars( phase )
+ * in the same launch */
+HYTEG_HIP_API int hyteg_hip_p1_dot_cells_cg( int                  ncells,
+                                             const double* const* a,
+                                             const double* const* b,
+                                             int                  level,
+                                             const unsigned*      masks,
+                                             double*              s_dev,
+                                             int                  slot,
+                                             int                  phase,
+                                             double               rel_tol,
+                                             double               abs_tol,
+                                             void*                workspace_dev,
+                                             hyteg_hip_stream_t   stream );
+/* *result_dev = sum over all cells and masked points of a.b; one launch (the workgroup that finishes last reduces the
+ * partial sums in a fixed order: the result does not depend on timing); workspace: hyteg_hip_dot_workspace_bytes() */
 HYTEG_HIP_API int hyteg_hip_p1_dot_cells( int                  ncells,
                                           const double* const* a,
                                           const double* const* b,
