@@ -106,6 +106,9 @@ struct BrickTable
 };
 int get_bricks( int level, int NY, int LZ, BrickTable* out );
 
+// ticket counter of the single-launch reductions (p1_batch.hip), one per (device, stream); zero between launches
+int dot_counter( hipStream_t stream, unsigned** out );
+
 inline hipStream_t as_stream( hyteg_hip_stream_t s ) { return reinterpret_cast< hipStream_t >( s ); }
 
 enum ApplyMode

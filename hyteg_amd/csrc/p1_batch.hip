@@ -213,6 +213,13 @@ __global__ __launch_bounds__( kThreads ) void batch_dot_kernel( const DotB A )
       }
    }
    const double r = block_sum_b( acc, sh );
+   if ( A.counter == nullptr )
+   {
+      // many workgroups: batch_dot_final_kernel reduces the partial sums (tickets on one address would serialise)
+      if ( threadIdx.x == 0 )
+         A.partial[blockIdx.x] = r;
+      return;
+   }
    // one launch: the workgroup that finishes last reduces the partial sums, in the same fixed order whichever it is
    __shared__ bool last;
    if ( threadIdx.x == 0 )
@@ -236,6 +243,22 @@ __global__ __launch_bounds__( kThreads ) void batch_dot_kernel( const DotB A )
       *A.counter = 0u;
       if ( A.cg )
          cg_scalars_update( A.cg, A.cgPhase, A.relTol, A.absTol );
+   }
+}
+
+__global__ __launch_bounds__( kThreads ) void batch_dot_final_kernel( const double* partial, int n, double* result, double* cg, int cgPhase,
+                                                                       double relTol, double absTol )
+{
+   __shared__ double sh[kThreads / 64];
+   double            acc = 0.0;
+   for ( int k = threadIdx.x; k < n; k += kThreads )
+      acc += partial[k];
+   const double r = block_sum_b( acc, sh );
+   if ( threadIdx.x == 0 )
+   {
+      *result = r;
+      if ( cg )
+         cg_scalars_update( cg, cgPhase, relTol, absTol );
    }
 }
 
@@ -505,27 +528,8 @@ HYTEG_HIP_API int hyteg_hip_cg_scalars( double* s_dev, int phase, double rel_tol
    return HYTEG_HIP_OK;
 }
 
-namespace {
-// ticket counter of the single-launch reduction, one per (device, stream); zero between launches
-int dot_counter( hipStream_t stream, unsigned** out )
-{
-   static std::mutex                                         mtx;
-   static std::map< std::pair< int, hipStream_t >, unsigned* > counters;
-   int                                                       dev = 0;
-   HH_CHECK_HIP( hipGetDevice( &dev ) );
-   std::lock_guard< std::mutex > lock( mtx );
-   auto                          it = counters.find( { dev, stream } );
-   if ( it == counters.end() )
-   {
-      void* p = nullptr;
-      HH_CHECK_HIP( hipMalloc( &p, sizeof( unsigned ) ) );
-      HH_CHECK_HIP( hipMemset( p, 0, sizeof( unsigned ) ) );
-      it = counters.emplace( std::make_pair( dev, stream ), static_cast< unsigned* >( p ) ).first;
-   }
-   *out = it->second;
-   return HYTEG_HIP_OK;
-}
 
+namespace {
 int launch_dot_b( int                  ncells,
                   const double* const* a,
                   const double* const* b,
@@ -557,12 +561,22 @@ int launch_dot_b( int                  ncells,
    A.partial = static_cast< double* >( workspace_dev );
    A.result  = result_dev;
    A.cg = cg, A.cgPhase = cgPhase, A.relTol = relTol, A.absTol = absTol;
-   rc = dot_counter( as_stream( stream ), &A.counter );
-   if ( rc != HYTEG_HIP_OK )
-      return rc;
    const int total  = tt.count * ncells;
    const int blocks = total < 1024 ? ( total > 0 ? total : 1 ) : 1024; // workspace holds 1024 + 256 doubles
-   hipLaunchKernelGGL( batch_dot_kernel, dim3( blocks ), dim3( kThreads ), 0, as_stream( stream ), A );
+   if ( blocks <= 64 )
+   {
+      rc = dot_counter( as_stream( stream ), &A.counter );
+      if ( rc != HYTEG_HIP_OK )
+         return rc;
+      hipLaunchKernelGGL( batch_dot_kernel, dim3( blocks ), dim3( kThreads ), 0, as_stream( stream ), A );
+   }
+   else
+   {
+      A.counter = nullptr;
+      hipLaunchKernelGGL( batch_dot_kernel, dim3( blocks ), dim3( kThreads ), 0, as_stream( stream ), A );
+      hipLaunchKernelGGL( batch_dot_final_kernel, dim3( 1 ), dim3( kThreads ), 0, as_stream( stream ), A.partial, blocks, result_dev, cg, cgPhase,
+                          relTol, absTol );
+   }
    HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;
 }

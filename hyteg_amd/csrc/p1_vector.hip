@@ -127,6 +127,7 @@ int launch_vec( double* dst, int nsrc, const double* const* srcs, const double* 
 
 // ---- dot ---------------------------------------------------------------------------------------
 constexpr int kDotBlocks = 1024; // partial sums; also the workspace size in doubles
+constexpr int kDotSingleLaunchBlocks = 64;
 
 __device__ inline double wave_sum( double v )
 {
@@ -157,7 +158,9 @@ __global__ __launch_bounds__( kThreads ) void p1_dot_partial_kernel( const doubl
                                                                       const Tile* tiles,
                                                                       int         ntiles,
                                                                       int         N,
-                                                                      double*     partial )
+                                                                      double*     partial,
+                                                                      unsigned*   counter,
+                                                                      double*     result )
 {
    __shared__ double sh[kThreads / 64];
    double            acc = 0.0;
@@ -182,8 +185,35 @@ __global__ __launch_bounds__( kThreads ) void p1_dot_partial_kernel( const doubl
          acc = in[u] ? fma( va[u], vb[u], acc ) : acc;
    }
    const double r = block_sum( acc, sh );
+   if ( result == nullptr )
+   {
+      // the caller reduces the partial sums together with others (masked dot)
+      if ( threadIdx.x == 0 )
+         partial[blockIdx.x] = r;
+      return;
+   }
+   // one launch: the workgroup that finishes last reduces the partial sums, in the same fixed order whichever it is
+   __shared__ bool last;
    if ( threadIdx.x == 0 )
+   {
       partial[blockIdx.x] = r;
+      __threadfence(); // visible device-wide (the XCDs do not share an L2) before the ticket is taken
+      last = atomicAdd( counter, 1u ) == gridDim.x - 1;
+   }
+   __syncthreads();
+   if ( !last )
+      return;
+   __threadfence();
+   double sum = 0.0;
+   for ( int k = threadIdx.x; k < (int) gridDim.x; k += kThreads )
+      sum += __hip_atomic_load( partial + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+   __syncthreads(); // sh is reused
+   const double grand = block_sum( sum, sh );
+   if ( threadIdx.x == 0 )
+   {
+      *result  = grand;
+      *counter = 0u;
+   }
 }
 
 __global__ __launch_bounds__( kThreads ) void p1_dot_final_kernel( const double* partial, int n, double* result )
@@ -218,7 +248,7 @@ int launch_dot_inner_partial( const double* a, const double* b, int level, doubl
    *nblocks = tt.count < kDotBlocks ? tt.count : kDotBlocks;
    if ( *nblocks > 0 )
       hipLaunchKernelGGL( p1_dot_partial_kernel, dim3( *nblocks ), dim3( kThreads ), 0, stream, a, b, tt.dev, tt.count,
-                          ( 1 << level ) + 1, partial );
+                          ( 1 << level ) + 1, partial, (unsigned*) nullptr, (double*) nullptr );
    return HYTEG_HIP_OK;
 }
 } // namespace hyteg_hip
@@ -280,18 +310,24 @@ HYTEG_HIP_API int hyteg_hip_p1_dot_cell( const double*      a,
       return rc;
    const int nblocks = tt.count < kDotBlocks ? ( tt.count > 0 ? tt.count : 1 ) : kDotBlocks;
    double*   partial = static_cast< double* >( workspace_dev );
-   hipLaunchKernelGGL( p1_dot_partial_kernel,
-                       dim3( nblocks ),
-                       dim3( kThreads ),
-                       0,
-                       as_stream( stream ),
-                       a,
-                       b,
-                       tt.dev,
-                       tt.count,
-                       ( 1 << level ) + 1,
-                       partial );
-   hipLaunchKernelGGL( p1_dot_final_kernel, dim3( 1 ), dim3( kThreads ), 0, as_stream( stream ), partial, nblocks, result_dev );
+   if ( nblocks <= kDotSingleLaunchBlocks )
+   {
+      // few workgroups (coarse levels): the one that finishes last reduces the partial sums -- one launch.  With ~1000
+      // workgroups the tickets (device-scope atomics on one address, ~25 ns each) cost more than a second launch:
+      // measured 38.5 vs 12.8 us at level 8.
+      unsigned* counter = nullptr;
+      rc                = dot_counter( as_stream( stream ), &counter );
+      if ( rc != HYTEG_HIP_OK )
+         return rc;
+      hipLaunchKernelGGL( p1_dot_partial_kernel, dim3( nblocks ), dim3( kThreads ), 0, as_stream( stream ), a, b, tt.dev, tt.count,
+                          ( 1 << level ) + 1, partial, counter, result_dev );
+   }
+   else
+   {
+      hipLaunchKernelGGL( p1_dot_partial_kernel, dim3( nblocks ), dim3( kThreads ), 0, as_stream( stream ), a, b, tt.dev, tt.count,
+                          ( 1 << level ) + 1, partial, (unsigned*) nullptr, (double*) nullptr );
+      hipLaunchKernelGGL( p1_dot_final_kernel, dim3( 1 ), dim3( kThreads ), 0, as_stream( stream ), partial, nblocks, result_dev );
+   }
    HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;
 }

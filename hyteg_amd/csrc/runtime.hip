@@ -142,6 +142,28 @@ int get_bricks( int level, int NY, int LZ, BrickTable* out )
 
 using namespace hyteg_hip;
 
+namespace hyteg_hip {
+// ticket counter of the single-launch reductions, one per (device, stream); zero between launches
+int dot_counter( hipStream_t stream, unsigned** out )
+{
+   static std::mutex                                         mtx;
+   static std::map< std::pair< int, hipStream_t >, unsigned* > counters;
+   int                                                       dev = 0;
+   HH_CHECK_HIP( hipGetDevice( &dev ) );
+   std::lock_guard< std::mutex > lock( mtx );
+   auto                          it = counters.find( { dev, stream } );
+   if ( it == counters.end() )
+   {
+      void* p = nullptr;
+      HH_CHECK_HIP( hipMalloc( &p, sizeof( unsigned ) ) );
+      HH_CHECK_HIP( hipMemset( p, 0, sizeof( unsigned ) ) );
+      it = counters.emplace( std::make_pair( dev, stream ), static_cast< unsigned* >( p ) ).first;
+   }
+   *out = it->second;
+   return HYTEG_HIP_OK;
+}
+} // namespace hyteg_hip
+
 extern "C" {
 
 HYTEG_HIP_API const char* hyteg_hip_version( void ) { return "hyteg_hip 0.1 (gfx950)"; }

@@ -397,8 +397,9 @@ HYTEG_HIP_API int hyteg_hip_p1_dot_cells_cg( int                  ncells,
                                              double               abs_tol,
                                              void*                workspace_dev,
                                              hyteg_hip_stream_t   stream );
-/* *result_dev = sum over all cells and masked points of a.b; one launch (the workgroup that finishes last reduces the
- * partial sums in a fixed order: the result does not depend on timing); workspace: hyteg_hip_dot_workspace_bytes() */
+/* *result_dev = sum over all cells and masked points of a.b; up to 64 workgroups: one launch (the workgroup that finishes
+ * last reduces the partial sums), more: a second launch does; fixed order either way: the result does not depend on timing;
+ * workspace: hyteg_hip_dot_workspace_bytes() */
 HYTEG_HIP_API int hyteg_hip_p1_dot_cells( int                  ncells,
                                           const double* const* a,
                                           const double* const* b,
