@@ -105,6 +105,28 @@ def main():
            lambda k: capi.p2_elementwise_apply_cell(DV[k % nb2].data_ptr(), DE[k % nb2].data_ptr(), SV[k % nb2].data_ptr(),
                                                     SE[k % nb2].data_ptr(), L2, em.data_ptr(), 1.0, 0, 0x7FFF, sh),
            16 * (nv2 + ne2), nv2 + ne2, r=max(3, reps // 10))
+    # BASELINE config 4 shape on one GPU: P2 Laplace, level 7, the 6 macro-cells one GPU holds (cube_6el = the unit cube)
+    if L >= 7:
+        s6 = host.Storage.from_gmsh(ROOT / "tests/golden/meshes/cube_6el.msh")
+        s6.set_stream(sh)
+        A6 = host.P2ElementwiseLaplaceOperator(s6, 7, 7)
+        u6, r6 = host.P2Function(s6, "u", 7, 7), host.P2Function(s6, "r", 7, 7)
+        u6.interpolate(1.0, 7)
+        for _ in range(3):
+            A6.apply(u6, r6, 7, host.Inner)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n6 = 10
+        for _ in range(n6):
+            A6.apply(u6, r6, 7, host.Inner)
+        torch.cuda.synchronize()
+        us6 = (time.perf_counter() - t0) / n6 * 1e6
+        dofs6 = 6 * (nv2 + ne2)
+        rows.append(dict(kernel="P2 elementwise apply, cube_6el, level 7, host layer (6 cells + exchange)", us=us6, GDoFps=dofs6 / us6 * 1e-3))
+        print(f"P2 elementwise apply, cube_6el (6 macro-cells), level 7, host layer: {us6:9.1f} us  {dofs6 / us6 * 1e-3:7.1f} GDoF/s "
+              f"({dofs6} DoFs incl. copies of shared ones)", flush=True)
+        for o in (u6, r6, A6, s6):
+            o.close()
     # V-cycles through the host layer
     for mesh, lo, hi, smoother, name in (("tet_1el", 2, L, host.JACOBI, "Jacobi(2/3)"), ("tet_1el", 2, min(L, 7), host.GAUSS_SEIDEL, "GS"),
                                           ("regular_octahedron_8el", 2, min(L, 6), host.JACOBI, "Jacobi(2/3)"),
