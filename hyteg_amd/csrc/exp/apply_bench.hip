@@ -844,6 +844,21 @@ int main( int argc, char** argv )
          }
          filter = "zsoff";
       }
+      if ( want( "zpfd" ) )
+      {
+         filter = "";
+         printf( "prefetch distance (slices ahead): 4,8 PFD 1 (shipped) | 2 | 3 ; 4,4 PFD 1 | 2 ; 2,8 PFD 2 ; twice\n" );
+         for ( int rep = 0; rep < 2; ++rep )
+         {
+            run( 4, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 8, 0, 2, 0, 1, false, true, 0, true, 1 > );
+            run( 4, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 8, 0, 2, 0, 1, false, true, 0, true, 2 > );
+            run( 4, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 8, 0, 2, 0, 1, false, true, 0, true, 3 > );
+            run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 0, 2, 0, 1, false, true, 0, true, 1 > );
+            run( 4, 4, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 0, 2, 0, 1, false, true, 0, true, 2 > );
+            run( 2, 8, 1, p1_apply_zmarch_kernel< APPLY_REPLACE, 2, 8, 0, 2, 0, 1, false, true, 0, true, 2 > );
+         }
+         filter = "zpfd";
+      }
       if ( want( "zabl" ) )
       {
          filter = "";

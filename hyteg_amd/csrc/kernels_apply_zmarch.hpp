@@ -114,7 +114,7 @@ constexpr int kStoreAuxDefault = 2;
 // returns 0 without touching the cache) instead of fetching the next row's entries: ~30% of all lanes at level 8.
 // Also means the kernel never reads past the end of the source array.  Level 8: -1..2%.
 template < int MODE, int NY, int LZ, int ABL = 0, int ST_AUX = kStoreAuxDefault, int LD_AUX = 0, int FACT = 1, bool PFALL = false,
-           bool MASKLD = false, int EX_AUX = 0, bool SOFF = false >
+           bool MASKLD = false, int EX_AUX = 0, bool SOFF = false, int PFD = 1 >
 __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_kernel( const ZMarchArgs A )
 {
    int b = blockIdx.x;
@@ -182,6 +182,12 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_k
    load_slice( std::integral_constant< int, 0 >{}, baseq[0], Wqs[0] );
    load_slice( std::integral_constant< int, 1 >{}, baseq[1], Wqs[1] );
    load_slice( std::integral_constant< int, 2 >{}, baseq[2], Wqs[2] );
+   // PFD: how many slices ahead of the one being computed the loads run (1: the next slice is loaded while this one is
+   // computed).  All LZ+2 slices have their own registers, so a longer distance costs no registers, only earlier issue.
+   if constexpr ( !PFALL && PFD >= 2 && LZ + 1 >= 3 )
+      load_slice( std::integral_constant< int, 3 >{}, baseq[3 <= LZ + 1 ? 3 : 0], Wqs[3 <= LZ + 1 ? 3 : 0] );
+   if constexpr ( !PFALL && PFD >= 3 && LZ + 1 >= 4 )
+      load_slice( std::integral_constant< int, 4 >{}, baseq[4 <= LZ + 1 ? 4 : 0], Wqs[4 <= LZ + 1 ? 4 : 0] );
    if constexpr ( PFALL )
    {
       [&]< int... Is >( std::integer_sequence< int, Is... > ) {
@@ -198,8 +204,8 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_k
    auto step = [&]( auto sc ) {
       constexpr int s = decltype( sc )::value; // output slice z0 + s, centre q = s+1
       constexpr int q = s + 1;
-      if constexpr ( q + 2 <= LZ + 1 && !PFALL )
-         load_slice( std::integral_constant< int, q + 2 >{}, baseq[q + 2], Wqs[q + 2] );
+      if constexpr ( q + 1 + PFD <= LZ + 1 && !PFALL )
+         load_slice( std::integral_constant< int, q + 1 + PFD >{}, baseq[q + 1 + PFD], Wqs[q + 1 + PFD] );
 
       const int W  = Wqs[q];
       int       io = baseq[q] + ( W - ym ); // (xb, y0, z)
