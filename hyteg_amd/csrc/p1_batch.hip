@@ -13,7 +13,7 @@ using namespace hyteg_hip;
 
 namespace {
 
-constexpr int kTile    = 1024;
+constexpr int kTile    = 256; // one entry per thread: the batched levels are small, a thread looping over 4 entries pays 4 x the dependent-load latency
 constexpr int kThreads = 256;
 constexpr int kPer     = kTile / kThreads;
 constexpr int kMaxB    = HYTEG_HIP_MAX_BATCH;
