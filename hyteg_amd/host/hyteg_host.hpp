@@ -436,7 +436,11 @@ class PrimitiveStorage
       {
          const char* e  = std::getenv( "HYTEG_AMD_BATCH_MAX_LEVEL" );
          batchMaxLevel_ = e ? std::atoi( e ) : 6;
+         const char* s  = std::getenv( "HYTEG_AMD_BATCH_SINGLE_MAX_LEVEL" );
+         batchSingleMaxLevel_ = s ? std::atoi( s ) : kBatchSingleMaxLevelDefault;
       }
+      if ( localCells_.size() == 1 )
+         return (int) level <= std::min( batchMaxLevel_, batchSingleMaxLevel_ );
       return localCells_.size() > 1 && (int) level <= batchMaxLevel_;
    }
    // the one-workgroup Gauss-Seidel sweep of small cells (levels <= 5) also pays off for a single cell: 1 launch instead of ~3n
@@ -852,6 +856,9 @@ class PrimitiveStorage
    mutable std::map< std::vector< double* >, double** >    pointerTables_;
    mutable double*                                         nncInv_        = nullptr;
    mutable int                                             batchMaxLevel_ = -2; // -2: read HYTEG_AMD_BATCH_MAX_LEVEL on first use
+   // a rank with ONE macro-cell: levels up to this one use the generic batched kernels as well
+   static constexpr int                                    kBatchSingleMaxLevelDefault = -1;
+   mutable int                                             batchSingleMaxLevel_        = kBatchSingleMaxLevelDefault;
    mutable std::map< std::pair< int, int >, ExchangePlan > plans_;
 };
 
