@@ -75,6 +75,9 @@ SIGNATURES = {
     "hyteg_hip_p2_elementwise_apply_cell": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _d, _i, C.c_uint, _vp]),
     "hyteg_hip_p1_vector_cells_dev": (_i, [_i, _i, C.POINTER(_vp), _i, C.POINTER(_vp), C.POINTER(_vp), _i, C.POINTER(C.c_uint), _vp]),
     "hyteg_hip_cg_scalars": (_i, [_vp, _i, _d, _d, _vp]),
+    "hyteg_hip_p1_cg_small_max_entries": (_i, []),
+    "hyteg_hip_p1_cg_small_cells": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), _i, _vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(_vp),
+                                         C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), _i, _d, _d, _vp, _vp]),
     "hyteg_hip_p1_dot_cells_cg": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), _i, C.POINTER(C.c_uint), _vp, _i, _i, _d, _d, _vp, _vp]),
     "hyteg_hip_p1_sor_cells": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), _i, _vp, _d, _i, C.POINTER(C.c_uint), _vp]),
     "hyteg_hip_p1_sor_shell_cells": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i, _vp, _d, C.POINTER(C.c_uint), _i, _vp]),

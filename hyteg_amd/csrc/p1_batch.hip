@@ -520,6 +520,226 @@ __global__ void cg_scalars_kernel( double* s, int phase, double relTol, double a
 }
 } // namespace
 
+namespace {
+// ---- conjugate gradients for problems that fit one workgroup ------------------------------------------------------------
+// The coarsest level of a multigrid hierarchy (8 macro-cells at level 2: 280 array entries) needs ~17 CG iterations per
+// cycle; as separate launches an iteration costs ~35 us of pure latency (apply, sum over shared copies, two reductions,
+// three updates).  Here ONE workgroup runs the whole solve: p, A p and r live in LDS, an iteration is a handful of
+// workgroup barriers.  Same recurrences as CGSolver.hpp:91-140 (identity preconditioner), same operator (per-cell shares
+// of the stencil on shared points, summed over the copies of a point), same masks as the separate kernels.
+constexpr int kCgThreads  = 1024;
+constexpr int kCgMaxTotal = 4096; // entries of all cell arrays together
+constexpr int kCgPer      = kCgMaxTotal / kCgThreads;
+
+struct CgSmallArgs
+{
+   double*         x[kMaxB];
+   const double*   b[kMaxB];
+   unsigned        mask[kMaxB], owned[kMaxB];
+   const double*   stencils;
+   const int*      groupPtr[2];
+   const int*      entryCell[2];
+   const int*      entryOff[2];
+   int             ngroups[2];
+   int             N, cs, ncells, maxIter;
+   double          relTol, absTol;
+   double*         info; // [0] iterations, [1] sqrt(<r,r>) at exit
+};
+
+__device__ inline double cg_block_sum( double v, double* sh )
+{
+   v = wave_sum_b( v );
+   __syncthreads(); // sh may still be read from the previous reduction
+   if ( ( threadIdx.x & 63 ) == 0 )
+      sh[threadIdx.x >> 6] = v;
+   __syncthreads();
+   double r = 0.0;
+#pragma unroll
+   for ( int k = 0; k < kCgThreads / 64; ++k )
+      r += sh[k];
+   return r; // the same value in every thread
+}
+
+__global__ __launch_bounds__( kCgThreads ) void p1_cg_small_kernel( const CgSmallArgs A )
+{
+   extern __shared__ double lds[];
+   __shared__ double        sh[kCgThreads / 64];
+   const int                total = A.ncells * A.cs;
+   double *                 P = lds, *AP = lds + total, *R = lds + 2 * total;
+
+   // this thread's entries: cell, coordinates, class, whether the flag selects them / the dot products count them
+   int  idx[kCgPer], cell[kCgPer], px[kCgPer], py[kCgPer], pz[kCgPer], cls[kCgPer];
+   bool sel[kCgPer], own[kCgPer];
+#pragma unroll
+   for ( int u = 0; u < kCgPer; ++u )
+   {
+      const int i = (int) threadIdx.x + u * kCgThreads;
+      idx[u]      = i < total ? i : -1;
+      sel[u] = own[u] = false;
+      cell[u] = px[u] = py[u] = pz[u] = 0;
+      cls[u]                           = 14;
+      if ( i < total )
+      {
+         const int c = i / A.cs;
+         int       j = i - c * A.cs, z = 0;
+         while ( j >= tri( A.N - z ) )
+         {
+            j -= tri( A.N - z );
+            ++z;
+         }
+         int y = 0;
+         while ( j >= A.N - z - y )
+         {
+            j -= A.N - z - y;
+            ++y;
+         }
+         cell[u] = c, px[u] = j, py[u] = y, pz[u] = z;
+         cls[u] = point_class( A.N, j, y, z );
+         sel[u] = ( A.mask[c] >> cls[u] ) & 1u;
+         own[u] = ( A.owned[c] >> cls[u] ) & 1u;
+      }
+   }
+   auto applyTo = [&]( const double* srcBase, bool srcGlobal ) {
+      // AP = this cell's part of A * src on the selected points, then the sum over the copies of shared points
+#pragma unroll
+      for ( int u = 0; u < kCgPer; ++u )
+         if ( idx[u] >= 0 && sel[u] )
+         {
+            Point p;
+            p.i = idx[u] - cell[u] * A.cs, p.x = px[u], p.y = py[u], p.z = pz[u], p.cls = cls[u], p.ok = true;
+            const double* src = srcGlobal ? A.x[cell[u]] : srcBase + cell[u] * A.cs;
+            AP[idx[u]]        = stencil_sum( A.stencils + (size_t) cell[u] * 225 + cls[u] * 15, src, A.N, p );
+         }
+      __syncthreads();
+      for ( int k = 0; k < 2; ++k )
+         for ( int g = threadIdx.x; g < A.ngroups[k]; g += kCgThreads )
+         {
+            const int lo = A.groupPtr[k][g], hi = A.groupPtr[k][g + 1];
+            double    s  = 0.0;
+            for ( int e = lo; e < hi; ++e )
+            {
+               const double v = AP[A.entryCell[k][e] * A.cs + A.entryOff[k][e]];
+               s              = e == lo ? v : s + v;
+            }
+            for ( int e = lo; e < hi; ++e )
+               AP[A.entryCell[k][e] * A.cs + A.entryOff[k][e]] = s;
+         }
+      __syncthreads();
+   };
+
+   // r = b - A x ; p = r on the selected points, p = 0 elsewhere
+   applyTo( nullptr, true );
+   double rr = 0.0;
+#pragma unroll
+   for ( int u = 0; u < kCgPer; ++u )
+      if ( idx[u] >= 0 )
+      {
+         const double r = sel[u] ? A.b[cell[u]][idx[u] - cell[u] * A.cs] - AP[idx[u]] : 0.0;
+         R[idx[u]] = r, P[idx[u]] = r;
+         if ( own[u] && sel[u] )
+            rr = fma( r, r, rr );
+      }
+   rr                    = cg_block_sum( rr, sh );
+   double       prsold   = rr;
+   const double resStart = sqrt( rr );
+   int          its      = 0;
+   double       resNow   = resStart;
+   __syncthreads();
+   if ( !( resStart < A.absTol ) )
+      for ( int it = 0; it < A.maxIter; ++it )
+      {
+         applyTo( P, false );
+         double pap = 0.0;
+#pragma unroll
+         for ( int u = 0; u < kCgPer; ++u )
+            if ( idx[u] >= 0 && own[u] && sel[u] )
+               pap = fma( P[idx[u]], AP[idx[u]], pap );
+         pap                = cg_block_sum( pap, sh );
+         const double alpha = prsold / pap;
+         double       rsnew = 0.0;
+#pragma unroll
+         for ( int u = 0; u < kCgPer; ++u )
+            if ( idx[u] >= 0 && sel[u] )
+            {
+               double* xc = A.x[cell[u]] + ( idx[u] - cell[u] * A.cs );
+               *xc        = *xc + alpha * P[idx[u]];
+               const double r = R[idx[u]] + ( -alpha ) * AP[idx[u]];
+               R[idx[u]]      = r;
+               if ( own[u] )
+                  rsnew = fma( r, r, rsnew );
+            }
+         rsnew  = cg_block_sum( rsnew, sh );
+         its    = it + 1;
+         resNow = sqrt( rsnew );
+         if ( resNow / resStart < A.relTol || resNow < A.absTol )
+            break;
+         const double beta = rsnew / prsold;
+#pragma unroll
+         for ( int u = 0; u < kCgPer; ++u )
+            if ( idx[u] >= 0 && sel[u] )
+               P[idx[u]] = R[idx[u]] + beta * P[idx[u]];
+         prsold = rsnew;
+         __syncthreads();
+      }
+   if ( threadIdx.x == 0 && A.info )
+   {
+      A.info[0] = (double) its;
+      A.info[1] = resNow;
+   }
+}
+} // namespace
+
+HYTEG_HIP_API int hyteg_hip_p1_cg_small_max_entries( void ) { return kCgMaxTotal; }
+
+HYTEG_HIP_API int hyteg_hip_p1_cg_small_cells( int                  ncells,
+                                               double* const*       x,
+                                               const double* const* b,
+                                               int                  level,
+                                               const double*        stencils_dev,
+                                               const unsigned*      masks,
+                                               const unsigned*      owned_masks,
+                                               const int* const*    group_ptr_dev,
+                                               const int* const*    entry_cell_dev,
+                                               const int* const*    entry_off_dev,
+                                               const int*           ngroups,
+                                               int                  max_iter,
+                                               double               rel_tol,
+                                               double               abs_tol,
+                                               double*              info_dev,
+                                               hyteg_hip_stream_t   stream )
+{
+   BATCH_CHECKS( "p1_cg_small_cells" );
+   HH_REQUIRE( x && b && stencils_dev && owned_masks && ngroups, "p1_cg_small_cells: null pointer" );
+   const int N = ( 1 << level ) + 1, cs = (int) tet64( N );
+   HH_REQUIRE( (int64_t) ncells * cs <= kCgMaxTotal, "p1_cg_small_cells: the cell arrays together exceed hyteg_hip_p1_cg_small_max_entries()" );
+   CgSmallArgs A{};
+   for ( int c = 0; c < ncells; ++c )
+   {
+      HH_REQUIRE( x[c] && b[c], "p1_cg_small_cells: null array" );
+      A.x[c] = x[c], A.b[c] = b[c];
+      A.mask[c] = masks[c] & HYTEG_HIP_MASK_ALL, A.owned[c] = owned_masks[c] & HYTEG_HIP_MASK_ALL;
+   }
+   for ( int k = 0; k < 2; ++k )
+   {
+      A.ngroups[k] = ngroups[k];
+      if ( ngroups[k] > 0 )
+      {
+         HH_REQUIRE( group_ptr_dev && entry_cell_dev && entry_off_dev && group_ptr_dev[k] && entry_cell_dev[k] && entry_off_dev[k],
+                     "p1_cg_small_cells: null group table" );
+         A.groupPtr[k] = group_ptr_dev[k], A.entryCell[k] = entry_cell_dev[k], A.entryOff[k] = entry_off_dev[k];
+      }
+   }
+   A.stencils = stencils_dev, A.N = N, A.cs = cs, A.ncells = ncells, A.maxIter = max_iter;
+   A.relTol = rel_tol, A.absTol = abs_tol, A.info = info_dev;
+   const size_t lds = (size_t) 3 * ncells * cs * sizeof( double );
+   if ( lds > 48 * 1024 )
+      HH_CHECK_HIP( hipFuncSetAttribute( reinterpret_cast< const void* >( p1_cg_small_kernel ), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int) lds ) );
+   hipLaunchKernelGGL( p1_cg_small_kernel, dim3( 1 ), dim3( kCgThreads ), lds, as_stream( stream ), A );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
 HYTEG_HIP_API int hyteg_hip_cg_scalars( double* s_dev, int phase, double rel_tol, double abs_tol, hyteg_hip_stream_t stream )
 {
    HH_REQUIRE( s_dev && phase >= 0 && phase <= 2, "cg_scalars: null pointer or phase not in 0..2" );

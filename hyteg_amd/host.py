@@ -350,9 +350,9 @@ class Solver:
         """GeometricMultigridSolver::setUseGraphs: record the launches of a cycle once, replay them as graphs (default off)"""
         _ck(lib().hyteg_host_gmg_set_use_graphs(self.h, int(on)), "gmg_set_use_graphs")
 
-    def set_use_device_scalars(self, on: bool) -> None:
-        """CGSolver::setUseDeviceScalars (for a multigrid solver: of its coarse-grid CG)"""
-        _ck(lib().hyteg_host_cg_set_use_device_scalars(self.h, int(on)), "cg_set_use_device_scalars")
+    def set_use_device_scalars(self, on: bool, single_launch: bool = False) -> None:
+        """CGSolver::setUseDeviceScalars / setUseSingleLaunch (for a multigrid solver: of its coarse-grid CG)"""
+        _ck(lib().hyteg_host_cg_set_use_device_scalars(self.h, int(bool(on)) | (2 if single_launch else 0)), "cg_set_use_device_scalars")
 
     @property
     def iterations(self) -> int:

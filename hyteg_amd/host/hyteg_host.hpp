@@ -1983,6 +1983,35 @@ class P1ConstantOperator
                    "apply: add shell (batched)" );
       } );
    }
+ public:
+   // ---- the whole CG solve in one launch for problems that fit one workgroup (hyteg_hip_p1_cg_small_cells) ----
+   bool canCgSolveSmall( uint_t level ) const
+   {
+      const size_t n = storage_->getNumberOfLocalCells();
+      return storage_->numRanks() == 1 && n >= 1 && n <= HYTEG_HIP_MAX_BATCH &&
+             (int64_t) n * layout::cellSize( (int) level ) <= hyteg_hip_p1_cg_small_max_entries();
+   }
+   void cgSolveSmall( const P1Function< double >& x, const P1Function< double >& b, uint_t level, DoFType flag, uint_t maxIter, double relTol,
+                      double absTol, double* infoDev ) const
+   {
+      const int  count = (int) storage_->getNumberOfLocalCells();
+      const auto masks = storage_->masksFor( flag ), owned = storage_->masksFor( flag, true );
+      const auto xs = x.cellPointers( level, 0, count ), bs = b.cellPointers( level, 0, count );
+      const int* gp[2] = { nullptr, nullptr }, *ec[2] = { nullptr, nullptr }, *eo[2] = { nullptr, nullptr };
+      int        ng[2] = { 0, 0 };
+      for ( int cls = 0; cls < 2; ++cls )
+      {
+         if ( !testFlag( storage_->boundaryTypeOf( cls == 1 ), flag ) || storage_->exchangePlan( (int) level, cls ).ngroups() == 0 )
+            continue;
+         const auto& plan = storage_->devicePlan( (int) level, cls );
+         gp[cls] = plan.dGroupPtr, ec[cls] = plan.dEntryBuf, eo[cls] = plan.dEntryOff, ng[cls] = plan.ngroups();
+      }
+      hipCheck( hyteg_hip_p1_cg_small_cells( count, xs.data(), bs.data(), (int) level, stencilTable( level ), masks.data(), owned.data(), gp, ec,
+                                             eo, ng, (int) maxIter, relTol, absTol, infoDev, storage_->stream() ),
+                "cgSolveSmall" );
+   }
+
+ private:
    // device tables [local cell][15 point classes][15 weights] for the batched kernels: classes 0..13 the cell's shares, 14 inner
    const double* stencilTable( uint_t level ) const
    {
@@ -2481,6 +2510,7 @@ class CGSolver : public Solver< OperatorType >
 
    void solve( const OperatorType& A, const FunctionType& x, const FunctionType& b, uint_t level ) override
    {
+      iterationsOnDevice_ = false;
       if ( deviceScalarsUsable( x, level ) )
       {
          solveWithDeviceScalars( A, x, b, level );
@@ -2519,7 +2549,20 @@ class CGSolver : public Solver< OperatorType >
          prsold = prsnew;
       }
    }
-   uint_t getIterations() const { return iterations_; }
+   uint_t getIterations() const
+   {
+      if ( iterationsOnDevice_ )
+      {
+         // the one-launch solve leaves its iteration count on the device; fetched (one synchronisation) only when asked for
+         double h = 0.0;
+         hipCheck( hyteg_hip_download( &h, scalars_, sizeof( double ), nullptr ), "CGSolver: iterations" );
+         iterations_         = (uint_t) h;
+         iterationsOnDevice_ = false;
+      }
+      return iterations_;
+   }
+   // levels whose cell arrays together fit one workgroup are solved by ONE launch (hyteg_hip_p1_cg_small_cells); off: false
+   void setUseSingleLaunch( bool on ) { useSingleLaunch_ = on; }
 
  private:
    template < typename F >
@@ -2550,6 +2593,12 @@ class CGSolver : public Solver< OperatorType >
          scalars_ = static_cast< double* >( d );
       }
       double* const S = scalars_;
+      if ( useSingleLaunch_ && A.canCgSolveSmall( level ) )
+      {
+         A.cgSolveSmall( x, b, level, flag_, maxIter_, relTol_, absTol_, S );
+         iterationsOnDevice_ = true;
+         return;
+      }
       p_.setToZero( level ); // apply( p ) reads p on every point; assign below writes only the points flag_ selects
       A.apply( x, p_, level, flag_, Replace );
       r_.assign( { 1.0, -1.0 }, { b, p_ }, level, flag_ );
@@ -2576,13 +2625,14 @@ class CGSolver : public Solver< OperatorType >
       }
    }
 
-   bool                 useDeviceScalars_ = true;
+   bool                 useDeviceScalars_ = true, useSingleLaunch_ = true;
+   mutable bool         iterationsOnDevice_ = false;
    double*              scalars_          = nullptr;
    FunctionType         p_, z_, ap_, r_;
    DoFType              flag_;
    uint_t               maxIter_;
    double               relTol_, absTol_;
-   uint_t               iterations_ = 0;
+   mutable uint_t       iterations_ = 0;
 };
 
 // GeometricMultigridSolver.hpp:40-330

@@ -343,7 +343,8 @@ HYTEG_HOST_API int hyteg_host_cg_set_use_device_scalars( hh_solver_t solver, int
       auto cg = std::dynamic_pointer_cast< CGSolver< Op > >( sp );
       if ( !cg )
          throw std::runtime_error( "cg_set_use_device_scalars: neither a CG solver nor a multigrid solver with a CG coarse solver" );
-      cg->setUseDeviceScalars( on != 0 );
+      cg->setUseDeviceScalars( ( on & 1 ) != 0 );
+      cg->setUseSingleLaunch( ( on & 2 ) != 0 );
    } );
 }
 HYTEG_HOST_API int hyteg_host_cg_iterations( hh_solver_t solver, int* iterations )

@@ -383,6 +383,30 @@ enum hyteg_hip_cg_slot
    HYTEG_HIP_CG_SLOTS      = 16
 };
 HYTEG_HIP_API int hyteg_hip_cg_scalars( double* s_dev, int phase, double rel_tol, double abs_tol, hyteg_hip_stream_t stream );
+/* The whole conjugate gradient solve of CGSolver::solve (CGSolver.hpp:91-140, identity preconditioner) in ONE launch of one
+ * workgroup, for problems whose cell arrays together have at most hyteg_hip_p1_cg_small_max_entries() entries (the
+ * coarsest level of a multigrid hierarchy).  x: initial guess in, solution out (entries the masks do not select are read
+ * as boundary values); operator and masks as in hyteg_hip_p1_apply_cells; owned_masks select the points a dot product
+ * counts (each shared point once).  The copies of shared points are summed inside the kernel: group tables of up to two
+ * exchange classes (group_ptr[k]: ngroups[k] + 1 offsets into entry_cell[k] / entry_off[k], all device arrays; entries
+ * name a cell of this batch and an array offset).  info_dev (may be NULL): [0] iterations, [1] final residual norm. */
+HYTEG_HIP_API int hyteg_hip_p1_cg_small_max_entries( void );
+HYTEG_HIP_API int hyteg_hip_p1_cg_small_cells( int                  ncells,
+                                               double* const*       x,
+                                               const double* const* b,
+                                               int                  level,
+                                               const double*        stencils_dev,
+                                               const unsigned*      masks,
+                                               const unsigned*      owned_masks,
+                                               const int* const*    group_ptr_dev,
+                                               const int* const*    entry_cell_dev,
+                                               const int* const*    entry_off_dev,
+                                               const int*           ngroups,
+                                               int                  max_iter,
+                                               double               rel_tol,
+                                               double               abs_tol,
+                                               double*              info_dev,
+                                               hyteg_hip_stream_t   stream );
 /* hyteg_hip_p1_dot_cells into s_dev[slot] (slot = HYTEG_HIP_CG_PAP or HYTEG_HIP_CG_RR) followed by hyteg_hip_cg_scalars( phase )
  * in the same launch */
 HYTEG_HIP_API int hyteg_hip_p1_dot_cells_cg( int                  ncells,

@@ -99,8 +99,9 @@ HYTEG_HOST_API int hyteg_host_gmg_create( hh_storage_t s, int min_level, int max
  * replayed_cycles counts the cycles that ran from a recording */
 HYTEG_HOST_API int hyteg_host_gmg_set_use_graphs( hh_solver_t solver, int on );
 HYTEG_HOST_API int hyteg_host_gmg_replayed_cycles( hh_solver_t solver, int* count );
-/* CGSolver::setUseDeviceScalars (hyteg_host.hpp): alpha, beta and the convergence test stay on the device (default on for
- * storages of one rank up to level 5); `solver` is a CG solver or a multigrid solver whose coarse solver is one */
+/* CGSolver::setUseDeviceScalars / setUseSingleLaunch (hyteg_host.hpp); on: bit 0 = alpha, beta and the convergence test stay
+ * on the device (storages of one rank up to level 5), bit 1 = problems that fit one workgroup are solved by one launch
+ * (both default on); `solver` is a CG solver or a multigrid solver whose coarse solver is one */
 HYTEG_HOST_API int hyteg_host_cg_set_use_device_scalars( hh_solver_t solver, int on );
 /* CGSolver::getIterations of the last solve */
 HYTEG_HOST_API int hyteg_host_cg_iterations( hh_solver_t solver, int* iterations );

@@ -107,7 +107,7 @@ def test_cg_with_device_scalars_matches_the_host_loop(env, mesh, level):
     from hostutil import cell_points
 
     out = []
-    for dev in (False, True):
+    for dev in (False, True, "single launch"):
         st = host.Storage.from_gmsh(MESHES / f"{mesh}.msh")
         st.set_stream(torch.cuda.current_stream().cuda_stream)
         A = host.P1ConstantOperator(st, level, level)
@@ -119,15 +119,16 @@ def test_cg_with_device_scalars_matches_the_host_loop(env, mesh, level):
         xe.interpolate(0.0, level, host.DirichletBoundary)
         A.apply(xe, b, level, host.Inner)
         cg = host.Solver.cg(st, level, level, 300, 1e-13)
-        cg.set_use_device_scalars(dev)
+        cg.set_use_device_scalars(bool(dev), single_launch=(dev == "single launch"))
         cg.solve(A, x, b, level)
         err = host.P1Function(st, "err", level, level)
         err.assign([1.0, -1.0], [x, xe], level, host.Inner)
         rel = np.sqrt(err.dot(err, level, host.Inner) / xe.dot(xe, level, host.Inner))
         out.append(([x.download_cell(c, level) for c in range(st.n_local_cells)], rel, cg.iterations))
-    (xh, relh, ith), (xd, reld, itd) = out
-    assert relh < 1e-9 and reld < 1e-9
-    assert abs(ith - itd) <= 1  # a residual within rounding of the tolerance may fall on either side
+    (xh, relh, ith), (xd, reld, itd), (xs, rels, its) = out  # the one-launch form falls back to device scalars when too large
+    assert relh < 1e-9 and reld < 1e-9 and rels < 1e-9
+    assert abs(ith - itd) <= 1 and abs(ith - its) <= 1  # a residual within rounding of the tolerance may fall on either side
     scale = max(np.abs(a).max() for a in xh)
-    for a, b_ in zip(xh, xd):
+    for a, b_, c_ in zip(xh, xd, xs):
         assert np.abs(a - b_).max() <= 1e-9 * scale
+        assert np.abs(a - c_).max() <= 1e-9 * scale
