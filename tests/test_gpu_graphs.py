@@ -95,7 +95,7 @@ def test_new_functions_get_their_own_recording(env):
     assert np.abs(results[0]).max() > 0
 
 
-@pytest.mark.parametrize("mesh,level", [("tet_1el", 3), ("regular_octahedron_8el", 2), ("regular_octahedron_8el", 4), ("cube_6el", 3)])
+@pytest.mark.parametrize("mesh,level", [("tet_1el", 3), ("regular_octahedron_8el", 2), ("regular_octahedron_8el", 4), ("cube_6el", 3), ("cube_24el", 3)])
 def test_cg_with_device_scalars_matches_the_host_loop(env, mesh, level):
     """CGSolver::solveWithDeviceScalars keeps alpha, beta and the convergence test on the device (hyteg_hip_cg_scalars);
     the recurrences are the reference's (CGSolver.hpp:91-140), so iterates agree with the host loop up to the rounding
