@@ -1,0 +1,158 @@
+"""The upper end of the supported level range (HYTEG_HIP_MAX_LEVEL = 11): the kernels switch index arithmetic and code
+paths with the size -- 32-bit slice offsets up to level 10, 64-bit above; buffer addressing with a 32-bit byte range up to
+level 8..10 arrays (23 MB .. 1.4 GB), the LDS-tiled apply with 64-bit pointers for the 11.5 GB arrays of level 11.
+Level 9 is compared with the CPU oracle entry by entry for every kernel of the path; levels 10 and 11 check the apply against
+a stencil evaluation at random points done with torch on the device (the arrays never leave the GPU) and against the
+reference's own property that the Laplace stencil annihilates linear functions (P1LaplaceOperator3DTest.cpp:109-126)."""
+import numpy as np
+import pytest
+
+from conftest import OCT_TET, SKEW_TET
+
+pytestmark = pytest.mark.gpu
+
+OFFS = [(0, 0, -1), (1, 0, -1), (-1, 1, -1), (0, 1, -1), (0, -1, 0), (1, -1, 0), (-1, 0, 0), (0, 0, 0), (1, 0, 0), (-1, 1, 0),
+        (0, 1, 0), (0, -1, 1), (1, -1, 1), (-1, 0, 1), (0, 0, 1)]  # order of the 15 weights (include/hyteg_hip.h)
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    from hyteg_amd import capi
+    from oracle import p1_oracle as po
+
+    assert torch.cuda.is_available()
+    capi.lib()
+    return torch, capi, po
+
+
+def _rel(a, b):
+    nb = np.linalg.norm(b)
+    return np.linalg.norm(a - b) / (nb if nb > 0 else 1.0)
+
+
+def test_level9_every_kernel_against_the_oracle(env):
+    torch, capi, po = env
+    level = 9
+    n, nc = po.cell_size(level), po.cell_size(level - 1)
+    assert n == 22632705
+    rng = np.random.default_rng(9)
+    w = po.assemble_cell_stencil(SKEW_TET, level)
+    a_h, b_h = rng.random(n), rng.random(n)
+    a, b = torch.from_numpy(a_h).cuda(), torch.from_numpy(b_h).cuda()
+    m = po.inner_mask(level)
+    # apply Replace / Add
+    d = torch.from_numpy(b_h).cuda()
+    capi.p1_apply_cell(d.data_ptr(), a.data_ptr(), level, w, capi.ADD)
+    ref = b_h.copy()
+    po.apply_cell(ref, a_h, level, w, capi.ADD)
+    torch.cuda.synchronize()
+    got = d.cpu().numpy()
+    assert np.array_equal(got[~m], b_h[~m])
+    assert _rel(got[m], ref[m]) < 1e-13
+    # fused Jacobi
+    d = torch.zeros(n, dtype=torch.float64, device="cuda")
+    capi.p1_jacobi_cell(d.data_ptr(), b.data_ptr(), a.data_ptr(), level, w, 0.6, None)
+    ref = np.zeros(n)
+    po.jacobi_cell(ref, b_h, a_h, level, w, 0.6)
+    torch.cuda.synchronize()
+    assert _rel(d.cpu().numpy(), ref) < 1e-13
+    # assign, dot
+    capi.p1_assign_cell(d.data_ptr(), [2.0, -0.5], [a.data_ptr(), b.data_ptr()], level)
+    torch.cuda.synchronize()
+    assert _rel(d.cpu().numpy()[m], (2.0 * a_h - 0.5 * b_h)[m]) < 1e-15
+    res = torch.zeros(1, dtype=torch.float64, device="cuda")
+    ws = torch.zeros(capi.dot_workspace_bytes() // 8, dtype=torch.float64, device="cuda")
+    capi.p1_dot_cell(a.data_ptr(), b.data_ptr(), level, res.data_ptr(), ws.data_ptr())
+    torch.cuda.synchronize()
+    assert abs(float(res[0]) - float(np.dot(a_h[m], b_h[m]))) < 1e-11 * float(np.dot(a_h[m], b_h[m]))
+    # grid transfer 9 <-> 8
+    nnc = [1.0] * 14
+    coarse = torch.zeros(nc, dtype=torch.float64, device="cuda")
+    capi.p1_restrict_cell(coarse.data_ptr(), a.data_ptr(), level - 1, nnc)
+    ref = np.zeros(nc)
+    po.restrict_cell(ref, a_h, level - 1, nnc)
+    torch.cuda.synchronize()
+    assert _rel(coarse.cpu().numpy(), ref) < 1e-13
+    c_h = rng.random(nc)
+    fine = torch.zeros(n, dtype=torch.float64, device="cuda")
+    capi.p1_prolongate_cell(torch.from_numpy(c_h).cuda().data_ptr(), fine.data_ptr(), level - 1, nnc, capi.REPLACE)
+    ref = np.zeros(n)
+    po.prolongate_prepare(ref, level, capi.REPLACE)
+    po.prolongate_cell(c_h, ref, level - 1, nnc)
+    torch.cuda.synchronize()
+    assert _rel(fine.cpu().numpy(), ref) < 1e-13
+    # Gauss-Seidel, exact order (blocked form: 32 x 32 x 32 blocks of 16^3)
+    u = torch.from_numpy(a_h).cuda()
+    capi.p1_sor_cell(u.data_ptr(), b.data_ptr(), level, w, 1.0, False)
+    ref = a_h.copy()
+    po.sor_cell(ref, b_h, level, w, 1.0, False)
+    torch.cuda.synchronize()
+    assert _rel(u.cpu().numpy(), ref) < 1e-12
+
+
+def _sampled_apply_check(torch, capi, po, level, nsamples=3000):
+    """apply on device arrays that never leave the GPU; the stencil is re-evaluated with torch at random interior points"""
+    n = capi.cell_size(level)
+    N = (1 << level) + 1
+    w = po.assemble_cell_stencil(OCT_TET, level)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(level)
+    src = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+    dst = torch.full((n,), 7.0, dtype=torch.float64, device="cuda")
+    capi.p1_apply_cell(dst.data_ptr(), src.data_ptr(), level, w, capi.REPLACE)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(level)
+    pts = []
+    while len(pts) < nsamples:
+        x, y, z = (int(v) for v in rng.integers(1, N - 2, 3))
+        if x + y + z <= N - 2:
+            pts.append((x, y, z))
+    # corners of the interior too: first / last inner point of the array, longest row, tip
+    pts += [(1, 1, 1), (N - 4, 1, 1), (1, N - 4, 1), (1, 1, N - 4), (N - 5, 2, 1)]
+    centre = torch.tensor([capi.cell_index(level, *p) for p in pts], dtype=torch.int64, device="cuda")
+    want = torch.zeros(len(pts), dtype=torch.float64, device="cuda")
+    for k, (dx, dy, dz) in enumerate(OFFS):
+        idx = torch.tensor([capi.cell_index(level, x + dx, y + dy, z + dz) for x, y, z in pts], dtype=torch.int64, device="cuda")
+        want += w[k] * src[idx]
+    got = dst[centre]
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 1e-13 * scale
+    # boundary entries are not written: first and last array entries, a face point
+    for p in ((0, 0, 0), (N - 1, 0, 0), (0, 0, N - 1), (3, 0, 5), (0, 4, 4)):
+        assert float(dst[capi.cell_index(level, *p)]) == 7.0
+    # the stencil annihilates linear functions: rows are contiguous in x, so a linear field is built row by row on the device
+    del dst
+    return n, N, w, src
+
+
+@pytest.mark.parametrize("level", [10, 11])
+def test_apply_at_the_largest_levels(env, level):
+    torch, capi, po = env
+    free, _ = torch.cuda.mem_get_info()
+    n = capi.cell_size(level)
+    if free < 3.2 * n * 8:
+        pytest.skip(f"needs {3.2 * n * 8 / 2**30:.0f} GiB of device memory")
+    n, N, w, src = _sampled_apply_check(torch, capi, po, level)
+    # Laplace of a linear function vanishes at every inner point (checked through the largest magnitude): fill src with
+    # 3x - 2y + 5z + 1 using the array layout (index of (x,y,z) = slice start + row start + x)
+    k = 0
+    src.zero_()
+    z_starts = [capi.cell_index(level, 0, 0, z) for z in range(N)]
+    for z in range(N):
+        W = N - z
+        # rows of this slice: lengths W, W-1, ..., 1; coordinates from the slice-local offset
+        j = torch.arange(W * (W + 1) // 2, dtype=torch.int64, device="cuda")
+        # row y of offset j: largest y with y*W - y(y-1)/2 <= j
+        y = torch.floor(((2 * W + 1) - torch.sqrt(((2 * W + 1) ** 2 - 8 * j).double())) / 2).long()
+        y = torch.where(y * W - y * (y - 1) // 2 > j, y - 1, y)
+        y = torch.where((y + 1) * W - (y + 1) * y // 2 <= j, y + 1, y)
+        x = j - (y * W - y * (y - 1) // 2)
+        src[z_starts[z]:z_starts[z] + j.numel()] = 3.0 * x.double() - 2.0 * y.double() + 5.0 * z + 1.0
+    dst = torch.zeros(n, dtype=torch.float64, device="cuda")
+    capi.p1_apply_cell(dst.data_ptr(), src.data_ptr(), level, w, capi.REPLACE)
+    torch.cuda.synchronize()
+    # |w| ~ 2^level-independent O(1) sums of values up to ~1e4: rounding level 1e-16 * 15 * 1e4
+    assert float(dst.abs().max()) < 1e-9
+    assert float(src[capi.cell_index(level, 2, 3, 4)]) == 3 * 2 - 2 * 3 + 5 * 4 + 1
