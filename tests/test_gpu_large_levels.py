@@ -156,3 +156,87 @@ def test_apply_at_the_largest_levels(env, level):
     # |w| ~ 2^level-independent O(1) sums of values up to ~1e4: rounding level 1e-16 * 15 * 1e4
     assert float(dst.abs().max()) < 1e-9
     assert float(src[capi.cell_index(level, 2, 3, 4)]) == 3 * 2 - 2 * 3 + 5 * 4 + 1
+
+
+def _inner_mask_on_device(torch, capi, level):
+    """bool array: True at inner points (x, y, z >= 1, x + y + z <= N - 2), built slice by slice from the layout"""
+    N = (1 << level) + 1
+    n = capi.cell_size(level)
+    mask = torch.zeros(n, dtype=torch.bool, device="cuda")
+    for z in range(1, N - 2):
+        W = N - z
+        j = torch.arange(W * (W + 1) // 2, dtype=torch.int64, device="cuda")
+        y = torch.floor(((2 * W + 1) - torch.sqrt(((2 * W + 1) ** 2 - 8 * j).double())) / 2).long()
+        y = torch.where(y * W - y * (y - 1) // 2 > j, y - 1, y)
+        y = torch.where((y + 1) * W - (y + 1) * y // 2 <= j, y + 1, y)
+        x = j - (y * W - y * (y - 1) // 2)
+        s0 = capi.cell_index(level, 0, 0, z)
+        mask[s0:s0 + j.numel()] = (x >= 1) & (y >= 1) & (x + y + z <= N - 2)
+    return mask
+
+
+def test_vector_kernels_jacobi_and_transfer_at_level_11(env):
+    """11.5 GB per array: every index of these kernels has to be 64-bit clean.  Checked on the device against torch."""
+    torch, capi, po = env
+    level = 11
+    n = capi.cell_size(level)
+    free, _ = torch.cuda.mem_get_info()
+    if free < 6.5 * n * 8:
+        pytest.skip(f"needs {6.5 * n * 8 / 2**30:.0f} GiB of device memory")
+    N = (1 << level) + 1
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    a = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+    b = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+    mask = _inner_mask_on_device(torch, capi, level)
+    assert int(mask.sum()) == capi.cell_inner_size(level)
+    # assign: inner points get 2a - 0.5b, everything else keeps its value
+    d = torch.full((n,), -3.0, dtype=torch.float64, device="cuda")
+    capi.p1_assign_cell(d.data_ptr(), [2.0, -0.5], [a.data_ptr(), b.data_ptr()], level)
+    torch.cuda.synchronize()
+    want = torch.where(mask, 2.0 * a - 0.5 * b, torch.full_like(a, -3.0))
+    assert bool(torch.equal(d, want))
+    del want
+    # dot over the inner points
+    res = torch.zeros(1, dtype=torch.float64, device="cuda")
+    ws = torch.zeros(capi.dot_workspace_bytes() // 8, dtype=torch.float64, device="cuda")
+    capi.p1_dot_cell(a.data_ptr(), b.data_ptr(), level, res.data_ptr(), ws.data_ptr())
+    torch.cuda.synchronize()
+    ref = float((a * b * mask).sum())
+    assert abs(float(res[0]) - ref) <= 1e-11 * ref
+    # fused Jacobi at random points (and untouched boundary)
+    w = po.assemble_cell_stencil(OCT_TET, level)
+    d.fill_(-3.0)
+    capi.p1_jacobi_cell(d.data_ptr(), b.data_ptr(), a.data_ptr(), level, w, 0.6, None)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(3)
+    pts = []
+    while len(pts) < 2000:
+        x, y, z = (int(v) for v in rng.integers(1, N - 2, 3))
+        if x + y + z <= N - 2:
+            pts.append((x, y, z))
+    pts += [(1, 1, 1), (N - 4, 1, 1), (1, N - 4, 1), (1, 1, N - 4)]
+    centre = torch.tensor([capi.cell_index(level, *p) for p in pts], dtype=torch.int64, device="cuda")
+    au = torch.zeros(len(pts), dtype=torch.float64, device="cuda")
+    for k, (dx, dy, dz) in enumerate(OFFS):
+        idx = torch.tensor([capi.cell_index(level, x + dx, y + dy, z + dz) for x, y, z in pts], dtype=torch.int64, device="cuda")
+        au += w[k] * a[idx]
+    want = a[centre] + 0.6 * (1.0 / w[7]) * (b[centre] - au)
+    assert float((d[centre] - want).abs().max()) <= 1e-12 * float(want.abs().max())
+    assert float(d[capi.cell_index(level, 0, 5, 5)]) == -3.0 and float(d[n - 1]) == -3.0
+    del d, mask
+    # grid transfer 11 <-> 10 on constants: restriction of 1 with all neighbour counts 1 gives the column sums of the
+    # prolongation (8 at inner coarse points: 1 + 14/2), prolongation of 1 gives 1 at every fine point
+    nc = capi.cell_size(level - 1)
+    a.fill_(1.0)
+    coarse = torch.zeros(nc, dtype=torch.float64, device="cuda")
+    capi.p1_restrict_cell(coarse.data_ptr(), a.data_ptr(), level - 1, [1.0] * 14)
+    torch.cuda.synchronize()
+    assert float(coarse[capi.cell_index(level - 1, 3, 4, 5)]) == 8.0
+    assert float(coarse[capi.cell_index(level - 1, 1, 1, (1 << (level - 1)) - 3)]) == 8.0  # the last inner point along z
+    assert float(coarse.max()) == 8.0
+    coarse.fill_(1.0)
+    b.fill_(-1.0)
+    capi.p1_prolongate_cell(coarse.data_ptr(), b.data_ptr(), level - 1, [1.0] * 14, capi.REPLACE)
+    torch.cuda.synchronize()
+    assert float(b.min()) == 1.0 and float(b.max()) == 1.0
