@@ -240,3 +240,49 @@ def test_vector_kernels_jacobi_and_transfer_at_level_11(env):
     capi.p1_prolongate_cell(coarse.data_ptr(), b.data_ptr(), level - 1, [1.0] * 14, capi.REPLACE)
     torch.cuda.synchronize()
     assert float(b.min()) == 1.0 and float(b.max()) == 1.0
+
+
+def test_gauss_seidel_level_10_against_the_oracle(env):
+    """180 M points, 64^3 / 6 blocks of 16^3 in 190 block wavefronts: block tables, row-base table and staging at 1.4 GB"""
+    torch, capi, po = env
+    level = 10
+    n = po.cell_size(level)
+    rng = np.random.default_rng(10)
+    w = po.assemble_cell_stencil(SKEW_TET, level)
+    u_h, b_h = rng.random(n), rng.random(n)
+    u, b = torch.from_numpy(u_h).cuda(), torch.from_numpy(b_h).cuda()
+    capi.p1_sor_cell(u.data_ptr(), b.data_ptr(), level, w, 1.0, False)
+    capi.p1_sor_cell(u.data_ptr(), b.data_ptr(), level, w, 1.2, True)
+    po.sor_cell(u_h, b_h, level, w, 1.0, False)
+    po.sor_cell(u_h, b_h, level, w, 1.2, True)
+    torch.cuda.synchronize()
+    assert _rel(u.cpu().numpy(), u_h) < 1e-12
+
+
+def test_gauss_seidel_level_11_leaves_a_linear_function_alone(env):
+    """A u = 0 for linear u, so with rhs = 0 every update of a sweep reproduces the value it replaces: a fixed point of the
+    smoother whatever the order -- and any wrong index at 11.5 GB shows as a jump of O(1000)"""
+    torch, capi, po = env
+    level = 11
+    n = capi.cell_size(level)
+    free, _ = torch.cuda.mem_get_info()
+    if free < 3.5 * n * 8:
+        pytest.skip(f"needs {3.5 * n * 8 / 2**30:.0f} GiB of device memory")
+    N = (1 << level) + 1
+    w = po.assemble_cell_stencil(OCT_TET, level)
+    u = torch.zeros(n, dtype=torch.float64, device="cuda")
+    for z in range(N):
+        W = N - z
+        j = torch.arange(W * (W + 1) // 2, dtype=torch.int64, device="cuda")
+        y = torch.floor(((2 * W + 1) - torch.sqrt(((2 * W + 1) ** 2 - 8 * j).double())) / 2).long()
+        y = torch.where(y * W - y * (y - 1) // 2 > j, y - 1, y)
+        y = torch.where((y + 1) * W - (y + 1) * y // 2 <= j, y + 1, y)
+        x = j - (y * W - y * (y - 1) // 2)
+        s0 = capi.cell_index(level, 0, 0, z)
+        u[s0:s0 + j.numel()] = 3.0 * x.double() - 2.0 * y.double() + 5.0 * z + 1.0
+    u0 = u.clone()
+    rhs = torch.zeros(n, dtype=torch.float64, device="cuda")
+    capi.p1_sor_cell(u.data_ptr(), rhs.data_ptr(), level, w, 1.0, False)
+    capi.p1_sor_cell(u.data_ptr(), rhs.data_ptr(), level, w, 1.0, True)
+    torch.cuda.synchronize()
+    assert float((u - u0).abs().max()) < 1e-8  # values up to 1e4, 2 x 15-term sums per point
