@@ -1,7 +1,10 @@
 // C-ABI entry points: assign / add / multElementwise / dot on the interior of one macro-cell.
 // Pure streaming kernels: one workgroup per inner tile, 8-byte coalesced accesses, the only extra
 // work being the row decode that masks the two boundary entries of every row.
+#include <algorithm>
+
 #include "common.hpp"
+#include "kernels_apply_zmarch.hpp" // BrickTask
 
 using namespace hyteg_hip;
 
@@ -216,6 +219,53 @@ __global__ __launch_bounds__( kThreads ) void p1_dot_partial_kernel( const doubl
    }
 }
 
+// Dot product over the inner points enumerated by the brick tasks of the z-march apply (NY rows x nz slices x 62 lanes):
+// no index decoding per entry, coalesced 512-byte row segments, only inner points are touched.  Fixed task -> wave
+// assignment and fixed reduction trees: deterministic.
+template < int NY >
+__global__ __launch_bounds__( kThreads ) void p1_dot_brick_kernel( const double* __restrict__ a,
+                                                                    const double* __restrict__ b,
+                                                                    const BrickTask* __restrict__ tasks,
+                                                                    int     ntasks,
+                                                                    double* partial )
+{
+   __shared__ double sh[kThreads / 64];
+   const int         lane = threadIdx.x & 63;
+   constexpr int     kWaves = kThreads / 64;
+   double            acc  = 0.0;
+   for ( int task = blockIdx.x * kWaves + ( threadIdx.x >> 6 ); task < ntasks; task += gridDim.x * kWaves )
+   {
+      const BrickTask t  = tasks[task];
+      const int       ym = t.y0 - 1;
+      int             base = t.i0, Wq = t.W0; // (xb, ym, z0 - 1), row-0 length of that slice
+      for ( int s = 0; s < t.nz; ++s )
+      {
+         base += tri( Wq ) - ym; // (xb, ym, z0 + s)
+         Wq -= 1;
+         int    io = base + ( Wq - ym ); // (xb, y0, z0 + s)
+         double va[NY], vb[NY];
+         bool   ok[NY];
+#pragma unroll
+         for ( int j = 0; j < NY; ++j )
+         {
+            const int R   = Wq - ( t.y0 + j );       // length of row y0 + j
+            const int cnt = min( 62, R - 2 - t.xb ); // inner points of the row held by lanes 1 .. cnt
+            ok[j]         = (unsigned) ( lane - 1 ) < (unsigned) max( cnt, 0 );
+            const int i   = ok[j] ? io + lane : t.i0;
+            va[j]         = a[i];
+            vb[j]         = b[i];
+            io += R;
+         }
+#pragma unroll
+         for ( int j = 0; j < NY; ++j )
+            acc = ok[j] ? fma( va[j], vb[j], acc ) : acc;
+      }
+   }
+   const double r = block_sum( acc, sh );
+   if ( threadIdx.x == 0 )
+      partial[blockIdx.x] = r;
+}
+
 __global__ __launch_bounds__( kThreads ) void p1_dot_final_kernel( const double* partial, int n, double* result )
 {
    __shared__ double sh[kThreads / 64];
@@ -308,8 +358,21 @@ HYTEG_HIP_API int hyteg_hip_p1_dot_cell( const double*      a,
    int       rc = get_tiles( level, TILES_INNER, kTile, &tt );
    if ( rc != HYTEG_HIP_OK )
       return rc;
+   double* partial = static_cast< double* >( workspace_dev );
+   if ( level >= 8 && level <= 10 )
+   {
+      // large arrays: the brick tasks of the apply enumerate the inner points without any per-entry index decoding
+      BrickTable bt;
+      rc = get_bricks( level, 4, 8, &bt );
+      if ( rc != HYTEG_HIP_OK )
+         return rc;
+      const int nb = std::min( kDotBlocks, ( bt.count + kThreads / 64 - 1 ) / ( kThreads / 64 ) );
+      hipLaunchKernelGGL( p1_dot_brick_kernel< 4 >, dim3( nb ), dim3( kThreads ), 0, as_stream( stream ), a, b, bt.dev, bt.count, partial );
+      hipLaunchKernelGGL( p1_dot_final_kernel, dim3( 1 ), dim3( kThreads ), 0, as_stream( stream ), partial, nb, result_dev );
+      HH_CHECK_HIP( hipGetLastError() );
+      return HYTEG_HIP_OK;
+   }
    const int nblocks = tt.count < kDotBlocks ? ( tt.count > 0 ? tt.count : 1 ) : kDotBlocks;
-   double*   partial = static_cast< double* >( workspace_dev );
    if ( nblocks <= kDotSingleLaunchBlocks )
    {
       // few workgroups (coarse levels): the one that finishes last reduces the partial sums -- one launch.  With ~1000
