@@ -2555,7 +2555,7 @@ class CGSolver : public Solver< OperatorType >
       {
          // the one-launch solve leaves its iteration count on the device; fetched (one synchronisation) only when asked for
          double h = 0.0;
-         hipCheck( hyteg_hip_download( &h, scalars_, sizeof( double ), nullptr ), "CGSolver: iterations" );
+         hipCheck( hyteg_hip_download( &h, scalars_, sizeof( double ), iterationsStream_ ), "CGSolver: iterations" );
          iterations_         = (uint_t) h;
          iterationsOnDevice_ = false;
       }
@@ -2597,6 +2597,7 @@ class CGSolver : public Solver< OperatorType >
       {
          A.cgSolveSmall( x, b, level, flag_, maxIter_, relTol_, absTol_, S );
          iterationsOnDevice_ = true;
+         iterationsStream_   = st.stream(); // the download has to be ordered after the solve on ITS stream
          return;
       }
       p_.setToZero( level ); // apply( p ) reads p on every point; assign below writes only the points flag_ selects
@@ -2627,6 +2628,7 @@ class CGSolver : public Solver< OperatorType >
 
    bool                 useDeviceScalars_ = true, useSingleLaunch_ = true;
    mutable bool         iterationsOnDevice_ = false;
+   hyteg_hip_stream_t   iterationsStream_   = nullptr;
    double*              scalars_          = nullptr;
    FunctionType         p_, z_, ap_, r_;
    DoFType              flag_;
