@@ -34,33 +34,64 @@ MALL_BYTES = 256 * 1024 * 1024
 REF_TET = ((0.0, 0.0, 0.0), (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0))
 
 
-def cpu_baseline(level: int, w, budget_s: float = 12.0):
-    """Time the CPU restatement of apply_3D_macrocell_vertexdof_to_vertexdof_replace (oracle/, test
-    infrastructure used here ONLY as the reported baseline), 1 thread, protocol of
-    apps/benchmarks/KernelBench/3DKernelBench.cpp:59-82 (double the sweeps until the block is long enough)."""
+def _time_sweeps(fn, budget_s):
+    """protocol of apps/benchmarks/KernelBench/3DKernelBench.cpp:59-82: double the sweeps until the block is long enough"""
+    sweeps, total_t, total_sweeps = 1, 0.0, 0
+    while True:
+        t0 = time.perf_counter()
+        for _ in range(sweeps):
+            fn()
+        dt = time.perf_counter() - t0
+        total_t += dt
+        total_sweeps += sweeps
+        last = dt / sweeps
+        if dt > 0.5 * budget_s or total_t >= budget_s:
+            return last, total_sweeps, total_t
+        sweeps *= 2
+
+
+def cpu_baseline(level: int, w, budget_s: float = 10.0, threads: int = 16):
+    """Time the CPU restatement of apply_3D_macrocell_vertexdof_to_vertexdof_replace (oracle/, test infrastructure used
+    here ONLY as the reported baseline): (a) 1 thread, as the reference kernel runs per MPI rank, (b) `threads` threads,
+    one macro-cell per thread (emulates that many ranks of the reference on this host)."""
+    import threading
+
     import numpy as np
 
     from oracle import p1_oracle as po
 
     n = po.cell_size(level)
+    inner = po.cell_inner_size(level)
     rng = np.random.default_rng(42)
     src = rng.random(n)
     dst = np.zeros(n)
     for _ in range(2):
         po.apply_cell(dst, src, level, w, fast=True)
-    sweeps, total_t, total_sweeps = 1, 0.0, 0
-    while total_t < budget_s:
-        t0 = time.perf_counter()
-        for _ in range(sweeps):
-            po.apply_cell(dst, src, level, w, fast=True)
-        dt = time.perf_counter() - t0
-        total_t += dt
-        total_sweeps += sweeps
-        last = dt / sweeps
-        if dt > 0.5 * budget_s:
-            break
-        sweeps *= 2
-    inner = po.cell_inner_size(level)
+    last, total_sweeps, total_t = _time_sweeps(lambda: po.apply_cell(dst, src, level, w, fast=True), budget_s)
+
+    # one macro-cell per thread (ctypes releases the GIL inside the C sweep); every thread sweeps its own arrays
+    threads = max(1, min(threads, os.cpu_count() or 1))
+    srcs = [rng.random(n) for _ in range(threads)]
+    dsts = [np.zeros(n) for _ in range(threads)]
+    reps = max(2, int(0.5 * budget_s / last))
+    barrier = threading.Barrier(threads + 1)
+
+    def work(k):
+        po.apply_cell(dsts[k], srcs[k], level, w, fast=True)
+        barrier.wait()
+        for _ in range(reps):
+            po.apply_cell(dsts[k], srcs[k], level, w, fast=True)
+        barrier.wait()
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
+    for t in ts:
+        t.start()
+    barrier.wait()
+    t0 = time.perf_counter()
+    barrier.wait()
+    dt_multi = time.perf_counter() - t0
+    for t in ts:
+        t.join()
     return {
         "value": inner / last,
         "unit": "DoF-updates/s",
@@ -70,6 +101,12 @@ def cpu_baseline(level: int, w, budget_s: float = 12.0):
                   f"{total_t:.1f} s, gcc -O3 -march=native, last block {last * 1e3:.2f} ms/sweep",
         "ms_per_sweep": last * 1e3,
         "host_cpus": os.cpu_count(),
+        "one_cell_per_thread": {
+            "value": inner * reps * threads / dt_multi,
+            "unit": "DoF-updates/s",
+            "cores": threads,
+            "sample": f"{threads} threads x {reps} sweeps, one level-{level} macro-cell per thread, {dt_multi:.1f} s",
+        },
     }
 
 
@@ -124,7 +161,7 @@ def main():
 
     # one level-`level` macro-cell per GPU: meshes of 1, 2, 4, 8 tetrahedra from the reference's test data; the cells of
     # a rank-r process are those with (cell id % world) == r (HyTeG's round-robin default)
-    mesh = ROOT / "tests" / "golden" / "meshes" / f"{MESH_FOR_WORLD[world]}.msh"
+    mesh = ROOT / "hyteg_amd" / "data" / "meshes" / f"{MESH_FOR_WORLD[world]}.msh"
     storage = host.Storage.from_gmsh(mesh, rank, world)
     stream = torch.cuda.current_stream()
     storage.set_stream(stream.cuda_stream)
@@ -155,6 +192,11 @@ def main():
         # -> interior stencil kernel (overlaps the exchange) -> reduction of the shares
         laplace.apply(srcs[k % nbuf], dsts[k % nbuf], level, host.Inner, host.Replace)
 
+    # untimed: every ring pair is touched (twice) whatever --warmup says, so that no first access (page tables, TLB) of a
+    # buffer falls into the timed region; then the W warm-up steps of the contract
+    pre_warm = 2 * nbuf
+    for k in range(pre_warm):
+        step(k)
     for k in range(args.warmup):
         step(k)
     torch.cuda.synchronize()
@@ -174,24 +216,44 @@ def main():
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels are launched on
 
+    # the same K steps once more, every step between its own pair of events: the median is the launch duration without
+    # the one-off gap in front of the region's first kernel (20 steps cannot average that out)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    evs[0].record(stream)
+    for k in range(args.steps):
+        step(k)
+        evs[k + 1].record(stream)
+    torch.cuda.synchronize()
+    per_step_us = sorted(evs[k].elapsed_time(evs[k + 1]) * 1e3 for k in range(args.steps))
+    median_us = per_step_us[len(per_step_us) // 2]
+
     if dist is not None:
-        tmax = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        tmax = torch.tensor([elapsed, dev_ms, median_us], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed, dev_ms = float(tmax[0]), float(tmax[1])
+        elapsed, dev_ms, median_us = float(tmax[0]), float(tmax[1]), float(tmax[2])
 
     if rank == 0:
         w = laplace.stencils(0, level)[0]
-        launch_us = dev_ms * 1e3 / args.steps
+        mean_us = dev_ms * 1e3 / args.steps  # events around the whole timed region / K
+        launch_us = median_us                # median of the per-step event pairs
         cell_inner = capi.cell_inner_size(level)
         algo_bytes = 16 * cell_inner  # 8 B compulsory src read + 8 B dst write per DoF-update, one cell
         achieved = algo_bytes / (launch_us * 1e-6) / 1e9
-        traffic = None
+        kernel_name = capi.p1_apply_kernel_name(level, capi.REPLACE)
+        # HBM traffic of that kernel from the PMC passes of tools/profile_bench.sh: reported only if the recorded file
+        # is for the instantiation this run launched
+        traffic, traffic_note = None, "no profiles/pmc_traffic.json"
         tfile = ROOT / "profiles" / "pmc_traffic.json"
         if tfile.exists():
             try:
-                traffic = json.loads(tfile.read_text()).get("p1_apply_zmarch_kernel_bytes_per_launch")
-            except Exception:
-                traffic = None
+                rec = json.loads(tfile.read_text())
+                if rec.get("kernel_name") == kernel_name and rec.get("level") == level:
+                    traffic = rec.get("bytes_per_launch")
+                    traffic_note = f"profiles/pmc_traffic.json (git {rec.get('git_head')}, {rec.get('round')})"
+                else:
+                    traffic_note = f"profiles/pmc_traffic.json is for {rec.get('kernel_name')!r} at level {rec.get('level')}: not this kernel"
+            except Exception as e:  # noqa: BLE001
+                traffic_note = f"profiles/pmc_traffic.json unreadable: {e}"
         out = {
             "metric": "DoF-updates/s, P1 Laplace apply() level 8",
             "value": inner_dofs * args.steps / elapsed,
@@ -212,22 +274,30 @@ def main():
                             f"{nbuf} rotating function pairs ({nbuf * pair_bytes / 2**20:.0f} MiB per GPU > 256 MiB Infinity Cache)",
                 "level": level,
                 "macro_cells": world,
+                "pre_warm_applies": pre_warm,
+                "mesh_note": "1/2/4/8 GPUs run tet_1el / pyramid_2el / pyramid_4el / regular_octahedron_8el (one macro-cell per GPU);"
+                             " they stand in for the MultigridStudies cube, whose 6 or 24 cells do not give one cell per GPU",
                 "halo_exchange": ("RCCL all_to_all of shared face/edge/vertex shares, overlapped with the interior kernel"
                                   if world > 1 else None),
                 "device": capi.device_name(),
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "p1_apply_zmarch_kernel<REPLACE,NY=4,LZ=8>" if level >= 8 else "p1_apply_zmarch_kernel<REPLACE,NY=4,LZ=4>",
+                "kernel": kernel_name,
                 "achieved": achieved if world == 1 else None,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if world == 1 else None,
                 "traffic": traffic,
+                "traffic_source": traffic_note,
                 "launch_us": launch_us,
+                "launch_us_mean_over_timed_region": mean_us,
+                "launch_us_min": per_step_us[0],
                 "algorithmic_bytes_per_launch": algo_bytes,
-                "note": "achieved = algorithmic bytes of one cell's interior kernel / time per apply on the launch stream"
-                        " (N=1: one kernel per apply)",
+                "note": "achieved = algorithmic bytes of one cell's interior kernel / launch_us; launch_us = median over the K steps"
+                        " of the time between HIP events recorded on the launch stream around each apply (N=1: one kernel per"
+                        " apply), taken in a second pass of the same K steps right after the wall-clock region;"
+                        " launch_us_mean_over_timed_region = one event pair around the wall-clock region / K",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

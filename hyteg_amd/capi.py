@@ -40,6 +40,7 @@ SIGNATURES = {
     "hyteg_hip_cell_inner_size": (_i64, [_i]),
     "hyteg_hip_cell_index": (_i64, [_i, _i, _i, _i]),
     "hyteg_hip_p1_apply_cell": (_i, [_vp, _vp, _i, _dp, _i, _vp]),
+    "hyteg_hip_p1_apply_kernel_name": (_i, [_i, _i, C.c_char_p, _sz]),
     "hyteg_hip_p1_jacobi_cell": (_i, [_vp, _vp, _vp, _vp, _i, _dp, _d, _vp]),
     "hyteg_hip_p1_sor_cell": (_i, [_vp, _vp, _i, _dp, _d, _i, _vp]),
     "hyteg_hip_set_sor_algorithm": (_i, [_i]),
@@ -149,6 +150,12 @@ def prepare_level(level): check(lib().hyteg_hip_prepare_level(level), "prepare_l
 def device_name() -> str:
     buf = C.create_string_buffer(256)
     check(lib().hyteg_hip_device_name(buf, 256), "device_name")
+    return buf.value.decode()
+
+
+def p1_apply_kernel_name(level, update=REPLACE) -> str:
+    buf = C.create_string_buffer(256)
+    check(lib().hyteg_hip_p1_apply_kernel_name(level, update, buf, 256), "p1_apply_kernel_name")
     return buf.value.decode()
 
 

@@ -103,6 +103,8 @@ struct BrickTable
 {
    const BrickTask* dev   = nullptr;
    int              count = 0;
+   bool             decodable = false; // z-chunk starts fit the kernel arguments (decode mode of the z-march kernel)
+   int              zs[32]    = {};    // first task of z-chunk k, padded with count
 };
 int get_bricks( int level, int NY, int LZ, BrickTable* out );
 

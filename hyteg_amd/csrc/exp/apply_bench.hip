@@ -9,9 +9,9 @@
 #include <vector>
 
 #include "../kernels_apply.hpp"
-#include "../kernels_apply_rowmarch.hpp"
-#include "../kernels_apply_strip2.hpp"
-#include "../kernels_apply_zmarch.hpp"
+#include "kernels_apply_rowmarch.hpp"
+#include "kernels_apply_strip2.hpp"
+#include "kernels_apply_zmarch_r01.hpp"
 
 using namespace hyteg_hip;
 

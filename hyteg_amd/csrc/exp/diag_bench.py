@@ -3,7 +3,7 @@ sys.path.insert(0, '.')
 import numpy as np, torch
 from hyteg_amd import capi, host
 level=8
-st=host.Storage.from_gmsh('tests/golden/meshes/tet_1el.msh')
+st=host.Storage.from_gmsh('hyteg_amd/data/meshes/tet_1el.msh')
 stream=torch.cuda.current_stream(); st.set_stream(stream.cuda_stream)
 A=host.P1ConstantOperator(st,level,level)
 n=capi.cell_size(level); nbuf=9

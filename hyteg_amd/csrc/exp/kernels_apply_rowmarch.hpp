@@ -18,7 +18,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "common.hpp"
+#include "../common.hpp"
 
 namespace hyteg_hip {
 

@@ -23,7 +23,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "common.hpp"
+#include "../common.hpp"
 
 namespace hyteg_hip {
 

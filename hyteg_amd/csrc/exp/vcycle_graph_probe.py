@@ -15,7 +15,7 @@ mesh, lo, hi = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 sm = host.GAUSS_SEIDEL if len(sys.argv) > 4 and sys.argv[4] == "gs" else host.JACOBI
 capi.lib(), host.lib()
 for graphs in (False, True):
-    st = host.Storage.from_gmsh(ROOT / f"tests/golden/meshes/{mesh}.msh")
+    st = host.Storage.from_gmsh(ROOT / f"hyteg_amd/data/meshes/{mesh}.msh")
     st.set_stream(torch.cuda.current_stream().cuda_stream)
     A = host.P1ConstantOperator(st, lo, hi)
     A.compute_inverse_diagonal()

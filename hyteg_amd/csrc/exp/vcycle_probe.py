@@ -7,7 +7,7 @@ hi = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 lo = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 smoother = host.GAUSS_SEIDEL if (len(sys.argv) > 4 and sys.argv[4] == "gs") else host.JACOBI
 ROOT = pathlib.Path(__file__).resolve().parents[3]
-st = host.Storage.from_gmsh(ROOT / f"tests/golden/meshes/{mesh}.msh")
+st = host.Storage.from_gmsh(ROOT / f"hyteg_amd/data/meshes/{mesh}.msh")
 st.set_stream(torch.cuda.current_stream().cuda_stream)
 A = host.P1ConstantOperator(st, lo, hi); A.compute_inverse_diagonal()
 x, b = host.P1Function(st, "x", lo, hi), host.P1Function(st, "b", lo, hi)

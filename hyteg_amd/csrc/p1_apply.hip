@@ -1,4 +1,6 @@
 // C-ABI entry points: constant-stencil apply and fused weighted Jacobi on one macro-cell.
+#include <cstdlib>
+
 #include "kernels_apply.hpp"
 #include "kernels_apply_zmarch.hpp"
 
@@ -13,6 +15,16 @@ constexpr int kTile = 1024;
 // level 8 on, 4 x 4 below (MI355X: level 7 4.3 vs 5.9 us, level 8 9.9 vs 9.7 us, level 9 equal).
 constexpr int kBrickNY = 4;
 inline int   brick_lz( int level ) { return level >= 8 ? 8 : 4; }
+
+// developer switch: HYTEG_HIP_APPLY_DECODE=0 falls back to the brick table at every level
+inline bool apply_decode_enabled()
+{
+   static const bool on = [] {
+      const char* e = getenv( "HYTEG_HIP_APPLY_DECODE" );
+      return !( e && e[0] == '0' );
+   }();
+   return on;
+}
 
 template < int MODE, int LZ >
 int launch_zmarch_lz( double* dst, const double* src, const double* rhs, const double* invdiag, int level, const double* w,
@@ -31,24 +43,27 @@ int launch_zmarch_lz( double* dst, const double* src, const double* rhs, const d
    A.invdiag = invdiag;
    A.tasks   = bt.dev;
    A.ntasks  = bt.count;
-   A.bytes   = (unsigned) ( tet64( ( 1 << level ) + 1 ) * 8 );
+   A.N       = ( 1 << level ) + 1;
+   A.bytes   = (unsigned) ( tet64( A.N ) * 8 );
    A.relax   = relax;
    for ( int k = 0; k < 15; ++k )
       A.st.w[k] = w[k];
+   static_assert( sizeof( bt.zs ) == sizeof( A.zs ), "z-chunk table sizes" );
+   for ( int k = 0; k < kZMarchMaxZChunks; ++k )
+      A.zs[k] = bt.zs[k];
    int nblocks = ( bt.count + kZMarchWavesPerBlock - 1 ) / kZMarchWavesPerBlock;
    nblocks     = ( nblocks + 7 ) & ~7;
    A.xcd_chunk = nblocks / 8;
-   // nontemporal stores, plain source loads, factorised lane shifts, scalar-offset addressing with clamped loads and a
-   // one-compare store predicate (SOFF).  dst of Add is read exactly once per element and written right after: nontemporal
-   // load (18.6 -> 17.2 us).  rhs / inverse diagonal of Jacobi are re-read by the next sweep of the smoother and stay plain
-   // (nontemporal: 12.4 -> 17.6 us when they are still in the Infinity Cache, -2% when they are not).
+   // dst of Add is read exactly once per element and written right after: nontemporal load (18.6 -> 17.2 us).  rhs /
+   // inverse diagonal of Jacobi are re-read by the next sweep of the smoother and stay plain (nontemporal: 12.4 -> 17.6 us
+   // when they are still in the Infinity Cache, -2% when they are not).
    constexpr int kExAux = MODE == APPLY_ADD ? 2 : 0;
-   hipLaunchKernelGGL( ( p1_apply_zmarch_kernel< MODE, kBrickNY, LZ, 0, kStoreAuxDefault, 0, 1, false, true, kExAux, true > ),
-                       dim3( nblocks ),
-                       dim3( 64 * kZMarchWavesPerBlock ),
-                       0,
-                       stream,
-                       A );
+   // up to level 8 a wave decodes its brick from its index (no table load in front of the first source loads)
+   const dim3 grid( nblocks ), block( 64 * kZMarchWavesPerBlock );
+   if ( bt.decodable && apply_decode_enabled() )
+      hipLaunchKernelGGL( ( p1_apply_zmarch_kernel< MODE, kBrickNY, LZ, kExAux, true > ), grid, block, 0, stream, A );
+   else
+      hipLaunchKernelGGL( ( p1_apply_zmarch_kernel< MODE, kBrickNY, LZ, kExAux, false > ), grid, block, 0, stream, A );
    HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;
 }
@@ -123,6 +138,27 @@ HYTEG_HIP_API int hyteg_hip_p1_apply_cell( double*            dst,
    if ( update == HYTEG_HIP_REPLACE )
       return launch_apply< APPLY_REPLACE >( dst, src, nullptr, nullptr, level, w, 0.0, as_stream( stream ) );
    return launch_apply< APPLY_ADD >( dst, src, nullptr, nullptr, level, w, 0.0, as_stream( stream ) );
+}
+
+HYTEG_HIP_API int hyteg_hip_p1_apply_kernel_name( int level, int update, char* buf, size_t buflen )
+{
+   HH_REQUIRE( buf && buflen > 0, "p1_apply_kernel_name: null buffer" );
+   HH_REQUIRE( level_ok( level ), "p1_apply_kernel_name: level out of range [2,11]" );
+   HH_REQUIRE( update == HYTEG_HIP_REPLACE || update == HYTEG_HIP_ADD, "p1_apply_kernel_name: bad update type" );
+   const int mode = update == HYTEG_HIP_REPLACE ? APPLY_REPLACE : APPLY_ADD;
+   if ( tet64( ( 1 << level ) + 1 ) * 8 >= ( (int64_t) 1 << 31 ) )
+   {
+      snprintf( buf, buflen, "p1_apply_tiled_kernel<MODE=%d>", mode );
+      return HYTEG_HIP_OK;
+   }
+   const int  lz = brick_lz( level );
+   BrickTable bt;
+   int        rc = lz == 8 ? get_bricks( level, kBrickNY, 8, &bt ) : get_bricks( level, kBrickNY, 4, &bt );
+   if ( rc != HYTEG_HIP_OK )
+      return rc;
+   snprintf( buf, buflen, "p1_apply_zmarch_kernel<MODE=%d,NY=%d,LZ=%d,EX_AUX=%d,DEC=%d,PFD=%d>", mode, kBrickNY, lz,
+             mode == APPLY_ADD ? 2 : 0, ( bt.decodable && apply_decode_enabled() ) ? 1 : 0, 1 );
+   return HYTEG_HIP_OK;
 }
 
 HYTEG_HIP_API int hyteg_hip_p1_jacobi_cell( double*            dst,

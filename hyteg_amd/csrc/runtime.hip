@@ -121,9 +121,14 @@ int get_bricks( int level, int NY, int LZ, BrickTable* out )
       return HYTEG_HIP_OK;
    }
    std::vector< BrickTask > host;
-   build_brick_tasks( level, NY, LZ, host );
+   std::vector< int >       zs;
+   build_brick_tasks( level, NY, LZ, host, &zs );
    BrickTable bt;
    bt.count = (int) host.size();
+   // decode mode: zs = starts of the z-chunks followed by the total
+   bt.decodable = (int) zs.size() - 1 <= kZMarchMaxZChunks && ( 1 << level ) - 3 <= 62 * kZMarchMaxStairs;
+   for ( int k = 0; k < kZMarchMaxZChunks; ++k )
+      bt.zs[k] = k + 1 < (int) zs.size() ? zs[k] : bt.count;
    if ( bt.count > 0 )
    {
       void* p = nullptr;

@@ -1,0 +1,175 @@
+// p2operator.hpp -- part of the C++ host layer above the C-ABI (see hyteg_host.hpp for the data model).
+// P2 forms and P2ElementwiseOperator (src/hyteg/elementwiseoperators/P2ElementwiseOperator.cpp)
+#pragma once
+
+#include "p2function.hpp"
+#include "forms.hpp"
+
+namespace hyteg {
+
+// =====================================================================================================
+// P2ElementwiseOperator< P2Form >  ( src/hyteg/elementwiseoperators/P2ElementwiseOperator.hpp:454, .cpp:110-223 ), affine cells:
+// the six element matrices per (cell, level) are computed once (kernel INPUT) and kept on the device.
+// =====================================================================================================
+namespace forms {
+// P2 diffusion element matrix in FEniCS ordering (vertices 0-3, edges (2,3) (1,3) (1,2) (0,3) (0,2) (0,1)); what
+// P2FenicsForm< ..., p2_tet_diffusion_cell_integral_0_otherwise >::integrateAll returns (form_fenics_base/P2FenicsForm.cpp:160-175).
+// Closed form: phi_a = l_a (2 l_a - 1), phi_ab = 4 l_a l_b; int l_a = V/4, int l_a l_b = V (1 + delta_ab) / 20.
+struct P2LaplaceForm
+{
+   static void integrateAll( const std::array< Point3D, 4 >& c, double elMat[100] )
+   {
+      double J[3][3];
+      for ( int r = 0; r < 3; ++r )
+         for ( int k = 0; k < 3; ++k )
+            J[r][k] = c[k + 1][r] - c[0][r];
+      const double det = det3( J );
+      double       Ji[3][3];
+      Ji[0][0] = ( J[1][1] * J[2][2] - J[1][2] * J[2][1] ) / det;
+      Ji[0][1] = ( J[0][2] * J[2][1] - J[0][1] * J[2][2] ) / det;
+      Ji[0][2] = ( J[0][1] * J[1][2] - J[0][2] * J[1][1] ) / det;
+      Ji[1][0] = ( J[1][2] * J[2][0] - J[1][0] * J[2][2] ) / det;
+      Ji[1][1] = ( J[0][0] * J[2][2] - J[0][2] * J[2][0] ) / det;
+      Ji[1][2] = ( J[0][2] * J[1][0] - J[0][0] * J[1][2] ) / det;
+      Ji[2][0] = ( J[1][0] * J[2][1] - J[1][1] * J[2][0] ) / det;
+      Ji[2][1] = ( J[0][1] * J[2][0] - J[0][0] * J[2][1] ) / det;
+      Ji[2][2] = ( J[0][0] * J[1][1] - J[0][1] * J[1][0] ) / det;
+      double g[4][3];
+      for ( int r = 0; r < 3; ++r )
+      {
+         g[1][r] = Ji[0][r], g[2][r] = Ji[1][r], g[3][r] = Ji[2][r];
+         g[0][r] = -( Ji[0][r] + Ji[1][r] + Ji[2][r] );
+      }
+      const double V = std::fabs( det ) / 6.0;
+      double       G[4][4];
+      for ( int a = 0; a < 4; ++a )
+         for ( int b = 0; b < 4; ++b )
+            G[a][b] = g[a][0] * g[b][0] + g[a][1] * g[b][1] + g[a][2] * g[b][2];
+      // grad phi_i = sum_a ( sum_p C[i][a][p] l_p + D[i][a] ) grad l_a
+      static const int pairs[6][2] = { { 2, 3 }, { 1, 3 }, { 1, 2 }, { 0, 3 }, { 0, 2 }, { 0, 1 } };
+      double           C[10][4][4] = {}, D[10][4] = {};
+      for ( int a = 0; a < 4; ++a )
+         C[a][a][a] = 4.0, D[a][a] = -1.0;
+      for ( int k = 0; k < 6; ++k )
+         C[4 + k][pairs[k][0]][pairs[k][1]] = 4.0, C[4 + k][pairs[k][1]][pairs[k][0]] = 4.0;
+      for ( int i = 0; i < 10; ++i )
+         for ( int j = 0; j < 10; ++j )
+         {
+            double s = 0.0;
+            for ( int a = 0; a < 4; ++a )
+               for ( int b = 0; b < 4; ++b )
+               {
+                  double t = D[i][a] * D[j][b] * V;
+                  for ( int p = 0; p < 4; ++p )
+                  {
+                     t += ( C[i][a][p] * D[j][b] + D[i][a] * C[j][b][p] ) * V / 4.0;
+                     for ( int q = 0; q < 4; ++q )
+                        t += C[i][a][p] * C[j][b][q] * V * ( p == q ? 2.0 : 1.0 ) / 20.0;
+                  }
+                  s += t * G[a][b];
+               }
+            elMat[10 * i + j] = s;
+         }
+   }
+};
+} // namespace forms
+
+template < class P2Form >
+class P2ElementwiseOperator
+{
+ public:
+   using srcType = P2Function< double >;
+   using dstType = P2Function< double >;
+   P2ElementwiseOperator( const std::shared_ptr< PrimitiveStorage >& storage, uint_t minLevel, uint_t maxLevel )
+   : storage_( storage )
+   , minLevel_( minLevel )
+   , maxLevel_( maxLevel )
+   {
+      if ( storage->numRanks() != 1 )
+         throw std::runtime_error( "P2ElementwiseOperator: storages distributed over several ranks are not supported in this version" );
+      // micro-cell vertex offsets of the six cell types, celldof::macrocell::getMicroVerticesFromMicroCell (CellDoFIndexing.hpp:155-198)
+      static const int verts[6][4][3] = {
+          { { 0, 0, 0 }, { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } }, { { 1, 0, 0 }, { 1, 1, 0 }, { 0, 1, 0 }, { 1, 0, 1 } },
+          { { 1, 0, 0 }, { 0, 1, 0 }, { 1, 0, 1 }, { 0, 0, 1 } }, { { 1, 1, 0 }, { 1, 1, 1 }, { 0, 1, 1 }, { 1, 0, 1 } },
+          { { 1, 0, 1 }, { 0, 1, 1 }, { 0, 0, 1 }, { 0, 1, 0 } }, { { 0, 1, 0 }, { 1, 1, 0 }, { 1, 0, 1 }, { 0, 1, 1 } } };
+      for ( uint_t l = minLevel; l <= maxLevel; ++l )
+         for ( uint_t lc = 0; lc < storage->getNumberOfLocalCells(); ++lc )
+         {
+            const MacroCell&      cell = storage->getLocalCell( lc );
+            const double          step = 1.0 / double( int64_t( 1 ) << l );
+            std::vector< double > h( 600 );
+            for ( int t = 0; t < 6; ++t )
+            {
+               std::array< Point3D, 4 > c;
+               for ( int k = 0; k < 4; ++k )
+                  for ( int r = 0; r < 3; ++r )
+                     c[k][r] = cell.coords[0][r] + ( cell.coords[1][r] - cell.coords[0][r] ) * step * verts[t][k][0] +
+                               ( cell.coords[2][r] - cell.coords[0][r] ) * step * verts[t][k][1] +
+                               ( cell.coords[3][r] - cell.coords[0][r] ) * step * verts[t][k][2];
+               P2Form::integrateAll( c, h.data() + 100 * t );
+            }
+            std::vector< double > table( hyteg_hip_p2_operator_table_size() );
+            hipCheck( hyteg_hip_p2_build_operator_table( h.data(), table.data() ), "P2ElementwiseOperator: operator table" );
+            elementMatrices_[l].push_back( storage->uploadTable( table ) );
+            hostMatrices_[l].push_back( h );
+         }
+   }
+   std::shared_ptr< PrimitiveStorage > getStorage() const { return storage_; }
+   const std::vector< double >&        getElementMatrices( uint_t level, uint_t localCell = 0 ) const { return hostMatrices_.at( level ).at( localCell ); }
+
+   // Operator::apply = gemv( 1, src, updateType == Replace ? 0 : 1, dst ), P2ElementwiseOperator.hpp:60-75
+   void apply( const P2Function< double >& src, const P2Function< double >& dst, uint_t level, DoFType flag, UpdateType updateType = Replace ) const
+   {
+      gemv( 1.0, src, updateType == Replace ? 0.0 : 1.0, dst, level, flag );
+   }
+   // every cell adds the contributions of its own micro-cells; on DoFs shared by several cells these are partial sums that the
+   // additive exchange completes (communicateAdditively< Cell, ... > at the end of the reference's gemv, :225-235)
+   void gemv( double alpha, const P2Function< double >& src, double beta, const P2Function< double >& dst, uint_t level, DoFType flag ) const
+   {
+      if ( &src == &dst )
+         throw std::runtime_error( "P2ElementwiseOperator::gemv: src and dst must differ" );
+      const bool shared = storage_->getNumberOfLocalCells() > 1;
+      if ( !shared )
+      {
+         if ( beta != 0.0 && beta != 1.0 )
+            dst.assign( { beta }, { dst }, level, flag );
+         launch( alpha, src, dst, level, flag, HYTEG_HIP_MASK_ALL, beta == 0.0 ? HYTEG_HIP_REPLACE : HYTEG_HIP_ADD );
+         return;
+      }
+      if ( beta == 0.0 )
+      {
+         launch( alpha, src, dst, level, flag, HYTEG_HIP_MASK_ALL, HYTEG_HIP_REPLACE );
+         dst.getVertexDoFFunction().sumSharedCopies( level, flag );
+         dst.sumSharedEdgeCopies( level, flag );
+         return;
+      }
+      // beta != 0: the summed shares of the shared DoFs are formed in a temporary and then added
+      P2Function< double > tmp( "p2_gemv_tmp", storage_, level, level );
+      launch( alpha, src, tmp, level, flag, HYTEG_HIP_MASK_ALL, HYTEG_HIP_REPLACE );
+      tmp.getVertexDoFFunction().sumSharedCopies( level, flag );
+      tmp.sumSharedEdgeCopies( level, flag );
+      dst.assign( { beta, 1.0 }, { dst, tmp }, level, flag );
+   }
+
+ private:
+   void launch( double alpha, const P2Function< double >& src, const P2Function< double >& dst, uint_t level, DoFType flag, unsigned keep,
+                int update ) const
+   {
+      for ( uint_t c = 0; c < storage_->getNumberOfLocalCells(); ++c )
+      {
+         const MacroCell& cell = storage_->getLocalCell( c );
+         hipCheck( hyteg_hip_p2_elementwise_apply_cell( dst.getVertexDoFFunction().getCellPointer( c, level ), dst.getEdgeCellPointer( c, level ),
+                                                        src.getVertexDoFFunction().getCellPointer( c, level ), src.getEdgeCellPointer( c, level ),
+                                                        (int) level, elementMatrices_.at( level ).at( c ), alpha, update,
+                                                        storage_->maskFor( cell, flag ) & keep, storage_->stream() ),
+                   "P2ElementwiseOperator::gemv" );
+      }
+   }
+   std::shared_ptr< PrimitiveStorage >                          storage_;
+   uint_t                                                       minLevel_, maxLevel_;
+   std::map< uint_t, std::vector< const double* > >             elementMatrices_;
+   std::map< uint_t, std::vector< std::vector< double > > >     hostMatrices_;
+};
+using P2ElementwiseLaplaceOperator = P2ElementwiseOperator< forms::P2LaplaceForm >; // P2ElementwiseOperator.hpp:454
+
+} // namespace hyteg

@@ -1,0 +1,459 @@
+// solvers.hpp -- part of the C++ host layer above the C-ABI (see hyteg_host.hpp for the data model).
+// smoother wrappers, CGSolver, GeometricMultigridSolver (src/hyteg/solvers/)
+#pragma once
+
+#include "p1operator.hpp"
+#include "p2operator.hpp"
+#include "gridtransfer.hpp"
+
+namespace hyteg {
+
+// =====================================================================================================
+// Solvers ( src/hyteg/solvers/ )
+// =====================================================================================================
+template < class OperatorType >
+class Solver
+{
+ public:
+   using FunctionType = typename OperatorType::srcType;
+   virtual ~Solver()  = default;
+   virtual void solve( const OperatorType& A, const FunctionType& x, const FunctionType& b, uint_t level ) = 0;
+   // `steps` consecutive solve() calls (the pre-/post-smoothing loops of GeometricMultigridSolver.hpp:228-233,300-305);
+   // a smoother may override it with something equivalent but cheaper
+   virtual void solveSteps( const OperatorType& A, const FunctionType& x, const FunctionType& b, uint_t level, uint_t steps )
+   {
+      for ( uint_t i = 0; i < steps; ++i )
+         solve( A, x, b, level );
+   }
+};
+
+// WeightedJacobiSmoother.hpp:46-62
+template < class OperatorType >
+class WeightedJacobiSmoother : public Solver< OperatorType >
+{
+ public:
+   WeightedJacobiSmoother( const std::shared_ptr< PrimitiveStorage >& storage, uint_t minLevel, uint_t maxLevel, double relax )
+   : relax_( relax )
+   , tmp_( "weighted_jacobi_tmp", storage, minLevel, maxLevel )
+   , flag_( Inner | NeumannBoundary )
+   {}
+   void solve( const OperatorType& A, const P1Function< double >& x, const P1Function< double >& b, uint_t level ) override
+   {
+      tmp_.assign( { 1.0 }, { x }, level, All );
+      A.smooth_jac( x, b, tmp_, relax_, level, flag_ );
+   }
+   // n steps with ONE copy instead of n: after tmp = x (all points) a Jacobi step may just as well write into tmp
+   // reading x, since a step only writes the points `flag_` selects and all other entries of the two functions agree.
+   // Every step computes exactly what solve() computes (same kernel, same operands): results are bit-identical.
+   void solveSteps( const OperatorType& A, const P1Function< double >& x, const P1Function< double >& b, uint_t level, uint_t steps ) override
+   {
+      if ( steps == 0 )
+         return;
+      tmp_.assign( { 1.0 }, { x }, level, All );
+      for ( uint_t i = 0; i < steps; ++i )
+      {
+         if ( i % 2 == 0 )
+            A.smooth_jac( x, b, tmp_, relax_, level, flag_ );
+         else
+            A.smooth_jac( tmp_, b, x, relax_, level, flag_ );
+      }
+      if ( steps % 2 == 0 )
+         x.assign( { 1.0 }, { tmp_ }, level, flag_ );
+   }
+
+ private:
+   double               relax_;
+   P1Function< double > tmp_;
+   DoFType              flag_;
+};
+
+// GaussSeidelSmoother.hpp:38-50, SORSmoother.hpp:33-46
+template < class OperatorType >
+class SORSmoother : public Solver< OperatorType >
+{
+ public:
+   explicit SORSmoother( double relax )
+   : relax_( relax )
+   , flag_( Inner | NeumannBoundary )
+   {}
+   void solve( const OperatorType& A, const P1Function< double >& x, const P1Function< double >& b, uint_t level ) override
+   {
+      A.smooth_sor( x, b, relax_, level, flag_ );
+   }
+
+ private:
+   double  relax_;
+   DoFType flag_;
+};
+template < class OperatorType >
+class GaussSeidelSmoother : public SORSmoother< OperatorType >
+{
+ public:
+   GaussSeidelSmoother()
+   : SORSmoother< OperatorType >( 1.0 )
+   {}
+};
+
+// CGSolver.hpp:88-205 (no preconditioner: IdentityPreconditioner)
+template < class OperatorType >
+class CGSolver : public Solver< OperatorType >
+{
+ public:
+   using FunctionType = typename OperatorType::srcType;
+   CGSolver( const std::shared_ptr< PrimitiveStorage >& storage, uint_t minLevel, uint_t maxLevel, uint_t maxIter = 1000,
+             double relativeTolerance = 1e-16, double absoluteTolerance = 1e-16 )
+   : p_( "p", storage, minLevel, maxLevel )
+   , z_( "z", storage, minLevel, maxLevel )
+   , ap_( "ap", storage, minLevel, maxLevel )
+   , r_( "r", storage, minLevel, maxLevel )
+   , flag_( Inner | NeumannBoundary )
+   , maxIter_( maxIter )
+   , relTol_( relativeTolerance )
+   , absTol_( absoluteTolerance )
+   {}
+   ~CGSolver() override
+   {
+      if ( scalars_ )
+         hyteg_hip_free( scalars_ );
+   }
+   // Device-resident scalars (no counterpart in the reference, whose loop reads every dot product on the host): on
+   // coarse levels a CG iteration is ~10 launches of a few microseconds, and three host round trips per iteration
+   // cost more than the launches.  alpha, beta and the convergence test are computed by a one-thread kernel
+   // (hyteg_hip_cg_scalars), the vector updates read them from device memory, and the host looks at the convergence
+   // flag every 4 iterations; iterations enqueued after convergence are exact no-ops (alpha = 0).  Same recurrences,
+   // same arithmetic as the loop below.  Used for storages of one rank, up to level 5; off: HYTEG_AMD_DEVICE_CG=0.
+   void setUseDeviceScalars( bool on ) { useDeviceScalars_ = on; }
+
+   void solve( const OperatorType& A, const FunctionType& x, const FunctionType& b, uint_t level ) override
+   {
+      iterationsOnDevice_ = false;
+      if ( deviceScalarsUsable( x, level ) )
+      {
+         solveWithDeviceScalars( A, x, b, level );
+         return;
+      }
+      p_.setToZero( level );
+      z_.setToZero( level );
+      ap_.setToZero( level );
+      r_.setToZero( level );
+      // init(): r = b - A x ; z = r ; p = z ; prsold = <r,z>
+      A.apply( x, p_, level, flag_, Replace );
+      r_.assign( { 1.0, -1.0 }, { b, p_ }, level, flag_ );
+      z_.assign( { 1.0 }, { r_ }, level, flag_ );
+      p_.assign( { 1.0 }, { z_ }, level, flag_ );
+      double       prsold    = r_.dotGlobal( z_, level, flag_ );
+      const double res_start = std::sqrt( r_.dotGlobal( r_, level, flag_ ) );
+      iterations_            = 0;
+      if ( res_start < absTol_ )
+         return;
+      for ( uint_t i = 0; i < maxIter_; ++i )
+      {
+         A.apply( p_, ap_, level, flag_, Replace );
+         const double pAp   = p_.dotGlobal( ap_, level, flag_ );
+         const double alpha = prsold / pAp;
+         x.add( { alpha }, { p_ }, level, flag_ );
+         r_.add( { -alpha }, { ap_ }, level, flag_ );
+         const double rsnew   = r_.dotGlobal( r_, level, flag_ );
+         const double sqrsnew = std::sqrt( rsnew );
+         iterations_          = i + 1;
+         if ( sqrsnew / res_start < relTol_ || sqrsnew < absTol_ )
+            break;
+         // identity preconditioner: z = r, so <r,z> is the <r,r> just computed (the reference copies and reduces again)
+         const double prsnew = rsnew;
+         const double beta   = prsnew / prsold;
+         p_.assign( { 1.0, beta }, { r_, p_ }, level, flag_ );
+         prsold = prsnew;
+      }
+   }
+   uint_t getIterations() const
+   {
+      if ( iterationsOnDevice_ )
+      {
+         // the one-launch solve leaves its iteration count on the device; fetched (one synchronisation) only when asked for
+         double h = 0.0;
+         hipCheck( hyteg_hip_download( &h, scalars_, sizeof( double ), iterationsStream_ ), "CGSolver: iterations" );
+         iterations_         = (uint_t) h;
+         iterationsOnDevice_ = false;
+      }
+      return iterations_;
+   }
+   // levels whose cell arrays together fit one workgroup are solved by ONE launch (hyteg_hip_p1_cg_small_cells); off: false
+   void setUseSingleLaunch( bool on ) { useSingleLaunch_ = on; }
+
+ private:
+   template < typename F >
+   bool deviceScalarsUsable( const F&, uint_t ) const
+   {
+      return false; // P2 functions: host scalars
+   }
+   bool deviceScalarsUsable( const P1Function< double >& x, uint_t level ) const
+   {
+      static const bool envOn = [] {
+         const char* e = std::getenv( "HYTEG_AMD_DEVICE_CG" );
+         return !( e && e[0] == '0' );
+      }();
+      const auto& st = *x.getStorage();
+      return envOn && useDeviceScalars_ && st.numRanks() == 1 && level <= 5 && st.getNumberOfLocalCells() >= 1 &&
+             st.getNumberOfLocalCells() <= HYTEG_HIP_MAX_BATCH;
+   }
+   template < typename F >
+   void solveWithDeviceScalars( const OperatorType&, const F&, const F&, uint_t )
+   {}
+   void solveWithDeviceScalars( const OperatorType& A, const P1Function< double >& x, const P1Function< double >& b, uint_t level )
+   {
+      const auto& st = *x.getStorage();
+      if ( !scalars_ )
+      {
+         void* d = nullptr;
+         hipCheck( hyteg_hip_malloc( &d, HYTEG_HIP_CG_SLOTS * sizeof( double ) ), "CGSolver: scalars" );
+         scalars_ = static_cast< double* >( d );
+      }
+      double* const S = scalars_;
+      if ( useSingleLaunch_ && A.canCgSolveSmall( level ) )
+      {
+         A.cgSolveSmall( x, b, level, flag_, maxIter_, relTol_, absTol_, S );
+         iterationsOnDevice_ = true;
+         iterationsStream_   = st.stream(); // the download has to be ordered after the solve on ITS stream
+         return;
+      }
+      p_.setToZero( level ); // apply( p ) reads p on every point; assign below writes only the points flag_ selects
+      A.apply( x, p_, level, flag_, Replace );
+      r_.assign( { 1.0, -1.0 }, { b, p_ }, level, flag_ );
+      p_.assign( { 1.0 }, { r_ }, level, flag_ );
+      hipCheck( hyteg_hip_memset_zero( S, HYTEG_HIP_CG_SLOTS * sizeof( double ), st.stream() ), "CGSolver: scalars reset" );
+      r_.dotLocalToCgScalars( r_, level, flag_, S, HYTEG_HIP_CG_RR, 0, relTol_, absTol_ );
+      iterations_ = 0;
+      for ( uint_t i = 0; i < maxIter_; ++i )
+      {
+         A.apply( p_, ap_, level, flag_, Replace );
+         p_.dotLocalToCgScalars( ap_, level, flag_, S, HYTEG_HIP_CG_PAP, 1, relTol_, absTol_ );
+         x.vectorOpDeviceScalars( 1, { S + HYTEG_HIP_CG_ALPHA }, { p_ }, level, flag_ );
+         r_.vectorOpDeviceScalars( 1, { S + HYTEG_HIP_CG_NEG_ALPHA }, { ap_ }, level, flag_ );
+         r_.dotLocalToCgScalars( r_, level, flag_, S, HYTEG_HIP_CG_RR, 2, relTol_, absTol_ );
+         p_.vectorOpDeviceScalars( 0, { S + HYTEG_HIP_CG_ONE, S + HYTEG_HIP_CG_BETA }, { r_, p_ }, level, flag_ );
+         if ( ( i + 1 ) % 4 == 0 || i + 1 == maxIter_ )
+         {
+            double h[2];
+            hipCheck( hyteg_hip_download( h, S + HYTEG_HIP_CG_DONE, 2 * sizeof( double ), st.stream() ), "CGSolver: convergence flag" );
+            iterations_ = (uint_t) h[1];
+            if ( h[0] != 0.0 )
+               break;
+         }
+      }
+   }
+
+   bool                 useDeviceScalars_ = true, useSingleLaunch_ = true;
+   mutable bool         iterationsOnDevice_ = false;
+   hyteg_hip_stream_t   iterationsStream_   = nullptr;
+   double*              scalars_          = nullptr;
+   FunctionType         p_, z_, ap_, r_;
+   DoFType              flag_;
+   uint_t               maxIter_;
+   double               relTol_, absTol_;
+   mutable uint_t       iterations_ = 0;
+};
+
+// GeometricMultigridSolver.hpp:40-330
+template < class OperatorType >
+class GeometricMultigridSolver : public Solver< OperatorType >
+{
+ public:
+   GeometricMultigridSolver( const std::shared_ptr< PrimitiveStorage >&         storage,
+                             std::shared_ptr< Solver< OperatorType > >          smoother,
+                             std::shared_ptr< Solver< OperatorType > >          coarseSolver,
+                             std::shared_ptr< P1toP1LinearRestriction >         restrictionOperator,
+                             std::shared_ptr< P1toP1LinearProlongation >        prolongationOperator,
+                             uint_t                                             minLevel,
+                             uint_t                                             maxLevel,
+                             uint_t                                             preSmoothSteps  = 3,
+                             uint_t                                             postSmoothSteps = 3,
+                             uint_t                                             smoothIncrement = 0,
+                             CycleType                                          cycleType       = CycleType::VCYCLE )
+   : minLevel_( minLevel )
+   , maxLevel_( maxLevel )
+   , preSmoothSteps_( preSmoothSteps )
+   , postSmoothSteps_( postSmoothSteps )
+   , smoothIncrement_( smoothIncrement )
+   , flag_( Inner | NeumannBoundary )
+   , cycleType_( cycleType )
+   , smoother_( smoother )
+   , coarseSolver_( coarseSolver )
+   , restrictionOperator_( restrictionOperator )
+   , prolongationOperator_( prolongationOperator )
+   , tmp_( "gmg_tmp", storage, minLevel, maxLevel )
+   , storage_( storage )
+   {}
+
+   ~GeometricMultigridSolver() override
+   {
+      for ( auto& kv : recordings_ )
+         kv.second.destroy();
+      if ( captureStream_ )
+         hyteg_hip_stream_destroy( captureStream_ );
+   }
+
+   // Launch graphs (no counterpart in the reference, whose cycle is host loops): the launches of a cycle -- ~20 per
+   // level, most of them a few microseconds on the coarse levels -- are recorded once per (operator, x, b, level) and
+   // replayed as one graph launch per segment between coarse-grid solves (the coarse solver reads dot products on the
+   // host and stays outside).  The first cycle with given arguments runs with ordinary launches (it creates every lazily
+   // built table and scratch array), the second records (nothing executes while recording) and replays, later cycles
+   // replay.  Same kernels, same order, same arguments: results are identical to ordinary launches.
+   // Opt-in: setUseGraphs( true ) or HYTEG_AMD_GRAPHS=1.  Measured on MI355X the replay saves only 1-8 % of a cycle (the
+   // cycle is bound by the ~3 us a dependent small kernel takes on the GPU, not by the host's launch rate), while
+   // recording and instantiating costs a few milliseconds once -- it pays for solves of many cycles only.  Never
+   // used for storages distributed over several ranks (the exchange hooks are host callbacks).
+   void setUseGraphs( bool on ) { useGraphs_ = on; }
+   std::shared_ptr< Solver< OperatorType > > getCoarseSolver() const { return coarseSolver_; }
+   bool usesGraphs() const { return graphsUsable(); }
+   // number of cycles that were replayed from a recording (tests)
+   uint_t replayedCycles() const { return replayed_; }
+
+   void solve( const OperatorType& A, const P1Function< double >& x, const P1Function< double >& b, uint_t level ) override
+   {
+      invokedLevel_ = level;
+      if ( !graphsUsable() )
+      {
+         solveRecursively( A, x, b, level );
+         return;
+      }
+      const Key key{ A.uid(), x.uid(), b.uid(), level };
+      auto      it = recordings_.find( key );
+      if ( it == recordings_.end() )
+      {
+         if ( recordings_.size() >= 8 )
+         {
+            for ( auto& kv : recordings_ )
+               kv.second.destroy();
+            recordings_.clear();
+         }
+         recordings_[key] = Recording{};
+         solveRecursively( A, x, b, level );
+         return;
+      }
+      Recording& rec = it->second;
+      if ( !rec.recorded && !rec.failed )
+         record( rec, A, x, b, level );
+      if ( !rec.recorded )
+      {
+         solveRecursively( A, x, b, level );
+         return;
+      }
+      for ( size_t k = 0; k < rec.segments.size(); ++k )
+      {
+         hipCheck( hyteg_hip_graph_launch( rec.segments[k], storage_->stream() ), "GeometricMultigridSolver: graph launch" );
+         if ( k + 1 < rec.segments.size() )
+            coarseSolver_->solve( A, x, b, minLevel_ );
+      }
+      ++replayed_;
+   }
+
+ private:
+   using Key = std::tuple< uint64_t, uint64_t, uint64_t, uint_t >;
+   struct Recording
+   {
+      std::vector< hyteg_hip_graph_t > segments; // separated by coarse-grid solves
+      bool                             recorded = false, failed = false;
+      int                              attempts = 0;
+      void                             destroy()
+      {
+         for ( auto g : segments )
+            hyteg_hip_graph_destroy( g );
+         segments.clear();
+      }
+   };
+
+   bool graphsUsable() const
+   {
+      static const bool envOn = [] {
+         const char* e = std::getenv( "HYTEG_AMD_GRAPHS" );
+         return e && e[0] == '1';
+      }();
+      return ( useGraphs_ || envOn ) && storage_->numRanks() == 1;
+   }
+
+   void endSegment( Recording& rec )
+   {
+      hyteg_hip_graph_t g = nullptr;
+      capturing_          = false;
+      hipCheck( hyteg_hip_graph_end_capture( captureStream_, &g ), "GeometricMultigridSolver: end capture" );
+      rec.segments.push_back( g );
+   }
+   void beginSegment()
+   {
+      hipCheck( hyteg_hip_graph_begin_capture( captureStream_ ), "GeometricMultigridSolver: begin capture" );
+      capturing_ = true;
+   }
+
+   void record( Recording& rec, const OperatorType& A, const P1Function< double >& x, const P1Function< double >& b, uint_t level )
+   {
+      const hyteg_hip_stream_t user = storage_->stream();
+      try
+      {
+         if ( !captureStream_ )
+            hipCheck( hyteg_hip_stream_create( &captureStream_ ), "GeometricMultigridSolver: stream" );
+         storage_->setStream( captureStream_ );
+         recording_ = &rec;
+         beginSegment();
+         solveRecursively( A, x, b, level );
+         endSegment( rec );
+         rec.recorded = true;
+      } catch ( const std::exception& e )
+      {
+         // something in the cycle cannot be recorded: nothing has executed, fall back to ordinary launches for good
+         if ( rec.attempts >= 2 )
+            std::fprintf( stderr, "hyteg_amd: multigrid cycle not recordable (%s); using ordinary launches\n", e.what() );
+         if ( capturing_ )
+            hyteg_hip_graph_abort_capture( captureStream_ );
+         capturing_ = false;
+         rec.destroy();
+         rec.failed = ++rec.attempts >= 3; // a table built lazily in this very cycle: the next cycle tries again
+      }
+      recording_ = nullptr;
+      storage_->setStream( user );
+   }
+
+   void solveRecursively( const OperatorType& A, const P1Function< double >& x, const P1Function< double >& b, uint_t level )
+   {
+      if ( level == minLevel_ )
+      {
+         if ( recording_ )
+         {
+            endSegment( *recording_ );
+            beginSegment();
+         }
+         else
+            coarseSolver_->solve( A, x, b, minLevel_ );
+         return;
+      }
+      const uint_t pre = preSmoothSteps_ + smoothIncrement_ * ( invokedLevel_ - level );
+      smoother_->solveSteps( A, x, b, level, pre );
+      A.apply( x, tmp_, level, flag_ );
+      tmp_.assign( { 1.0, -1.0 }, { b, tmp_ }, level, flag_ );
+      restrictionOperator_->restrict( tmp_, level, flag_ );
+      b.assign( { 1.0 }, { tmp_ }, level - 1, flag_ );
+      x.interpolate( 0.0, level - 1 );
+      solveRecursively( A, x, b, level - 1 );
+      if ( cycleType_ == CycleType::WCYCLE )
+         solveRecursively( A, x, b, level - 1 );
+      prolongationOperator_->prolongateAndAdd( x, level - 1, flag_ );
+      const uint_t post = postSmoothSteps_ + smoothIncrement_ * ( invokedLevel_ - level );
+      smoother_->solveSteps( A, x, b, level, post );
+   }
+
+   uint_t                                       minLevel_, maxLevel_, preSmoothSteps_, postSmoothSteps_, smoothIncrement_;
+   uint_t                                       invokedLevel_ = 0;
+   DoFType                                      flag_;
+   CycleType                                    cycleType_;
+   std::shared_ptr< Solver< OperatorType > >    smoother_, coarseSolver_;
+   std::shared_ptr< P1toP1LinearRestriction >   restrictionOperator_;
+   std::shared_ptr< P1toP1LinearProlongation >  prolongationOperator_;
+   P1Function< double >                         tmp_;
+   std::shared_ptr< PrimitiveStorage >          storage_;
+   bool                                         useGraphs_ = false, capturing_ = false;
+   hyteg_hip_stream_t                           captureStream_ = nullptr;
+   Recording*                                   recording_     = nullptr;
+   std::map< Key, Recording >                   recordings_;
+   uint_t                                       replayed_ = 0;
+};
+
+} // namespace hyteg

@@ -127,6 +127,11 @@ HYTEG_HIP_API int hyteg_hip_p1_apply_cell( double*            dst,
                                            int                update,
                                            hyteg_hip_stream_t stream );
 
+/* Name of the kernel instantiation hyteg_hip_p1_apply_cell( ..., level, ..., update, ... ) launches on the current device,
+ * with its template arguments, e.g. "p1_apply_zmarch_kernel<MODE=0,NY=4,LZ=8,EX_AUX=0,DEC=1,PFD=1>" — what profiler
+ * output and recorded counter files are matched against (no reference counterpart: measurement support). */
+HYTEG_HIP_API int hyteg_hip_p1_apply_kernel_name( int level, int update, char* buf, size_t buflen );
+
 /* ---- a4: weighted Jacobi sweep, fused ------------------------------------------------------------------
  * replaces the 1 apply + 3 vector passes of P1Operator::smooth_jac
  *   src/hyteg/p1functionspace/P1Operator.hpp:429-447

@@ -7,7 +7,7 @@ import numpy as np
 from hyteg_amd import host
 from oracle import p1_oracle as po
 
-MESHES = Path(__file__).resolve().parent / "golden" / "meshes"
+MESHES = Path(__file__).resolve().parent.parent / "hyteg_amd" / "data" / "meshes"
 
 
 def cell_points(coords4, level):

@@ -13,7 +13,7 @@ import torch
 import torch.multiprocessing as mp
 
 ROOT = Path(__file__).resolve().parent.parent
-MESH = ROOT / "tests" / "golden" / "meshes" / "regular_octahedron_8el.msh"
+MESH = ROOT / "hyteg_amd" / "data" / "meshes" / "regular_octahedron_8el.msh"
 
 
 def _free_port():

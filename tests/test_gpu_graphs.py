@@ -8,7 +8,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
-MESHES = ROOT / "tests" / "golden" / "meshes"
+MESHES = ROOT / "hyteg_amd" / "data" / "meshes"
 
 
 @pytest.fixture(scope="module")

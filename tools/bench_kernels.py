@@ -32,7 +32,7 @@ def main():
     B = [torch.rand(n, dtype=torch.float64, device="cuda") for _ in range(nbuf)]
     Cc = [torch.rand(n, dtype=torch.float64, device="cuda") for _ in range(nbuf)]
     Co = [torch.rand(nc, dtype=torch.float64, device="cuda") for _ in range(nbuf)]
-    st = host.Storage.from_gmsh(ROOT / "tests/golden/meshes/tet_1el.msh")
+    st = host.Storage.from_gmsh(ROOT / "hyteg_amd/data/meshes/tet_1el.msh")
     st.set_stream(sh)
     op = host.P1ConstantOperator(st, 2, L)
     w = list(op.stencils(0, L)[0])
@@ -82,7 +82,7 @@ def main():
     sys.path.insert(0, str(ROOT / "tests"))
     import hostutil as hu  # noqa: E402
 
-    mv, mc = hu.read_msh(ROOT / "tests/golden/meshes/regular_octahedron_8el.msh")
+    mv, mc = hu.read_msh(ROOT / "hyteg_amd/data/meshes/regular_octahedron_8el.msh")
     T = hu.sor_tables(mv, mc, L)[0]
     shell_pts = 4 * ((1 << L) + 1) * ((1 << L) + 2) // 2
     timeit("SOR shell forward (4 faces, 6 edges, 4 vertices)",
@@ -107,7 +107,7 @@ def main():
            16 * (nv2 + ne2), nv2 + ne2, r=max(3, reps // 10))
     # BASELINE config 4 shape on one GPU: P2 Laplace, level 7, the 6 macro-cells one GPU holds (cube_6el = the unit cube)
     if L >= 7:
-        s6 = host.Storage.from_gmsh(ROOT / "tests/golden/meshes/cube_6el.msh")
+        s6 = host.Storage.from_gmsh(ROOT / "hyteg_amd/data/meshes/cube_6el.msh")
         s6.set_stream(sh)
         A6 = host.P2ElementwiseLaplaceOperator(s6, 7, 7)
         u6, r6 = host.P2Function(s6, "u", 7, 7), host.P2Function(s6, "r", 7, 7)
@@ -131,7 +131,7 @@ def main():
     for mesh, lo, hi, smoother, name in (("tet_1el", 2, L, host.JACOBI, "Jacobi(2/3)"), ("tet_1el", 2, min(L, 7), host.GAUSS_SEIDEL, "GS"),
                                           ("regular_octahedron_8el", 2, min(L, 6), host.JACOBI, "Jacobi(2/3)"),
                                           ("regular_octahedron_8el", 0, min(L, 6), host.GAUSS_SEIDEL, "GS")):
-        s2 = host.Storage.from_gmsh(ROOT / f"tests/golden/meshes/{mesh}.msh")
+        s2 = host.Storage.from_gmsh(ROOT / f"hyteg_amd/data/meshes/{mesh}.msh")
         s2.set_stream(sh)
         A2 = host.P1ConstantOperator(s2, lo, hi)
         A2.compute_inverse_diagonal()
