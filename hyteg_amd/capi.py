@@ -29,6 +29,16 @@ SIGNATURES = {
     "hyteg_hip_stream_create": (_i, [C.POINTER(_vp)]),
     "hyteg_hip_stream_destroy": (_i, [_vp]),
     "hyteg_hip_stream_synchronize": (_i, [_vp]),
+    "hyteg_hip_event_create": (_i, [C.POINTER(_vp)]),
+    "hyteg_hip_event_destroy": (_i, [_vp]),
+    "hyteg_hip_event_record": (_i, [_vp, _vp]),
+    "hyteg_hip_stream_wait_event": (_i, [_vp, _vp]),
+    "hyteg_hip_comm_available": (_i, [C.c_char_p, _sz]),
+    "hyteg_hip_comm_unique_id": (_i, [C.c_char_p]),
+    "hyteg_hip_comm_create": (_i, [C.POINTER(_vp), _i, _i, C.c_char_p]),
+    "hyteg_hip_comm_destroy": (_i, [_vp]),
+    "hyteg_hip_comm_exchange": (_i, [_vp, _i, C.POINTER(_i), _vp, C.POINTER(_i), _vp, C.POINTER(_i), _vp]),
+    "hyteg_hip_comm_allreduce_sum": (_i, [_vp, _vp, _i, _vp]),
     "hyteg_hip_graph_begin_capture": (_i, [_vp]),
     "hyteg_hip_graph_end_capture": (_i, [_vp, C.POINTER(_vp)]),
     "hyteg_hip_graph_abort_capture": (_i, [_vp]),
@@ -151,6 +161,19 @@ def device_name() -> str:
     buf = C.create_string_buffer(256)
     check(lib().hyteg_hip_device_name(buf, 256), "device_name")
     return buf.value.decode()
+
+
+def comm_available() -> str:
+    """where librccl was resolved from (raises if it cannot be)"""
+    buf = C.create_string_buffer(256)
+    check(lib().hyteg_hip_comm_available(buf, 256), "comm_available")
+    return buf.value.decode()
+
+
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    check(lib().hyteg_hip_comm_unique_id(buf), "comm_unique_id")
+    return buf.raw
 
 
 def p1_apply_kernel_name(level, update=REPLACE) -> str:

@@ -35,6 +35,7 @@ __device__ unsigned long long* g_trace;
 #endif
 
 #include "../kernels_apply_zmarch.hpp"
+#include "kernels_apply_zloop.hpp"
 
 using namespace hyteg_hip;
 
@@ -265,14 +266,12 @@ int main( int argc, char** argv )
    };
 
    run( "zmarch 4x8 table PFD1", 4, 8, false, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 8, 0, false, 1 > );
+   run( "zmarch 4x8 table PFD2", 4, 8, false, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 8, 0, false, 2 > );
    run( "zmarch 4x8 decode PFD1", 4, 8, true, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 8, 0, true, 1 > );
-   run( "zmarch 4x8 decode PFD2", 4, 8, true, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 8, 0, true, 2 > );
    run( "zmarch 4x4 table PFD1", 4, 4, false, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 0, false, 1 > );
-   run( "zmarch 4x4 decode PFD1", 4, 4, true, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 0, true, 1 > );
-   run( "zmarch 4x4 decode PFD2", 4, 4, true, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 4, 0, true, 2 > );
-   run( "zmarch 2x8 decode PFD1", 2, 8, true, p1_apply_zmarch_kernel< APPLY_REPLACE, 2, 8, 0, true, 1 > );
-   run( "zmarch 4x6 decode PFD1", 4, 6, true, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 6, 0, true, 1 > );
-   run( "zmarch 4x16 decode PFD1", 4, 16, true, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 16, 0, true, 1 > );
-   run( "zmarch 6x8 decode PFD1", 6, 8, true, p1_apply_zmarch_kernel< APPLY_REPLACE, 6, 8, 0, true, 1 > );
+   run( "zmarch 4x6 table PFD1", 4, 6, false, p1_apply_zmarch_kernel< APPLY_REPLACE, 4, 6, 0, false, 1 > );
+   run( "zmarch 2x8 table PFD1", 2, 8, false, p1_apply_zmarch_kernel< APPLY_REPLACE, 2, 8, 0, false, 1 > );
+   run( "zmarch 3x8 table PFD1", 3, 8, false, p1_apply_zmarch_kernel< APPLY_REPLACE, 3, 8, 0, false, 1 > );
+   run( "zloop 4x8 renaming(4)", 4, 8, false, p1_apply_zloop_kernel< APPLY_REPLACE, 4, 4 > );
    return 0;
 }

@@ -5,3 +5,5 @@ D="$(cd "$(dirname "$0")" && pwd)"
 F="--offload-arch=gfx950 -O3 -std=c++20 -DHYTEG_HIP_BUILDING"
 /opt/rocm/bin/hipcc $F -o "$D/apply_trace_time" "$D/apply_trace.hip" "$D/../runtime.hip"
 /opt/rocm/bin/hipcc $F -DZM_DO_TRACE -o "$D/apply_trace" "$D/apply_trace.hip" "$D/../runtime.hip"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -o "$D/icache_probe" "$D/icache_probe.hip"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -o "$D/copy_calib" "$D/copy_calib.hip"

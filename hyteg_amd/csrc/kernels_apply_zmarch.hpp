@@ -15,7 +15,8 @@
 // end-of-kernel L2 write-back: 14.5 -> 10.4 us at level 8).
 //
 // The superseded variants and ablation switches of round 1 (reference summation order, all-loads-first, unmasked
-// loads, per-lane addressing ...) live in exp/kernels_apply_zmarch_r01.hpp with the harness that measured them.
+// loads, per-lane addressing ...) and their harness are in the history (commit ceeab28, hyteg_amd/csrc/exp/apply_bench.hip);
+// their measurements are profiles/r01_apply_*.txt.
 //
 // Index algebra: W = N-z; element (x,y,z) -> (x,y,z+1): + tri(W) - y;  (x,y,z) -> (x,y+1,z): + (W-y).
 #pragma once
@@ -28,6 +29,7 @@
 
 namespace hyteg_hip {
 
+constexpr int kBrickMaxSlices = 10; // LZ + 2 for the tallest brick shape in use (LZ = 8)
 struct BrickTask
 {
    int i0;  // element index of (xb, y0-1, z0-1): first row segment of the first slice
@@ -35,9 +37,13 @@ struct BrickTask
    int y0;  // first output row
    int xb;  // x held by lane 0 (= x0 - 1, x0 = first output x)
    int nz;  // slices of this brick that exist (<= LZ)
-   int pad[3];
+   int pad;
+   // element index of (xb, y0-1, z0-1+q), q = 0 .. LZ+1 (base[0] = i0): the table carries them so that a wave does not
+   // spend ~75 scalar instructions on triangular numbers between reading its task and issuing its first loads -- the 8
+   // waves of a CU share one scalar unit and at level 8 they all do this at the same moment
+   int base[kBrickMaxSlices];
 };
-static_assert( sizeof( BrickTask ) == 32, "BrickTask must be 32 bytes" );
+static_assert( sizeof( BrickTask ) == 64, "BrickTask must be 64 bytes (one s_load_dwordx16)" );
 
 constexpr int kZMarchMaxZChunks = 32; // decode mode: number of z-chunks whose first task index fits the kernel arguments
 constexpr int kZMarchMaxStairs  = 5;  // decode mode: x-chunks of the longest row (N - 4 <= 310: up to level 8)
@@ -97,6 +103,17 @@ __device__ inline double zm_lane_plus_1( double v )
    return __hiloint2double( hi, lo );
 }
 
+__host__ __device__ inline void zm_fill_bases( BrickTask& t, int LZ )
+{
+   int base = t.i0, Wq = t.W0;
+   for ( int q = 0; q < kBrickMaxSlices; ++q )
+   {
+      t.base[q] = q < LZ + 2 ? base : 0;
+      base += tri( Wq ) - ( t.y0 - 1 ); // (x, ym, z) -> (x, ym, z+1)
+      Wq -= 1;
+   }
+}
+
 // Bricks are enumerated z-chunk, y-chunk, x-chunk (memory order).  z-chunk k: z0 = 1 + LZ k, M = N - 4 - LZ k (>= 1);
 // its y-chunk yc (y0 = 1 + NY yc <= M) has ( M - NY yc + 61 ) / 62 x-chunks of 62 outputs.
 template < int NY, int LZ >
@@ -109,7 +126,7 @@ __host__ __device__ inline BrickTask zm_make_task( int N, int k, int yc, int xc 
    t.W0 = W + 1;
    t.i0 = slice_start( N, z0 - 1 ) + row_start( W + 1, y0 - 1 ) + t.xb;
    t.nz = LZ < N - 3 - z0 ? LZ : N - 3 - z0;
-   return t;
+   return t; // base[] is not filled: the decode mode recomputes the slice bases in the kernel
 }
 
 // Decode mode: the brick of a task index from the z-chunk starts in the kernel arguments, scalar arithmetic only —
@@ -212,13 +229,14 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_k
    };
 
    // wave-uniform element index of (xb, ym, z0-1+q) and row-0 length of that slice
+   static_assert( LZ + 2 <= kBrickMaxSlices || DEC, "brick taller than the table's base array" );
    int baseq[LZ + 2], Wqs[LZ + 2];
    {
       int base = t.i0, Wq = t.W0;
 #pragma unroll
       for ( int q = 0; q < LZ + 2; ++q )
       {
-         baseq[q] = base;
+         baseq[q] = DEC ? base : t.base[q < kBrickMaxSlices ? q : 0];
          Wqs[q]   = Wq;
          base += tri( Wq ) - ym; // (x, ym, z) -> (x, ym, z+1)
          Wq -= 1;
@@ -331,6 +349,7 @@ inline void build_brick_tasks( int level, int NY, int LZ, std::vector< BrickTask
             t.W0 = W + 1;
             t.i0 = slice_start( N, z0 - 1 ) + row_start( W + 1, y0 - 1 ) + t.xb;
             t.nz = std::min( LZ, N - 4 - z0 + 1 );
+            zm_fill_bases( t, LZ );
             out.push_back( t );
          }
       }

@@ -16,14 +16,25 @@ constexpr int kTile = 1024;
 constexpr int kBrickNY = 4;
 inline int   brick_lz( int level ) { return level >= 8 ? 8 : 4; }
 
-// developer switch: HYTEG_HIP_APPLY_DECODE=0 falls back to the brick table at every level
+// developer switches (measurement only).  HYTEG_HIP_APPLY_DECODE=1: bricks decoded from the task index instead of read from
+// the table (measured SLOWER: 12.0 vs 10.0 us at level 8 -- ~200 scalar instructions per wave on the CU's one scalar
+// unit cost more than the table's round trip; profiles/r02_apply_wave_trace_table_vs_decode.txt).
+// HYTEG_HIP_APPLY_PFD=2: loads run two slices ahead of the arithmetic instead of one.
 inline bool apply_decode_enabled()
 {
    static const bool on = [] {
       const char* e = getenv( "HYTEG_HIP_APPLY_DECODE" );
-      return !( e && e[0] == '0' );
+      return e && e[0] == '1';
    }();
    return on;
+}
+inline int apply_prefetch_distance()
+{
+   static const int pfd = [] {
+      const char* e = getenv( "HYTEG_HIP_APPLY_PFD" );
+      return ( e && e[0] == '2' ) ? 2 : 1;
+   }();
+   return pfd;
 }
 
 template < int MODE, int LZ >
@@ -58,10 +69,11 @@ int launch_zmarch_lz( double* dst, const double* src, const double* rhs, const d
    // inverse diagonal of Jacobi are re-read by the next sweep of the smoother and stay plain (nontemporal: 12.4 -> 17.6 us
    // when they are still in the Infinity Cache, -2% when they are not).
    constexpr int kExAux = MODE == APPLY_ADD ? 2 : 0;
-   // up to level 8 a wave decodes its brick from its index (no table load in front of the first source loads)
    const dim3 grid( nblocks ), block( 64 * kZMarchWavesPerBlock );
    if ( bt.decodable && apply_decode_enabled() )
       hipLaunchKernelGGL( ( p1_apply_zmarch_kernel< MODE, kBrickNY, LZ, kExAux, true > ), grid, block, 0, stream, A );
+   else if ( apply_prefetch_distance() == 2 )
+      hipLaunchKernelGGL( ( p1_apply_zmarch_kernel< MODE, kBrickNY, LZ, kExAux, false, 2 > ), grid, block, 0, stream, A );
    else
       hipLaunchKernelGGL( ( p1_apply_zmarch_kernel< MODE, kBrickNY, LZ, kExAux, false > ), grid, block, 0, stream, A );
    HH_CHECK_HIP( hipGetLastError() );
@@ -157,7 +169,8 @@ HYTEG_HIP_API int hyteg_hip_p1_apply_kernel_name( int level, int update, char* b
    if ( rc != HYTEG_HIP_OK )
       return rc;
    snprintf( buf, buflen, "p1_apply_zmarch_kernel<MODE=%d,NY=%d,LZ=%d,EX_AUX=%d,DEC=%d,PFD=%d>", mode, kBrickNY, lz,
-             mode == APPLY_ADD ? 2 : 0, ( bt.decodable && apply_decode_enabled() ) ? 1 : 0, 1 );
+             mode == APPLY_ADD ? 2 : 0, ( bt.decodable && apply_decode_enabled() ) ? 1 : 0,
+             ( bt.decodable && apply_decode_enabled() ) ? 1 : apply_prefetch_distance() );
    return HYTEG_HIP_OK;
 }
 

@@ -1,103 +1,128 @@
 """torch.distributed plumbing for storages partitioned over several ranks (one process per GPU).
 
-The C++ host layer (hyteg_amd/host/hyteg_host.hpp) packs the partial values of shared macro-face/edge/vertex DoFs
-into one send buffer per (level, boundary class), calls the `exchange` hook, and then reduces local and received
-values in a fixed order.  This module owns the buffers (torch tensors, so that the RCCL / gloo backends can move
-them) and implements the two hooks:
+Two transports sit behind the shared-point exchange of the C++ host layer (hyteg_amd/host/comm.hpp):
 
-  exchange(level, cls):   dist.all_to_all_single over the registered send/recv tensors, split per peer rank
-                          (neighbour exchange: ranks that share no primitive exchange 0 elements);
-  allreduce_sum(v, n):    dist.all_reduce(SUM) of n doubles  (walberla::mpi::allReduceInplace in
-                          src/hyteg/p1functionspace/VertexDoFFunction.cpp:1717).
+  "rccl"   the production path.  The host layer issues ncclSend / ncclRecv groups and ncclAllReduce itself (C-ABI
+           hyteg_hip_comm_*, RCCL over xGMI) on its own communication stream, ordered against the compute stream with
+           events -- nothing of an exchange passes through Python.  torch.distributed is only used here to hand the
+           128-byte unique id of rank 0 to the other ranks (what MPI_Bcast would do inside HyTeG).
+  "hooks"  the test path.  The host layer packs the partial values of shared macro-face/edge/vertex DoFs into one send
+           buffer per (level, plan), calls the `exchange` hook, and then reduces local and received values in a fixed
+           order.  This module owns the buffers (torch tensors) and implements the hooks with
+           dist.all_to_all_single (neighbour exchange: ranks that share no primitive exchange 0 elements) and
+           dist.all_reduce (walberla::mpi::allReduceInplace in src/hyteg/p1functionspace/VertexDoFFunction.cpp:1717).
+           Backend "gloo" moves them through host memory: this is how the CPU tests and the two-ranks-on-one-GPU tests
+           run the multi-rank logic without one GPU per rank.
 
-Backend "nccl" is RCCL over xGMI on ROCm; backend "gloo" with CPU tensors is used by the CPU tests, which emulate the
-pack / reduce kernels with numpy on the exported plan (tests/test_distributed_gloo.py)."""
+A plan is identified by (level, key) with key = cls + 2 * dof_kind (boundary class 0 / 1; vertex DoFs / edge DoFs of P2
+functions)."""
 from __future__ import annotations
-
-import ctypes as C
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import host
+from . import capi, host
 
 
 class DistributedContext:
-    def __init__(self, storage: host.Storage, levels, device: torch.device | str):
+    def __init__(self, storage: host.Storage, levels, device: torch.device | str, transport: str = "auto", dof_kinds=(0,),
+                 stream: int | None = None):
         self.storage = storage
         self.device = torch.device(device)
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
+        if transport == "auto":
+            transport = "rccl" if (dist.get_backend() == "nccl" and self.device.type == "cuda") else "hooks"
+        self.transport = transport
         self.buffers = {}
         self._views = {}
         self.plans = {}
+        self._pending = {}
+        if transport == "rccl":
+            # the unique id of rank 0 reaches the other ranks through torch.distributed's store; the communicator is
+            # created (collectively) on this rank's current device
+            ids = [capi.comm_unique_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            storage.use_rccl(ids[0])
+            return
+        if transport != "hooks":
+            raise ValueError(f"unknown transport {transport!r}")
+        # the hooks run on the stream the host layer launches its pack / reduce kernels on
+        self._stream = None
+        if self.device.type == "cuda":
+            raw = storage.stream if stream is None else stream
+            self._stream = torch.cuda.ExternalStream(raw, device=self.device) if raw else torch.cuda.default_stream(self.device)
         for level in levels:
-            for cls in (0, 1):
-                p = storage.plan(level, cls)
-                self.plans[(level, cls)] = p
-                # the exchange is a collective: either every rank takes part in it or none does
-                anybody = torch.tensor([1 if len(p["peers"]) else 0], dtype=torch.int32,
-                                       device=self.device if dist.get_backend() == "nccl" else "cpu")
-                dist.all_reduce(anybody, op=dist.ReduceOp.MAX)
-                if int(anybody.item()) == 0:
-                    continue
-                send = torch.zeros(max(1, p["total_send"]), dtype=torch.float64, device=self.device)
-                recv = torch.zeros(max(1, p["total_recv"]), dtype=torch.float64, device=self.device)
-                in_splits = [0] * self.world
-                out_splits = [0] * self.world
-                for k, peer in enumerate(p["peers"]):
-                    in_splits[int(peer)] = int(p["send_count"][k])
-                    out_splits[int(peer)] = int(p["recv_count"][k])
-                # views and split lists are built once: the hooks run once per operator application
-                self.buffers[(level, cls)] = (send, recv, in_splits, out_splits)
-                self._views[(level, cls)] = (send[:sum(in_splits)], recv[:sum(out_splits)])
-                if self.device.type == "cuda" and len(p["peers"]):
-                    storage.register_comm_buffers(level, cls, send.data_ptr(), recv.data_ptr())
-        # gloo cannot move device tensors in all_to_all: stage through pinned host memory (test / fallback transport;
-        # the production transport is RCCL, which works on the device buffers directly)
+            for dof_kind in dof_kinds:
+                for cls in (0, 1):
+                    key = cls + 2 * dof_kind
+                    p = storage.plan(level, key)
+                    self.plans[(level, key)] = p
+                    # the exchange is a collective: either every rank takes part in it or none does
+                    anybody = torch.tensor([1 if len(p["peers"]) else 0], dtype=torch.int32,
+                                           device=self.device if dist.get_backend() == "nccl" else "cpu")
+                    dist.all_reduce(anybody, op=dist.ReduceOp.MAX)
+                    if int(anybody.item()) == 0:
+                        continue
+                    send = torch.zeros(max(1, p["total_send"]), dtype=torch.float64, device=self.device)
+                    recv = torch.zeros(max(1, p["total_recv"]), dtype=torch.float64, device=self.device)
+                    in_splits = [0] * self.world
+                    out_splits = [0] * self.world
+                    for k, peer in enumerate(p["peers"]):
+                        in_splits[int(peer)] = int(p["send_count"][k])
+                        out_splits[int(peer)] = int(p["recv_count"][k])
+                    # views and split lists are built once: the hooks run once per operator application
+                    self.buffers[(level, key)] = (send, recv, in_splits, out_splits)
+                    self._views[(level, key)] = (send[:sum(in_splits)], recv[:sum(out_splits)])
+                    if self.device.type == "cuda" and len(p["peers"]):
+                        storage.register_comm_buffers(level, key, send.data_ptr(), recv.data_ptr())
+        # gloo cannot move device tensors in all_to_all: stage through host memory
         self._stage = dist.get_backend() == "gloo" and self.device.type == "cuda"
         self._scalar = torch.zeros(8, dtype=torch.float64, device="cpu" if self._stage else self.device)
-        self._pending = {}
         storage.set_hooks(self.exchange_begin, self.exchange_end, self.allreduce_sum)
 
-    def send_tensor(self, level, cls):
-        return self.buffers[(level, cls)][0]
+    def send_tensor(self, level, key):
+        return self.buffers[(level, key)][0]
 
-    def recv_tensor(self, level, cls):
-        return self.buffers[(level, cls)][1]
+    def recv_tensor(self, level, key):
+        return self.buffers[(level, key)][1]
 
-    # ---- hooks ----
-    def exchange_begin(self, level: int, cls: int) -> None:
-        """start the neighbour all-to-all; the pack kernel ran on torch's current stream (= the storage's stream) and
-        the collective orders itself after it.  Returns immediately: kernels launched next overlap the transfer."""
-        if (level, cls) not in self.buffers:
-            return
-        send, recv, in_splits, out_splits = self.buffers[(level, cls)]
+    def _on_stream(self):
+        return torch.cuda.stream(self._stream) if self._stream is not None else _NullContext()
+
+    # ---- hooks (an exception raised here fails the host-layer operation that called the hook) ----
+    def exchange_begin(self, level: int, key: int) -> None:
+        """start the neighbour all-to-all behind the pack kernel (same stream).  Returns immediately: kernels launched
+        next overlap the transfer."""
+        if (level, key) not in self.buffers:
+            raise KeyError(f"exchange of level {level}, plan {key}: no buffers were set up for it "
+                           f"(levels / dof_kinds given to DistributedContext)")
+        send, recv, in_splits, out_splits = self.buffers[(level, key)]
         n_in, n_out = sum(in_splits), sum(out_splits)
-        if self._stage:
-            host_send = send[:n_in].cpu()  # synchronises with the pack kernel on the current stream
-            host_recv = torch.empty(n_out, dtype=torch.float64)
-            work = dist.all_to_all_single(host_recv, host_send, out_splits, in_splits, async_op=True)
-            self._pending[(level, cls)] = (work, host_recv, recv, n_out)
-        else:
-            send_v, recv_v = self._views[(level, cls)]
-            self._pending[(level, cls)] = dist.all_to_all_single(recv_v, send_v, out_splits, in_splits, async_op=True)
+        with self._on_stream():
+            if self._stage:
+                host_send = send[:n_in].cpu()  # synchronises with the pack kernel on the stream
+                host_recv = torch.empty(n_out, dtype=torch.float64)
+                work = dist.all_to_all_single(host_recv, host_send, out_splits, in_splits, async_op=True)
+                self._pending[(level, key)] = (work, host_recv, recv, n_out)
+            else:
+                send_v, recv_v = self._views[(level, key)]
+                self._pending[(level, key)] = dist.all_to_all_single(recv_v, send_v, out_splits, in_splits, async_op=True)
 
-    def exchange_end(self, level: int, cls: int) -> None:
-        work = self._pending.pop((level, cls), None)
-        if work is None:
-            return
-        if self._stage:
-            w, host_recv, recv, n_out = work
-            w.wait()
-            recv[:n_out].copy_(host_recv)
-        else:
-            work.wait()  # makes the current stream wait for the collective (no host sync on the nccl backend)
+    def exchange_end(self, level: int, key: int) -> None:
+        work = self._pending.pop((level, key))
+        with self._on_stream():
+            if self._stage:
+                w, host_recv, recv, n_out = work
+                w.wait()
+                recv[:n_out].copy_(host_recv)
+            else:
+                work.wait()  # makes the stream wait for the collective (no host sync on the nccl backend)
 
-    def exchange(self, level: int, cls: int) -> None:
-        self.exchange_begin(level, cls)
-        self.exchange_end(level, cls)
+    def exchange(self, level: int, key: int) -> None:
+        self.exchange_begin(level, key)
+        self.exchange_end(level, key)
 
     def allreduce_sum(self, values, n: int) -> None:
         arr = np.ctypeslib.as_array(values, shape=(n,))
@@ -105,3 +130,11 @@ class DistributedContext:
         t.copy_(torch.from_numpy(arr.copy()))
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         arr[:] = t.cpu().numpy()
+
+
+class _NullContext:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

@@ -17,8 +17,8 @@ JACOBI, GAUSS_SEIDEL, SOR = 0, 1, 2
 
 _vp, _i, _d, _u = C.c_void_p, C.c_int, C.c_double, C.c_uint
 _ip, _dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
-EXCHANGE_CB = C.CFUNCTYPE(None, _vp, _i, _i)
-ALLREDUCE_CB = C.CFUNCTYPE(None, _vp, _dp, _i)
+EXCHANGE_CB = C.CFUNCTYPE(_i, _vp, _i, _i)
+ALLREDUCE_CB = C.CFUNCTYPE(_i, _vp, _dp, _i)
 
 SIGNATURES = {
     "hyteg_host_last_error": (C.c_char_p, []),
@@ -32,6 +32,9 @@ SIGNATURES = {
     "hyteg_host_storage_set_stream": (_i, [_vp, _vp]),
     "hyteg_host_storage_set_batch_max_level": (_i, [_vp, _i]),
     "hyteg_host_storage_set_hooks": (_i, [_vp, EXCHANGE_CB, EXCHANGE_CB, ALLREDUCE_CB, _vp]),
+    "hyteg_host_storage_use_rccl": (_i, [_vp, C.c_char_p]),
+    "hyteg_host_storage_transport_name": (_i, [_vp, C.c_char_p, _i]),
+    "hyteg_host_storage_allreduce_sum": (_i, [_vp, _dp, _i]),
     "hyteg_host_plan_sizes": (_i, [_vp, _i, _i, _ip]),
     "hyteg_host_plan_export": (_i, [_vp, _i, _i, _ip, _ip, _ip, _ip, _ip, _ip, _ip, _ip]),
     "hyteg_host_plan_register_buffers": (_i, [_vp, _i, _i, _vp, _vp]),
@@ -109,9 +112,19 @@ def lib() -> C.CDLL:
     return _lib
 
 
+# an exception raised inside a communication hook (a Python callback called from C++) cannot cross the C frames: the
+# trampoline stores it here and returns non-zero, the host layer aborts the operation, and _ck re-raises it
+_hook_exception = None
+
+
 def _ck(rc, what):
+    global _hook_exception
     if rc != 0:
-        raise HytegHostError(f"{what}: {lib().hyteg_host_last_error().decode(errors='replace')}")
+        msg = f"{what}: {lib().hyteg_host_last_error().decode(errors='replace')}"
+        if _hook_exception is not None:
+            exc, _hook_exception = _hook_exception, None
+            raise HytegHostError(msg) from exc
+        raise HytegHostError(msg)
 
 
 def cell_size(level: int) -> int:
@@ -125,6 +138,7 @@ class Storage:
     def __init__(self, handle):
         self.h = handle
         self._hooks = None
+        self.stream = 0  # raw hipStream_t the host layer launches on (0: the null stream)
         c = (C.c_int * 6)()
         _ck(lib().hyteg_host_storage_counts(self.h, c), "storage_counts")
         self.n_cells, self.n_faces, self.n_edges, self.n_vertices, self.n_local_cells, self.n_ranks = list(c)
@@ -170,15 +184,48 @@ class Storage:
 
     def set_stream(self, stream):
         _ck(lib().hyteg_host_storage_set_stream(self.h, stream), "set_stream")
+        self.stream = int(stream) if stream else 0
 
     def set_hooks(self, exchange_begin, exchange_end, allreduce_sum):
-        exb = EXCHANGE_CB(lambda user, level, cls: exchange_begin(level, cls))
-        exe = EXCHANGE_CB(lambda user, level, cls: exchange_end(level, cls))
-        ar = ALLREDUCE_CB(lambda user, values, n: allreduce_sum(values, n))
+        """hooks(level, key) with key = cls + 2 * dof_kind; an exception in a hook fails the operation that called it"""
+
+        def guard(fn):
+            def call(user, *args):
+                global _hook_exception
+                try:
+                    fn(*args)
+                    return 0
+                except BaseException as e:  # noqa: BLE001 - must not propagate into the C frames
+                    _hook_exception = e
+                    return 1
+            return call
+
+        exb, exe, ar = EXCHANGE_CB(guard(exchange_begin)), EXCHANGE_CB(guard(exchange_end)), ALLREDUCE_CB(guard(allreduce_sum))
         self._hooks = (exb, exe, ar)  # keep alive
         _ck(lib().hyteg_host_storage_set_hooks(self.h, exb, exe, ar, None), "set_hooks")
 
-    def plan(self, level, cls):
+    def use_rccl(self, unique_id: bytes):
+        """RCCL over xGMI issued from the C++ host layer (collective over all ranks; the rank's device must be current).
+        unique_id: the bytes of capi.comm_unique_id() from rank 0, distributed by the caller."""
+        if len(unique_id) != 128:
+            raise ValueError("use_rccl: the unique id has 128 bytes")
+        _ck(lib().hyteg_host_storage_use_rccl(self.h, bytes(unique_id)), "storage_use_rccl")
+
+    def allreduce_sum(self, values):
+        """sum over all ranks of a sequence of floats (through the storage's transport)"""
+        a = np.ascontiguousarray(values, dtype=np.float64).copy()
+        _ck(lib().hyteg_host_storage_allreduce_sum(self.h, a.ctypes.data_as(_dp), len(a)), "storage_allreduce_sum")
+        return a
+
+    @property
+    def transport(self) -> str:
+        buf = C.create_string_buffer(32)
+        _ck(lib().hyteg_host_storage_transport_name(self.h, buf, 32), "storage_transport_name")
+        return buf.value.decode()
+
+    def plan(self, level, key):
+        """exchange plan of (level, key = cls + 2 * dof_kind)"""
+        cls = key
         s = (C.c_int * 5)()
         _ck(lib().hyteg_host_plan_sizes(self.h, level, cls, s), "plan_sizes")
         ng, ne, npeer, ts, tr = list(s)

@@ -120,8 +120,30 @@ HYTEG_HOST_API int hyteg_host_storage_set_batch_max_level( hh_storage_t s, int l
 {
    return guarded( [&] { S( s ).setBatchMaxLevel( level ); } );
 }
-HYTEG_HOST_API int hyteg_host_storage_set_hooks( hh_storage_t s, void ( *exb )( void*, int, int ), void ( *exe )( void*, int, int ),
-                                                 void ( *ar )( void*, double*, int ), void* user )
+HYTEG_HOST_API int hyteg_host_storage_use_rccl( hh_storage_t s, const unsigned char* unique_id )
+{
+   return guarded( [&] {
+      if ( !unique_id )
+         throw std::runtime_error( "storage_use_rccl: null unique id" );
+      S( s ).useRccl( unique_id );
+   } );
+}
+HYTEG_HOST_API int hyteg_host_storage_allreduce_sum( hh_storage_t s, double* values, int n )
+{
+   return guarded( [&] {
+      if ( S( s ).numRanks() > 1 )
+         S( s ).requireTransport( "allreduce_sum" ).allreduceSum( values, n );
+   } );
+}
+HYTEG_HOST_API int hyteg_host_storage_transport_name( hh_storage_t s, char* buf, int buflen )
+{
+   return guarded( [&] {
+      const char* n = S( s ).transport() ? S( s ).transport()->name() : "none";
+      snprintf( buf, (size_t) buflen, "%s", n );
+   } );
+}
+HYTEG_HOST_API int hyteg_host_storage_set_hooks( hh_storage_t s, int ( *exb )( void*, int, int ), int ( *exe )( void*, int, int ),
+                                                 int ( *ar )( void*, double*, int ), void* user )
 {
    return guarded( [&] {
       CommHooks h;
@@ -132,10 +154,11 @@ HYTEG_HOST_API int hyteg_host_storage_set_hooks( hh_storage_t s, void ( *exb )( 
       S( s ).setCommHooks( h );
    } );
 }
-HYTEG_HOST_API int hyteg_host_plan_sizes( hh_storage_t s, int level, int cls, int* sizes )
+// key = cls + 2 * dof_kind (dof_kind 0: vertex DoFs, 1: edge DoFs of P2 functions)
+HYTEG_HOST_API int hyteg_host_plan_sizes( hh_storage_t s, int level, int key, int* sizes )
 {
    return guarded( [&] {
-      const auto& P = S( s ).exchangePlan( level, cls );
+      const auto& P = S( s ).exchangePlan( level, key & 1, key >> 1 );
       sizes[0]      = P.ngroups();
       sizes[1]      = (int) P.entryBuf.size();
       sizes[2]      = (int) P.peers.size();
@@ -143,10 +166,10 @@ HYTEG_HOST_API int hyteg_host_plan_sizes( hh_storage_t s, int level, int cls, in
       sizes[4]      = P.totalRecv();
    } );
 }
-HYTEG_HOST_API int hyteg_host_plan_export( hh_storage_t s, int level, int cls, int* gp, int* eb, int* eo, int* peers, int* sc, int* rc, int* sb, int* so )
+HYTEG_HOST_API int hyteg_host_plan_export( hh_storage_t s, int level, int key, int* gp, int* eb, int* eo, int* peers, int* sc, int* rc, int* sb, int* so )
 {
    return guarded( [&] {
-      const auto& P = S( s ).exchangePlan( level, cls );
+      const auto& P = S( s ).exchangePlan( level, key & 1, key >> 1 );
       std::copy( P.groupPtr.begin(), P.groupPtr.end(), gp );
       std::copy( P.entryBuf.begin(), P.entryBuf.end(), eb );
       std::copy( P.entryOff.begin(), P.entryOff.end(), eo );

@@ -201,14 +201,7 @@ class P1Function
    }
    ValueType dotGlobal( const P1Function< ValueType >& rhs, uint_t level, DoFType flag = All ) const
    {
-      double v = dotLocal( rhs, level, flag );
-      if ( storage_->numRanks() > 1 )
-      {
-         if ( !storage_->hooks().allreduceSum )
-            throw std::runtime_error( "dotGlobal: storage is distributed but no allreduce hook is set" );
-         storage_->hooks().allreduceSum( storage_->hooks().user, &v, 1 );
-      }
-      return v;
+      return storage_->allreduceSum( dotLocal( rhs, level, flag ), "dotGlobal" );
    }
 
    // ---- shared-point exchange (the cell-centric replacement of communicate<> / communicateAdditively<>) ----
@@ -321,64 +314,21 @@ class P1Function
    }
 
  private:
-   // device table [ local cell arrays at `level` ..., receive segment of peer 0, peer 1, ... ]
-   double** basesFor( uint_t level, int cls ) const
+   std::vector< double* > cellArrays( uint_t level ) const
    {
-      const auto& plan = storage_->devicePlan( (int) level, cls );
-      std::vector< double* > host;
+      std::vector< double* > a;
       for ( uint_t c = 0; c < storage_->getNumberOfLocalCells(); ++c )
-         host.push_back( getCellPointer( c, level ) );
-      double* seg = plan.recvBuffer;
-      for ( uint_t s = 0; s < plan.peers.size(); ++s )
-      {
-         host.push_back( seg );
-         seg += plan.recvCount[s];
-      }
-      return storage_->pointerTable( host );
+         a.push_back( getCellPointer( c, level ) );
+      return a;
    }
-
-   // The hooks are called by EVERY rank for every boundary class the flag selects, also by a rank that shares nothing
-   // with anybody in that class: the transport behind them is a collective (all_to_all), and a rank that skipped the
-   // call would dead-lock the others.  The hook itself decides (globally) whether there is anything to exchange.
    void exchangeBegin( uint_t level, DoFType flag ) const
    {
       checkLevel( level );
-      if ( storage_->numRanks() == 1 )
-         return;
-      if ( !storage_->hooks().exchangeBegin || !storage_->hooks().exchangeEnd )
-         throw std::runtime_error( "exchange: storage is distributed but no exchange hooks are set" );
-      for ( int cls = 0; cls < 2; ++cls )
-      {
-         if ( !testFlag( storage_->boundaryTypeOf( cls == 1 ), flag ) )
-            continue;
-         if ( !storage_->exchangePlan( (int) level, cls ).peers.empty() )
-         {
-            const auto& plan  = storage_->devicePlan( (int) level, cls );
-            double**    bases = basesFor( level, cls );
-            hipCheck( hyteg_hip_gather_entries( plan.sendBuffer, bases, plan.dSendBuf, plan.dSendOff, plan.totalSend(), storage_->stream() ),
-                      "exchange: pack" );
-         }
-         storage_->hooks().exchangeBegin( storage_->hooks().user, (int) level, cls );
-      }
+      storage_->sharedExchangeBegin( cellArrays( level ), (int) level, flag, 0 );
    }
    void exchangeEnd( uint_t level, DoFType flag, bool additive ) const
    {
-      for ( int cls = 0; cls < 2; ++cls )
-      {
-         if ( !testFlag( storage_->boundaryTypeOf( cls == 1 ), flag ) )
-            continue;
-         if ( storage_->numRanks() > 1 )
-            storage_->hooks().exchangeEnd( storage_->hooks().user, (int) level, cls );
-         if ( storage_->exchangePlan( (int) level, cls ).ngroups() == 0 )
-            continue;
-         const auto& plan  = storage_->devicePlan( (int) level, cls );
-         double**    bases = basesFor( level, cls );
-         hipCheck( additive ? hyteg_hip_sum_shared( bases, plan.dGroupPtr, plan.dEntryBuf, plan.dEntryOff, plan.ngroups(),
-                                                    (int) storage_->getNumberOfLocalCells(), storage_->stream() )
-                            : hyteg_hip_copy_shared( bases, plan.dGroupPtr, plan.dEntryBuf, plan.dEntryOff, plan.ngroups(),
-                                                     (int) storage_->getNumberOfLocalCells(), storage_->stream() ),
-                   "exchange: reduce" );
-      }
+      storage_->sharedExchangeEnd( cellArrays( level ), (int) level, flag, 0, additive );
    }
 
    std::string                                                           name_;

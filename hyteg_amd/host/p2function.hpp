@@ -43,8 +43,6 @@ class P2Function
       for ( auto& perCell : edge_ )
          for ( double* q : perCell )
             hyteg_hip_free( q );
-      for ( auto& kv : edgeBases_ )
-         hyteg_hip_free( kv.second );
    }
    P2Function( const P2Function& )            = delete;
    P2Function& operator=( const P2Function& ) = delete;
@@ -150,7 +148,10 @@ class P2Function
          sum += v;
       return sum;
    }
-   ValueType dotGlobal( const P2Function< ValueType >& rhs, uint_t level, DoFType flag = All ) const { return dotLocal( rhs, level, flag ); }
+   ValueType dotGlobal( const P2Function< ValueType >& rhs, uint_t level, DoFType flag = All ) const
+   {
+      return storage_->allreduceSum( dotLocal( rhs, level, flag ), "P2Function::dotGlobal" );
+   }
 
    // every copy of a shared edge DoF := sum of all copies (communicateAdditively< Cell, Face / Edge > of the EdgeDoFFunction)
    void sumSharedEdgeCopies( uint_t level, DoFType flag = All ) const
@@ -179,31 +180,12 @@ class P2Function
       for ( uint_t c = 0; c < storage_->getNumberOfLocalCells(); ++c )
          fn( c, storage_->getLocalCell( c ) );
    }
-   // additive (or copy) exchange of the shared edge DoFs held in `arrays` (one edge-DoF array per local cell)
+   // additive (or copy) exchange of the shared edge DoFs held in `arrays` (one edge-DoF array per local cell), over all
+   // ranks: the edge-DoF plans (dofKind 1) of the storage travel through the same transport as the vertex-DoF ones
    void exchangeEdges( const std::vector< double* >& arrays, uint_t level, DoFType flag, bool additive ) const
    {
-      for ( int cls = 0; cls < 2; ++cls )
-      {
-         if ( !testFlag( storage_->boundaryTypeOf( cls == 1 ), flag ) || storage_->exchangePlan( (int) level, cls, 1 ).ngroups() == 0 )
-            continue;
-         const auto& plan = storage_->devicePlan( (int) level, cls, 1 );
-         // device table of the array pointers; cached per (first pointer) because temporaries come and go
-         auto   key = std::make_pair( arrays[0], cls );
-         auto   it  = edgeBases_.find( key );
-         if ( it == edgeBases_.end() )
-         {
-            void* d = nullptr;
-            hipCheck( hyteg_hip_malloc( &d, arrays.size() * sizeof( double* ) ), "edge bases: malloc" );
-            it = edgeBases_.emplace( key, static_cast< double** >( d ) ).first;
-         }
-         hipCheck( hyteg_hip_upload( it->second, arrays.data(), arrays.size() * sizeof( double* ), storage_->stream() ), "edge bases: upload" );
-         hipCheck( hyteg_hip_stream_synchronize( storage_->stream() ), "edge bases: sync" );
-         hipCheck( additive ? hyteg_hip_sum_shared( it->second, plan.dGroupPtr, plan.dEntryBuf, plan.dEntryOff, plan.ngroups(),
-                                                    (int) arrays.size(), storage_->stream() )
-                            : hyteg_hip_copy_shared( it->second, plan.dGroupPtr, plan.dEntryBuf, plan.dEntryOff, plan.ngroups(),
-                                                     (int) arrays.size(), storage_->stream() ),
-                   "edge exchange" );
-      }
+      storage_->sharedExchangeBegin( arrays, (int) level, flag, 1 );
+      storage_->sharedExchangeEnd( arrays, (int) level, flag, 1, additive );
    }
    void vectorOp( int                                                                       op,
                   const std::vector< ValueType >&                                           scalars,
@@ -235,7 +217,6 @@ class P2Function
    uint_t                                                 minLevel_, maxLevel_;
    P1Function< ValueType >                                vertexDoFFunction_;
    std::vector< std::vector< double* > >                  edge_; // [local cell][level - minLevel]
-   mutable std::map< std::pair< double*, int >, double** > edgeBases_;
 };
 
 } // namespace hyteg

@@ -3,6 +3,7 @@
 // communication hooks (src/hyteg/primitivestorage/, src/hyteg/communication/BufferedCommunication.cpp)
 #pragma once
 
+#include "comm.hpp"
 #include "mesh.hpp"
 
 namespace hyteg {
@@ -29,18 +30,6 @@ struct MacroPrimitive
    std::vector< int > cells; // adjacent global cell ids, ascending
    bool               onBoundary = false;
    uint_t             getNumNeighborCells() const { return cells.size(); }
-};
-
-// callbacks for storages distributed over several ranks (set by the embedding application; see hyteg_amd/host.py)
-struct CommHooks
-{
-   // all-to-all of the packed partial values of one (level, boundary class); buffers were registered before.
-   // Begin may return before the data has arrived (so that interior kernels overlap the transfer); End waits.
-   void ( *exchangeBegin )( void* user, int level, int cls ) = nullptr;
-   void ( *exchangeEnd )( void* user, int level, int cls )   = nullptr;
-   // in-place sum over all ranks of n doubles in host memory (walberla::mpi::allReduceInplace, VertexDoFFunction.cpp:1717)
-   void ( *allreduceSum )( void* user, double* values, int n ) = nullptr;
-   void* user                                                   = nullptr;
 };
 
 static const int kCellFaceVerts[4][3] = { { 0, 1, 2 }, { 0, 1, 3 }, { 0, 2, 3 }, { 1, 2, 3 } };
@@ -264,8 +253,82 @@ class PrimitiveStorage
 
    void              setStream( hyteg_hip_stream_t s ) { stream_ = s; }
    hyteg_hip_stream_t stream() const { return stream_; }
-   void              setCommHooks( const CommHooks& h ) { hooks_ = h; }
-   const CommHooks&  hooks() const { return hooks_; }
+   // ---- transport of the shared-point exchange (storages distributed over several ranks) ----
+   void setCommHooks( const CommHooks& h ) { transport_ = std::make_shared< HookTransport >( h ); }
+   void setTransport( std::shared_ptr< Transport > t ) { transport_ = std::move( t ); }
+   // RCCL over xGMI issued from this layer; uniqueId: HYTEG_HIP_COMM_ID_BYTES bytes created by rank 0
+   // (hyteg_hip_comm_unique_id) and distributed by the application.  Collective over all ranks.
+   void       useRccl( const unsigned char* uniqueId ) { transport_ = std::make_shared< RcclTransport >( nranks_, rank_, uniqueId ); }
+   Transport* transport() const { return transport_.get(); }
+   Transport& requireTransport( const char* what ) const
+   {
+      if ( !transport_ )
+         throw std::runtime_error( std::string( what ) + ": storage is distributed but no transport (RCCL or hooks) is set" );
+      return *transport_;
+   }
+   double allreduceSum( double v, const char* what ) const
+   {
+      if ( nranks_ > 1 )
+         requireTransport( what ).allreduceSum( &v, 1 );
+      return v;
+   }
+
+   // Shared-point exchange of the arrays `arrays` (one device array per local cell: the vertex-DoF or the edge-DoF arrays
+   // of one function at `level`): pack the partial values other ranks need + start the transfer / wait + reduce local and
+   // received copies in a fixed order (additive: every copy := sum of all copies, VertexDoFAdditivePackInfo.hpp:676-745;
+   // otherwise every copy := the copy of the lowest-numbered neighbour cell).  Kernels that do not touch shared points
+   // may be enqueued between Begin and End: they overlap the transfer.
+   void sharedExchangeBegin( const std::vector< double* >& arrays, int level, DoFType flag, int dofKind ) const
+   {
+      if ( nranks_ == 1 )
+         return;
+      Transport& T = requireTransport( "exchange" );
+      for ( int cls = 0; cls < 2; ++cls )
+      {
+         if ( !testFlag( boundaryTypeOf( cls == 1 ), flag ) )
+            continue;
+         const ExchangePlan& host = exchangePlan( level, cls, dofKind );
+         if ( host.peers.empty() && !T.collective() )
+            continue;
+         const ExchangePlan& plan = devicePlan( level, cls, dofKind );
+         if ( !plan.peers.empty() )
+            hipCheck( hyteg_hip_gather_entries( plan.sendBuffer, basesTable( arrays, plan ), plan.dSendBuf, plan.dSendOff, plan.totalSend(), stream_ ),
+                      "exchange: pack" );
+         T.exchangeBegin( plan, level, cls + 2 * dofKind, stream_ );
+      }
+   }
+   void sharedExchangeEnd( const std::vector< double* >& arrays, int level, DoFType flag, int dofKind, bool additive ) const
+   {
+      for ( int cls = 0; cls < 2; ++cls )
+      {
+         if ( !testFlag( boundaryTypeOf( cls == 1 ), flag ) )
+            continue;
+         const ExchangePlan& host = exchangePlan( level, cls, dofKind );
+         if ( nranks_ > 1 && ( !host.peers.empty() || requireTransport( "exchange" ).collective() ) )
+            transport_->exchangeEnd( devicePlan( level, cls, dofKind ), level, cls + 2 * dofKind, stream_ );
+         if ( host.ngroups() == 0 )
+            continue;
+         const ExchangePlan& plan  = devicePlan( level, cls, dofKind );
+         double**            bases = basesTable( arrays, plan );
+         hipCheck( additive ? hyteg_hip_sum_shared( bases, plan.dGroupPtr, plan.dEntryBuf, plan.dEntryOff, plan.ngroups(),
+                                                    (int) arrays.size(), stream_ )
+                            : hyteg_hip_copy_shared( bases, plan.dGroupPtr, plan.dEntryBuf, plan.dEntryOff, plan.ngroups(),
+                                                     (int) arrays.size(), stream_ ),
+                   "exchange: reduce" );
+      }
+   }
+   // device table [ local cell arrays ..., receive segment of peer 0, peer 1, ... ] (cached by content)
+   double** basesTable( const std::vector< double* >& arrays, const ExchangePlan& plan ) const
+   {
+      std::vector< double* > host( arrays );
+      double*                seg = plan.recvBuffer;
+      for ( uint_t s = 0; s < plan.peers.size(); ++s )
+      {
+         host.push_back( seg );
+         seg += plan.recvCount[s];
+      }
+      return pointerTable( host );
+   }
 
    // pool of scratch device arrays keyed by size, so that operators can use temporaries without hipMalloc/hipFree
    // in the hot path (the role of hyteg::getTemporaryFunction, src/hyteg/memory/TempFunctionManager.hpp)
@@ -324,29 +387,7 @@ class PrimitiveStorage
    // two neighbour cells, at least one of them local, is a group; its entries are its copies in ascending global
    // cell order.  cls 0: primitives in the interior of the domain, cls 1: primitives on the domain boundary.
    // ---------------------------------------------------------------------------------------------------
-   struct ExchangePlan
-   {
-      // host copies
-      std::vector< int > groupPtr, entryBuf, entryOff; // entryBuf < nLocal: local cell; else nLocal + peer slot
-      std::vector< int > peers;                        // ranks we exchange with, ascending
-      std::vector< int > sendCount, recvCount;         // per peer
-      std::vector< int > sendBuf, sendOff;             // concatenated per peer: (local cell, offset)
-      // device copies
-      int *dGroupPtr = nullptr, *dEntryBuf = nullptr, *dEntryOff = nullptr, *dSendBuf = nullptr, *dSendOff = nullptr;
-      // communication buffers (device), registered by the application for multi-rank runs or allocated here
-      double *sendBuffer = nullptr, *recvBuffer = nullptr;
-      bool    ownsBuffers = false;
-      bool    onDevice    = false;
-      int     ngroups() const { return (int) groupPtr.size() - 1; }
-      int     totalSend() const { return (int) sendBuf.size(); }
-      int     totalRecv() const
-      {
-         int t = 0;
-         for ( int r : recvCount )
-            t += r;
-         return t;
-      }
-   };
+   using ExchangePlan = hyteg::ExchangePlan;
 
    // host part of the plan (no GPU needed)
    // dofKind 0: vertex DoFs (P1 arrays); 1: edge DoFs (the edge-DoF arrays of P2 functions)
@@ -383,9 +424,9 @@ class PrimitiveStorage
       return P;
    }
    // multi-rank: the application owns the communication buffers (e.g. torch tensors) and registers them here
-   void registerCommBuffers( int level, int cls, double* send, double* recv ) const
+   void registerCommBuffers( int level, int key, double* send, double* recv ) const
    {
-      auto& p = const_cast< ExchangePlan& >( exchangePlan( level, cls ) );
+      auto& p = const_cast< ExchangePlan& >( exchangePlan( level, key & 1, key >> 1 ) ); // key = cls + 2 * dofKind
       if ( p.ownsBuffers )
       {
          hyteg_hip_free( p.sendBuffer );
@@ -619,7 +660,7 @@ class PrimitiveStorage
    std::vector< int >                                      localCells_;
    DoFType                                                 boundaryType_ = DirichletBoundary;
    hyteg_hip_stream_t                                      stream_       = nullptr;
-   CommHooks                                               hooks_;
+   std::shared_ptr< Transport >                            transport_;
    mutable void *                                          dotResult_ = nullptr, *dotWorkspace_ = nullptr;
    mutable std::map< size_t, std::vector< double* > >      scratchFree_;
    mutable std::vector< void* >                            scratchAll_;

@@ -613,6 +613,44 @@ HYTEG_HIP_API int hyteg_hip_p1_apply_face3d( double*            dst_face,
                                              int                update,
                                              hyteg_hip_stream_t stream );
 
+/* ---- events and the neighbour exchange over RCCL (xGMI) --------------------------------------------------------
+ * One process per GPU.  Replaces, on this path, what the reference does through waLBerla's BufferSystem over MPI:
+ *   src/hyteg/communication/BufferedCommunication.cpp:181-470   start/endCommunication: pack, Isend/Irecv, wait, unpack
+ *   src/hyteg/p1functionspace/VertexDoFAdditivePackInfo.hpp:676-745   payloads of the additive exchange
+ *   src/hyteg/p1functionspace/VertexDoFFunction.cpp:1710-1717   dotGlobal: allReduceInplace( SUM ) of one scalar
+ * The message pattern is sparse neighbour point-to-point: hyteg_hip_comm_exchange is ONE group of ncclSend / ncclRecv
+ * pairs (one per peer rank) enqueued on `stream`, no host synchronisation, no staging; the caller orders it against its
+ * pack / reduce kernels with events.  librccl is resolved at run time (a copy the process already holds -- PyTorch
+ * ships and loads its own -- is reused; HYTEG_HIP_RCCL_LIB overrides the search). */
+typedef void* hyteg_hip_event_t;
+HYTEG_HIP_API int hyteg_hip_event_create( hyteg_hip_event_t* event );
+HYTEG_HIP_API int hyteg_hip_event_destroy( hyteg_hip_event_t event );
+HYTEG_HIP_API int hyteg_hip_event_record( hyteg_hip_event_t event, hyteg_hip_stream_t stream );
+HYTEG_HIP_API int hyteg_hip_stream_wait_event( hyteg_hip_stream_t stream, hyteg_hip_event_t event );
+
+#define HYTEG_HIP_COMM_ID_BYTES 128 /* sizeof( ncclUniqueId ) */
+typedef void* hyteg_hip_comm_t;
+/* HYTEG_HIP_OK if librccl could be resolved; origin (optional) receives where it came from and its version code */
+HYTEG_HIP_API int hyteg_hip_comm_available( char* origin, size_t buflen );
+/* rank 0 creates the id and distributes its HYTEG_HIP_COMM_ID_BYTES bytes to all ranks by whatever means the
+ * application has (MPI_Bcast in HyTeG, a torch.distributed store in bench.py) */
+HYTEG_HIP_API int hyteg_hip_comm_unique_id( unsigned char* id );
+/* collective over all ranks; binds the communicator to the calling thread's current device */
+HYTEG_HIP_API int hyteg_hip_comm_create( hyteg_hip_comm_t* comm, int nranks, int rank, const unsigned char* id );
+HYTEG_HIP_API int hyteg_hip_comm_destroy( hyteg_hip_comm_t comm );
+/* send[ sum of send_count[0..k) ... ) goes to peers[k], recv[ sum of recv_count[0..k) ... ) comes from peers[k]
+ * (device buffers, counts in doubles, host arrays of length npeers); stream-ordered */
+HYTEG_HIP_API int hyteg_hip_comm_exchange( hyteg_hip_comm_t   comm,
+                                           int                npeers,
+                                           const int*         peers,
+                                           const double*      send,
+                                           const int*         send_count,
+                                           double*            recv,
+                                           const int*         recv_count,
+                                           hyteg_hip_stream_t stream );
+/* in-place sum over all ranks of n doubles in device memory; stream-ordered */
+HYTEG_HIP_API int hyteg_hip_comm_allreduce_sum( hyteg_hip_comm_t comm, double* values, int n, hyteg_hip_stream_t stream );
+
 #ifdef __cplusplus
 }
 #endif

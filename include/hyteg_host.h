@@ -44,17 +44,29 @@ HYTEG_HOST_API int hyteg_host_storage_set_stream( hh_storage_t s, void* stream )
 /* levels <= `level` use the batched kernels (one launch for all local cells, inner and boundary points together) when the
  * rank owns more than one cell; -1 disables batching.  Default 6, or the environment variable HYTEG_AMD_BATCH_MAX_LEVEL. */
 HYTEG_HOST_API int hyteg_host_storage_set_batch_max_level( hh_storage_t s, int level );
-/* multi-rank hooks: exchange_begin( user, level, cls ) starts the all-to-all of the packed send buffer (may return
- * before completion), exchange_end( user, level, cls ) waits for it; allreduce_sum( user, values, n ) */
-HYTEG_HOST_API int hyteg_host_storage_set_hooks( hh_storage_t s, void ( *exchange_begin )( void*, int, int ),
-                                                 void ( *exchange_end )( void*, int, int ),
-                                                 void ( *allreduce_sum )( void*, double*, int ), void* user );
-/* exchange plan of (level, cls) -- host data, works without a GPU.
- * sizes[0..4] = ngroups, nentries, npeers, total_send, total_recv */
-HYTEG_HOST_API int hyteg_host_plan_sizes( hh_storage_t s, int level, int cls, int* sizes );
-HYTEG_HOST_API int hyteg_host_plan_export( hh_storage_t s, int level, int cls, int* group_ptr, int* entry_buf, int* entry_off,
+/* Transport of the shared-point exchange of a storage distributed over several ranks (one process per GPU).
+ * (a) RCCL over xGMI issued from the host layer itself: neighbour send/recv groups on a communication stream, ordered
+ *     against the compute stream with events; all-reduce of dot products.  unique_id: HYTEG_HIP_COMM_ID_BYTES bytes from
+ *     hyteg_hip_comm_unique_id on rank 0, distributed to all ranks by the application; collective over all ranks; call
+ *     it with the rank's device current.  Semantics: BufferedCommunication.cpp:181-470 of the reference.
+ * (b) hooks: exchange_begin( user, level, key ) starts an all-to-all of the registered send buffer of plan
+ *     key = cls + 2 * dof_kind (may return before completion), exchange_end( user, level, key ) waits for it,
+ *     allreduce_sum( user, values, n ) sums host values in place.  A hook returns 0 on success; any other value makes
+ *     the calling operation fail (the host layer never reduces a receive buffer whose transfer failed). */
+HYTEG_HOST_API int hyteg_host_storage_use_rccl( hh_storage_t s, const unsigned char* unique_id );
+HYTEG_HOST_API int hyteg_host_storage_transport_name( hh_storage_t s, char* buf, int buflen );
+/* in-place sum over all ranks of n doubles in host memory through the storage's transport (no-op on one rank):
+ * walberla::mpi::allReduceInplace( ..., SUM ) of the reference's norms and dot products */
+HYTEG_HOST_API int hyteg_host_storage_allreduce_sum( hh_storage_t s, double* values, int n );
+HYTEG_HOST_API int hyteg_host_storage_set_hooks( hh_storage_t s, int ( *exchange_begin )( void*, int, int ),
+                                                 int ( *exchange_end )( void*, int, int ),
+                                                 int ( *allreduce_sum )( void*, double*, int ), void* user );
+/* exchange plan of (level, key = cls + 2 * dof_kind; dof_kind 0: vertex DoFs, 1: edge DoFs of P2 functions) -- host
+ * data, works without a GPU.  sizes[0..4] = ngroups, nentries, npeers, total_send, total_recv */
+HYTEG_HOST_API int hyteg_host_plan_sizes( hh_storage_t s, int level, int key, int* sizes );
+HYTEG_HOST_API int hyteg_host_plan_export( hh_storage_t s, int level, int key, int* group_ptr, int* entry_buf, int* entry_off,
                                            int* peers, int* send_count, int* recv_count, int* send_buf, int* send_off );
-HYTEG_HOST_API int hyteg_host_plan_register_buffers( hh_storage_t s, int level, int cls, double* send_dev, double* recv_dev );
+HYTEG_HOST_API int hyteg_host_plan_register_buffers( hh_storage_t s, int level, int key, double* send_dev, double* recv_dev );
 
 /* ---- P1Function<double> ---- */
 HYTEG_HOST_API int hyteg_host_function_create( hh_storage_t s, const char* name, int min_level, int max_level, hh_function_t* out );

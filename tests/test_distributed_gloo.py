@@ -118,3 +118,37 @@ def test_exchange_over_gloo_reproduces_the_single_process_sums(world):
             assert np.array_equal(arr, ref[gid]), f"rank {rank} cell {gid}"  # bit for bit: fixed summation order
             seen += 1
     assert seen == 8
+
+
+def test_an_exception_in_a_hook_fails_the_operation_that_called_it():
+    """a Python exception inside a ctypes callback used to be printed and dropped, and the host layer went
+    on to reduce stale receive buffers.  Hooks return a status now: the C++ layer throws, and the binding re-raises with
+    the original exception as its cause."""
+    sys.path.insert(0, str(ROOT))
+    from hyteg_amd import host
+
+    st = host.Storage.from_gmsh(MESH, 0, 2)  # rank 0 of 2: distributed, so global sums go through the transport
+    with pytest.raises(host.HytegHostError, match="no transport"):
+        st.allreduce_sum([1.0])
+
+    calls = []
+
+    def bad_allreduce(values, n):
+        calls.append(n)
+        raise RuntimeError("link down")
+
+    st.set_hooks(lambda level, key: None, lambda level, key: None, bad_allreduce)
+    assert st.transport == "hooks"
+    with pytest.raises(host.HytegHostError, match="all-reduce hook failed") as ei:
+        st.allreduce_sum([1.0, 2.0])
+    assert calls == [2]
+    assert isinstance(ei.value.__cause__, RuntimeError) and "link down" in str(ei.value.__cause__)
+
+    # a hook that works: values are summed in place (here: doubled, standing in for a second rank)
+    def ok_allreduce(values, n):
+        for k in range(n):
+            values[k] *= 2.0
+
+    st.set_hooks(lambda level, key: None, lambda level, key: None, ok_allreduce)
+    assert list(st.allreduce_sum([1.0, 2.5])) == [2.0, 5.0]
+    st.close()
