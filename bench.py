@@ -216,8 +216,8 @@ def main():
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels are launched on
 
-    # the same K steps once more, every step between its own pair of events: the median is the launch duration without
-    # the one-off gap in front of the region's first kernel (20 steps cannot average that out)
+    # the same K steps once more, every step between its own pair of events (reported beside the region mean: an upper bound,
+    # the events themselves cost ~2.4 us each between two kernels)
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     evs[0].record(stream)
     for k in range(args.steps):
@@ -234,8 +234,7 @@ def main():
 
     if rank == 0:
         w = laplace.stencils(0, level)[0]
-        mean_us = dev_ms * 1e3 / args.steps  # events around the whole timed region / K
-        launch_us = median_us                # median of the per-step event pairs
+        launch_us = dev_ms * 1e3 / args.steps  # one event pair around the whole timed region / K
         cell_inner = capi.cell_inner_size(level)
         algo_bytes = 16 * cell_inner  # 8 B compulsory src read + 8 B dst write per DoF-update, one cell
         achieved = algo_bytes / (launch_us * 1e-6) / 1e9
@@ -277,7 +276,10 @@ def main():
                 "pre_warm_applies": pre_warm,
                 "mesh_note": "1/2/4/8 GPUs run tet_1el / pyramid_2el / pyramid_4el / regular_octahedron_8el (one macro-cell per GPU);"
                              " they stand in for the MultigridStudies cube, whose 6 or 24 cells do not give one cell per GPU",
-                "halo_exchange": ("RCCL all_to_all of shared face/edge/vertex shares, overlapped with the interior kernel"
+                "halo_exchange": (f"transport '{ctx.transport}': "
+                                  + ("ncclSend/ncclRecv groups issued by the C++ host layer on a communication stream (RCCL over xGMI), "
+                                     "event-ordered, overlapped with the interior kernel" if ctx.transport == "rccl" else
+                                     "torch.distributed all_to_all hooks (rehearsal transport)")
                                   if world > 1 else None),
                 "device": capi.device_name(),
             },
@@ -291,13 +293,15 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_note,
                 "launch_us": launch_us,
-                "launch_us_mean_over_timed_region": mean_us,
-                "launch_us_min": per_step_us[0],
+                "per_step_event_median_us": median_us,
+                "per_step_event_min_us": per_step_us[0],
                 "algorithmic_bytes_per_launch": algo_bytes,
-                "note": "achieved = algorithmic bytes of one cell's interior kernel / launch_us; launch_us = median over the K steps"
-                        " of the time between HIP events recorded on the launch stream around each apply (N=1: one kernel per"
-                        " apply), taken in a second pass of the same K steps right after the wall-clock region;"
-                        " launch_us_mean_over_timed_region = one event pair around the wall-clock region / K",
+                "note": "achieved = algorithmic bytes of one cell's interior kernel / launch_us; launch_us = time between two HIP"
+                        " events recorded on the launch stream around the K applies of the wall-clock region / K (N=1: one kernel"
+                        " per apply; every ring pair was touched before, so also 20 steps see no first accesses)."
+                        " per_step_event_median_us: the same K steps once more with an event pair around EACH apply -- an event"
+                        " between two kernels costs ~2.4 us on this device (12.1 vs 9.7 us), so it bounds the launch duration"
+                        " from above and is not used for the roofline figure",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -176,6 +176,44 @@ def comm_unique_id() -> bytes:
     return buf.raw
 
 
+def comm_create(nranks: int, rank: int, unique_id: bytes) -> int:
+    h = _vp()
+    check(lib().hyteg_hip_comm_create(C.byref(h), nranks, rank, bytes(unique_id)), "comm_create")
+    return h.value
+
+
+def comm_destroy(comm) -> None:
+    check(lib().hyteg_hip_comm_destroy(comm), "comm_destroy")
+
+
+def comm_exchange(comm, peers, send_ptr, send_count, recv_ptr, recv_count, stream=0) -> None:
+    n = len(peers)
+    ia = lambda v: (C.c_int * max(n, 1))(*[int(x) for x in v])  # noqa: E731
+    check(lib().hyteg_hip_comm_exchange(comm, n, ia(peers), send_ptr, ia(send_count), recv_ptr, ia(recv_count), stream), "comm_exchange")
+
+
+def comm_allreduce_sum(comm, dev_ptr, n, stream=0) -> None:
+    check(lib().hyteg_hip_comm_allreduce_sum(comm, dev_ptr, n, stream), "comm_allreduce_sum")
+
+
+def event_create() -> int:
+    h = _vp()
+    check(lib().hyteg_hip_event_create(C.byref(h)), "event_create")
+    return h.value
+
+
+def event_destroy(ev) -> None:
+    check(lib().hyteg_hip_event_destroy(ev), "event_destroy")
+
+
+def event_record(ev, stream=0) -> None:
+    check(lib().hyteg_hip_event_record(ev, stream), "event_record")
+
+
+def stream_wait_event(stream, ev) -> None:
+    check(lib().hyteg_hip_stream_wait_event(stream, ev), "stream_wait_event")
+
+
 def p1_apply_kernel_name(level, update=REPLACE) -> str:
     buf = C.create_string_buffer(256)
     check(lib().hyteg_hip_p1_apply_kernel_name(level, update, buf, 256), "p1_apply_kernel_name")

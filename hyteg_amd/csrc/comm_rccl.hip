@@ -229,7 +229,7 @@ HYTEG_HIP_API int hyteg_hip_comm_exchange( hyteg_hip_comm_t   comm,
    HH_CHECK_RCCL( g_rccl.GroupStart() );
    for ( int k = 0; k < npeers; ++k )
    {
-      HH_REQUIRE( peers[k] >= 0 && peers[k] < c->nranks && peers[k] != c->rank, "comm_exchange: bad peer rank" );
+      HH_REQUIRE( peers[k] >= 0 && peers[k] < c->nranks, "comm_exchange: bad peer rank" ); // own rank: allowed (loop-back)
       if ( send_count[k] > 0 )
          HH_CHECK_RCCL( g_rccl.Send( send + so, (size_t) send_count[k], ncclDouble, peers[k], c->comm, as_stream( stream ) ) );
       if ( recv_count[k] > 0 )

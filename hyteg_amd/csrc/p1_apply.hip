@@ -19,7 +19,8 @@ inline int   brick_lz( int level ) { return level >= 8 ? 8 : 4; }
 // developer switches (measurement only).  HYTEG_HIP_APPLY_DECODE=1: bricks decoded from the task index instead of read from
 // the table (measured SLOWER: 12.0 vs 10.0 us at level 8 -- ~200 scalar instructions per wave on the CU's one scalar
 // unit cost more than the table's round trip; profiles/r02_apply_wave_trace_table_vs_decode.txt).
-// HYTEG_HIP_APPLY_PFD=2: loads run two slices ahead of the arithmetic instead of one.
+// HYTEG_HIP_APPLY_PFD=1: loads run one slice ahead of the arithmetic instead of two (default 2: 9.45 vs 9.6-9.7 us at level 8
+// in three A/B pairs of bench.py on one box, gpurun_out r02e; round 1 had measured no difference).
 inline bool apply_decode_enabled()
 {
    static const bool on = [] {
@@ -32,7 +33,7 @@ inline int apply_prefetch_distance()
 {
    static const int pfd = [] {
       const char* e = getenv( "HYTEG_HIP_APPLY_PFD" );
-      return ( e && e[0] == '2' ) ? 2 : 1;
+      return ( e && e[0] == '1' ) ? 1 : 2;
    }();
    return pfd;
 }
@@ -72,10 +73,10 @@ int launch_zmarch_lz( double* dst, const double* src, const double* rhs, const d
    const dim3 grid( nblocks ), block( 64 * kZMarchWavesPerBlock );
    if ( bt.decodable && apply_decode_enabled() )
       hipLaunchKernelGGL( ( p1_apply_zmarch_kernel< MODE, kBrickNY, LZ, kExAux, true > ), grid, block, 0, stream, A );
-   else if ( apply_prefetch_distance() == 2 )
-      hipLaunchKernelGGL( ( p1_apply_zmarch_kernel< MODE, kBrickNY, LZ, kExAux, false, 2 > ), grid, block, 0, stream, A );
+   else if ( apply_prefetch_distance() == 1 )
+      hipLaunchKernelGGL( ( p1_apply_zmarch_kernel< MODE, kBrickNY, LZ, kExAux, false, 1 > ), grid, block, 0, stream, A );
    else
-      hipLaunchKernelGGL( ( p1_apply_zmarch_kernel< MODE, kBrickNY, LZ, kExAux, false > ), grid, block, 0, stream, A );
+      hipLaunchKernelGGL( ( p1_apply_zmarch_kernel< MODE, kBrickNY, LZ, kExAux, false, 2 > ), grid, block, 0, stream, A );
    HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;
 }

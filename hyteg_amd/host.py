@@ -50,6 +50,20 @@ SIGNATURES = {
     "hyteg_host_function_dot": (_i, [_vp, _vp, _i, _i, _i, _dp]),
     "hyteg_host_function_sum_shared": (_i, [_vp, _i, _i]),
     "hyteg_host_function_sync_shared": (_i, [_vp, _i, _i]),
+    "hyteg_host_function_set_all_inner": (_i, [_vp, _i]),
+    "hyteg_host_stokes_function_create": (_i, [_vp, C.c_char_p, _i, _i, C.POINTER(_vp)]),
+    "hyteg_host_stokes_function_destroy": (_i, [_vp]),
+    "hyteg_host_stokes_function_component": (_i, [_vp, _i, C.POINTER(_vp)]),
+    "hyteg_host_stokes_function_assign": (_i, [_vp, _i, _dp, C.POINTER(_vp), _i, _i]),
+    "hyteg_host_stokes_function_dot": (_i, [_vp, _vp, _i, _i, _dp]),
+    "hyteg_host_project_mean": (_i, [_vp, _i]),
+    "hyteg_host_stokes_operator_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "hyteg_host_stokes_operator_destroy": (_i, [_vp]),
+    "hyteg_host_stokes_operator_apply": (_i, [_vp, _vp, _vp, _i, _i]),
+    "hyteg_host_stokes_uzawa_create": (_i, [_vp, _i, _i, _d, _i, _i, _d, C.POINTER(_vp)]),
+    "hyteg_host_stokes_gmg_create": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "hyteg_host_stokes_solver_solve": (_i, [_vp, _vp, _vp, _vp, _i]),
+    "hyteg_host_stokes_solver_destroy": (_i, [_vp]),
     "hyteg_host_operator_create": (_i, [_vp, _i, _i, _i, C.POINTER(_vp)]),
     "hyteg_host_operator_destroy": (_i, [_vp]),
     "hyteg_host_operator_stencils": (_i, [_vp, _i, _i, _dp, _dp]),
@@ -307,14 +321,22 @@ class P1Function:
     def sync_shared(self, level, flag=All):
         _ck(lib().hyteg_host_function_sync_shared(self.h, level, flag), "sync_shared")
 
+    def set_all_inner(self, on=True):
+        """BoundaryCondition::createAllInnerBC(): every point of this function counts as Inner (Stokes pressure)"""
+        _ck(lib().hyteg_host_function_set_all_inner(self.h, int(on)), "function_set_all_inner")
+
     def close(self):
         if self.h and not self._borrowed:
             lib().hyteg_host_function_destroy(self.h)
         self.h = None
 
 
+FORM_LAPLACE, FORM_MASS, FORM_DIV_X, FORM_DIV_Y, FORM_DIV_Z, FORM_DIVT_X, FORM_DIVT_Y, FORM_DIVT_Z, FORM_PSPG = range(9)
+
+
 class P1ConstantOperator:
-    """hyteg::P1ConstantLaplaceOperator (form=0) / P1ConstantMassOperator (form=1)"""
+    """hyteg::P1ConstantOperator< Form >: form = FORM_LAPLACE (P1ConstantLaplaceOperator), FORM_MASS, FORM_DIV_X/Y/Z
+    (P1Div{x,y,z}Operator), FORM_DIVT_X/Y/Z, FORM_PSPG"""
 
     def __init__(self, storage: Storage, min_level: int, max_level: int, form: int = 0):
         self.storage = storage
@@ -420,6 +442,91 @@ class Solver:
 
 
 # ---- P2 on a single macro-cell (first version) ----
+class P1StokesFunction:
+    """hyteg::P1StokesFunction<double>: velocity components u, v, w (boundary types of the storage) and pressure p (all inner)"""
+
+    def __init__(self, storage: Storage, name: str, min_level: int, max_level: int):
+        self.storage, self.min_level, self.max_level = storage, min_level, max_level
+        h = _vp()
+        _ck(lib().hyteg_host_stokes_function_create(storage.h, name.encode(), min_level, max_level, C.byref(h)), "stokes_function_create")
+        self.h = h
+        self.components = []
+        for k in range(4):
+            c = _vp()
+            _ck(lib().hyteg_host_stokes_function_component(self.h, k, C.byref(c)), "stokes_function_component")
+            self.components.append(P1Function(storage, "", min_level, max_level, _borrowed=c))
+        self.u, self.v, self.w, self.p = self.components
+        self.uvw = self.components[:3]
+
+    def assign(self, scalars, funcs, level, flag=All):
+        sc = np.ascontiguousarray(scalars, dtype=np.float64)
+        arr = (_vp * len(funcs))(*[f.h for f in funcs])
+        _ck(lib().hyteg_host_stokes_function_assign(self.h, len(funcs), sc.ctypes.data_as(_dp), arr, level, flag), "stokes_function_assign")
+
+    def dot(self, other, level, flag=All):
+        out = _d()
+        _ck(lib().hyteg_host_stokes_function_dot(self.h, other.h, level, flag, C.byref(out)), "stokes_function_dot")
+        return out.value
+
+    def close(self):
+        if self.h:
+            lib().hyteg_host_stokes_function_destroy(self.h)
+        self.h = None
+
+
+def project_mean(pressure: P1Function, level: int):
+    """hyteg::vertexdof::projectMean"""
+    _ck(lib().hyteg_host_project_mean(pressure.h, level), "project_mean")
+
+
+class P1P1StokesOperator:
+    """hyteg::P1P1StokesOperator: vector Laplace + divT + div + PSPG"""
+
+    def __init__(self, storage: Storage, min_level: int, max_level: int):
+        self.storage = storage
+        h = _vp()
+        _ck(lib().hyteg_host_stokes_operator_create(storage.h, min_level, max_level, C.byref(h)), "stokes_operator_create")
+        self.h = h
+
+    def apply(self, src: P1StokesFunction, dst: P1StokesFunction, level, flag):
+        _ck(lib().hyteg_host_stokes_operator_apply(self.h, src.h, dst.h, level, flag), "stokes_operator_apply")
+
+    def close(self):
+        if self.h:
+            lib().hyteg_host_stokes_operator_destroy(self.h)
+        self.h = None
+
+
+class StokesSolver:
+    def __init__(self, handle, keep=()):
+        self.h = handle
+        self._keep = keep
+
+    @classmethod
+    def uzawa(cls, storage, min_level, max_level, relax, velocity_iterations=2, velocity_smoother=GAUSS_SEIDEL, velocity_relax=1.0):
+        """hyteg::UzawaSmoother< P1P1StokesOperator > over StokesVelocityBlockBlockDiagonalPreconditioner( scalar smoother )"""
+        h = _vp()
+        _ck(lib().hyteg_host_stokes_uzawa_create(storage.h, min_level, max_level, relax, velocity_iterations, velocity_smoother,
+                                                 velocity_relax, C.byref(h)), "stokes_uzawa_create")
+        return cls(h)
+
+    @classmethod
+    def gmg(cls, storage, smoother, min_level, max_level, pre=3, post=3, increment=0, project_mean_after_restriction=True):
+        """hyteg::GeometricMultigridSolver< P1P1StokesOperator > with a dense direct solve on min_level"""
+        h = _vp()
+        _ck(lib().hyteg_host_stokes_gmg_create(storage.h, smoother.h, min_level, max_level, pre, post, increment,
+                                               int(project_mean_after_restriction), C.byref(h)), "stokes_gmg_create")
+        return cls(h, keep=(smoother,))
+
+    def solve(self, op: P1P1StokesOperator, x: P1StokesFunction, b: P1StokesFunction, level: int):
+        _ck(lib().hyteg_host_stokes_solver_solve(self.h, op.h, x.h, b.h, level), "stokes_solver_solve")
+
+    def close(self):
+        if self.h:
+            lib().hyteg_host_stokes_solver_destroy(self.h)
+        self.h = None
+
+
 class P2Function:
     """hyteg::P2Function<double>: vertex DoFs (the P1 cell array) + edge DoFs (EdgeDoFIndexing.hpp layout)"""
 

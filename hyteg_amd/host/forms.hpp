@@ -50,6 +50,71 @@ struct P1LaplaceForm
          row[j] = vol6 * ( g[0][0] * g[j][0] + g[0][1] * g[j][1] + g[0][2] * g[j][2] );
    }
 };
+// barycentric gradients g[4][3] and volume of a tetrahedron
+inline double tetGradients( const std::array< Point3D, 4 >& c, double g[4][3] )
+{
+   double J[3][3];
+   for ( int r = 0; r < 3; ++r )
+      for ( int k = 0; k < 3; ++k )
+         J[r][k] = c[k + 1][r] - c[0][r];
+   const double det = det3( J );
+   double       Ji[3][3];
+   Ji[0][0] = ( J[1][1] * J[2][2] - J[1][2] * J[2][1] ) / det;
+   Ji[0][1] = ( J[0][2] * J[2][1] - J[0][1] * J[2][2] ) / det;
+   Ji[0][2] = ( J[0][1] * J[1][2] - J[0][2] * J[1][1] ) / det;
+   Ji[1][0] = ( J[1][2] * J[2][0] - J[1][0] * J[2][2] ) / det;
+   Ji[1][1] = ( J[0][0] * J[2][2] - J[0][2] * J[2][0] ) / det;
+   Ji[1][2] = ( J[0][2] * J[1][0] - J[0][0] * J[1][2] ) / det;
+   Ji[2][0] = ( J[1][0] * J[2][1] - J[1][1] * J[2][0] ) / det;
+   Ji[2][1] = ( J[0][1] * J[2][0] - J[0][0] * J[2][1] ) / det;
+   Ji[2][2] = ( J[0][0] * J[1][1] - J[0][1] * J[1][0] ) / det;
+   for ( int r = 0; r < 3; ++r )
+   {
+      g[1][r] = Ji[0][r];
+      g[2][r] = Ji[1][r];
+      g[3][r] = Ji[2][r];
+      g[0][r] = -( Ji[0][r] + Ji[1][r] + Ji[2][r] );
+   }
+   return std::fabs( det ) / 6.0;
+}
+// Blocks of the P1-P1 Stokes operator (src/constant_stencil_operator/P1ConstantOperator.hpp:178-210; UFL sources
+// data/operators/form_{div,divt,pspg}_tet.ufl).  Row 0 = test function of vertex 0, entry j = trial function of vertex j.
+// P1Div{x,y,z}Operator: -u.dx(K) q dx
+template < int K >
+struct P1DivForm
+{
+   static void integrateRow0( const std::array< Point3D, 4 >& c, double row[4] )
+   {
+      double       g[4][3];
+      const double V = tetGradients( c, g );
+      for ( int j = 0; j < 4; ++j )
+         row[j] = -g[j][K] * V / 4.0;
+   }
+};
+// P1DivT{x,y,z}Operator: -v.dx(K) p dx
+template < int K >
+struct P1DivTForm
+{
+   static void integrateRow0( const std::array< Point3D, 4 >& c, double row[4] )
+   {
+      double       g[4][3];
+      const double V = tetGradients( c, g );
+      for ( int j = 0; j < 4; ++j )
+         row[j] = -g[0][K] * V / 4.0;
+   }
+};
+// P1PSPGOperator: -tau grad p . grad q dx, tau = (cell volume)^(2/3) / 12
+struct P1PSPGForm
+{
+   static void integrateRow0( const std::array< Point3D, 4 >& c, double row[4] )
+   {
+      double       g[4][3];
+      const double V   = tetGradients( c, g );
+      const double tau = std::pow( V, 2.0 / 3.0 ) / 12.0;
+      for ( int j = 0; j < 4; ++j )
+         row[j] = -tau * V * ( g[0][0] * g[j][0] + g[0][1] * g[j][1] + g[0][2] * g[j][2] );
+   }
+};
 struct P1MassForm
 {
    static void integrateRow0( const std::array< Point3D, 4 >& c, double row[4] )

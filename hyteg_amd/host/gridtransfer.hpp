@@ -12,8 +12,9 @@ namespace hyteg {
 class P1toP1LinearRestriction
 {
  public:
-   void restrict( const P1Function< double >& function, const uint_t& sourceLevel, const DoFType& flag ) const
+   void restrict( const P1Function< double >& function, const uint_t& sourceLevel, const DoFType& flagIn ) const
    {
+      const DoFType flag = function.effectiveFlag( flagIn ); // the function's boundary condition decides what `Inner` means
       auto         storage = function.getStorage();
       const uint_t dstLevel = sourceLevel - 1;
       if ( storage->useBatch( sourceLevel ) )
@@ -55,13 +56,15 @@ class P1toP1LinearProlongation
       // shared copies and the add read only those.
       auto                 storage = function.getStorage();
       P1Function< double > tmp( "prolongate_tmp", storage, sourceLevel + 1, sourceLevel + 1, true );
+      tmp.setBoundaryConditionAllInner( function.hasAllInnerBoundaryCondition() );
       run( function, tmp, sourceLevel, flag );
       function.add( { 1.0 }, { tmp }, sourceLevel + 1, flag );
    }
 
  private:
-   static void run( const P1Function< double >& src, const P1Function< double >& dst, uint_t sourceLevel, DoFType flag )
+   static void run( const P1Function< double >& src, const P1Function< double >& dst, uint_t sourceLevel, DoFType flagIn )
    {
+      const DoFType flag = dst.effectiveFlag( flagIn ); // the function's boundary condition decides what `Inner` means
       auto storage = src.getStorage();
       if ( storage->useBatch( sourceLevel + 1 ) )
       {

@@ -29,3 +29,4 @@
 #include "p2operator.hpp"
 #include "gridtransfer.hpp"
 #include "solvers.hpp"
+#include "stokes.hpp"

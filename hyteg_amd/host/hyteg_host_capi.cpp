@@ -16,12 +16,33 @@ struct FunctionH
 {
    std::shared_ptr< P1Function< double > > p;
 };
+// form ids of hyteg_host_operator_create (include/hyteg_host.h): 0 Laplace, 1 mass, 2-4 div x/y/z, 5-7 divT x/y/z, 8 PSPG
 struct OperatorH
 {
    int                                          form;
    std::shared_ptr< P1ConstantLaplaceOperator > laplace;
    std::shared_ptr< P1ConstantMassOperator >    mass;
+   std::shared_ptr< P1DivxOperator >            divx;
+   std::shared_ptr< P1DivyOperator >            divy;
+   std::shared_ptr< P1DivzOperator >            divz;
+   std::shared_ptr< P1DivTxOperator >           divtx;
+   std::shared_ptr< P1DivTyOperator >           divty;
+   std::shared_ptr< P1DivTzOperator >           divtz;
+   std::shared_ptr< P1PSPGOperator >            pspg;
    FunctionH                                    invDiag; // borrowed view
+};
+struct StokesFunctionH
+{
+   std::shared_ptr< P1StokesFunction< double > > p;
+   FunctionH                                     comp[4]; // borrowed views of u, v, w, p
+};
+struct StokesOperatorH
+{
+   std::shared_ptr< P1P1StokesOperator > p;
+};
+struct StokesSolverH
+{
+   std::shared_ptr< Solver< P1P1StokesOperator > > p;
 };
 struct SolverH
 {
@@ -233,6 +254,10 @@ HYTEG_HOST_API int hyteg_host_function_sum_shared( hh_function_t f, int level, i
 {
    return guarded( [&] { F( f ).sumSharedCopies( (uint_t) level, DoFType( flag ) ); } );
 }
+HYTEG_HOST_API int hyteg_host_function_set_all_inner( hh_function_t f, int on )
+{
+   return guarded( [&] { F( f ).setBoundaryConditionAllInner( on != 0 ); } );
+}
 HYTEG_HOST_API int hyteg_host_function_sync_shared( hh_function_t f, int level, int flag )
 {
    return guarded( [&] { F( f ).syncSharedCopies( (uint_t) level, DoFType( flag ) ); } );
@@ -241,12 +266,24 @@ HYTEG_HOST_API int hyteg_host_function_sync_shared( hh_function_t f, int level, 
 HYTEG_HOST_API int hyteg_host_operator_create( hh_storage_t s, int minL, int maxL, int form, hh_operator_t* out )
 {
    return guarded( [&] {
-      auto* h = new OperatorH{};
-      h->form = form;
-      if ( form == 0 )
-         h->laplace = std::make_shared< P1ConstantLaplaceOperator >( static_cast< StorageH* >( s )->p, (uint_t) minL, (uint_t) maxL );
-      else
-         h->mass = std::make_shared< P1ConstantMassOperator >( static_cast< StorageH* >( s )->p, (uint_t) minL, (uint_t) maxL );
+      if ( form < 0 || form > 8 )
+         throw std::runtime_error( "operator_create: unknown form id" );
+      auto* h      = new OperatorH{};
+      h->form      = form;
+      auto storage = static_cast< StorageH* >( s )->p;
+      const uint_t a = (uint_t) minL, b = (uint_t) maxL;
+      switch ( form )
+      {
+      case 0: h->laplace = std::make_shared< P1ConstantLaplaceOperator >( storage, a, b ); break;
+      case 1: h->mass = std::make_shared< P1ConstantMassOperator >( storage, a, b ); break;
+      case 2: h->divx = std::make_shared< P1DivxOperator >( storage, a, b ); break;
+      case 3: h->divy = std::make_shared< P1DivyOperator >( storage, a, b ); break;
+      case 4: h->divz = std::make_shared< P1DivzOperator >( storage, a, b ); break;
+      case 5: h->divtx = std::make_shared< P1DivTxOperator >( storage, a, b ); break;
+      case 6: h->divty = std::make_shared< P1DivTyOperator >( storage, a, b ); break;
+      case 7: h->divtz = std::make_shared< P1DivTzOperator >( storage, a, b ); break;
+      default: h->pspg = std::make_shared< P1PSPGOperator >( storage, a, b ); break;
+      }
       *out = h;
    } );
 }
@@ -254,20 +291,28 @@ HYTEG_HOST_API int hyteg_host_operator_destroy( hh_operator_t op )
 {
    return guarded( [&] { delete static_cast< OperatorH* >( op ); } );
 }
-#define WITH_OP( op, expr )                        \
-   do                                              \
-   {                                               \
-      auto* _h = static_cast< OperatorH* >( op );  \
-      if ( _h->form == 0 )                         \
-      {                                            \
-         auto& A = *_h->laplace;                   \
-         expr;                                     \
-      }                                            \
-      else                                         \
-      {                                            \
-         auto& A = *_h->mass;                      \
-         expr;                                     \
-      }                                            \
+#define WITH_OP_CASE( member ) \
+   {                           \
+      auto& A = *_h->member;   \
+      expr;                    \
+   }                           \
+   break
+#define WITH_OP( op, expr )                       \
+   do                                             \
+   {                                              \
+      auto* _h = static_cast< OperatorH* >( op ); \
+      switch ( _h->form )                         \
+      {                                           \
+      case 0: { auto& A = *_h->laplace; expr; } break; \
+      case 1: { auto& A = *_h->mass; expr; } break;    \
+      case 2: { auto& A = *_h->divx; expr; } break;    \
+      case 3: { auto& A = *_h->divy; expr; } break;    \
+      case 4: { auto& A = *_h->divz; expr; } break;    \
+      case 5: { auto& A = *_h->divtx; expr; } break;   \
+      case 6: { auto& A = *_h->divty; expr; } break;   \
+      case 7: { auto& A = *_h->divtz; expr; } break;   \
+      default: { auto& A = *_h->pspg; expr; } break;   \
+      }                                           \
    } while ( 0 )
 HYTEG_HOST_API int hyteg_host_operator_stencils( hh_operator_t op, int gc, int level, double* inner15, double* slots210 )
 {
@@ -407,6 +452,113 @@ HYTEG_HOST_API int hyteg_host_solver_solve( hh_solver_t solver, hh_operator_t la
 HYTEG_HOST_API int hyteg_host_solver_destroy( hh_solver_t solver )
 {
    return guarded( [&] { delete static_cast< SolverH* >( solver ); } );
+}
+
+/* ---- P1-P1 Stokes (src/mixed_operator/P1P1StokesOperator.hpp, src/hyteg/solvers/UzawaSmoother.hpp) ---- */
+HYTEG_HOST_API int hyteg_host_stokes_function_create( hh_storage_t s, const char* name, int minL, int maxL, hh_stokes_function_t* out )
+{
+   return guarded( [&] {
+      auto* h = new StokesFunctionH{};
+      h->p    = std::make_shared< P1StokesFunction< double > >( name, static_cast< StorageH* >( s )->p, (uint_t) minL, (uint_t) maxL );
+      *out    = h;
+   } );
+}
+HYTEG_HOST_API int hyteg_host_stokes_function_destroy( hh_stokes_function_t f )
+{
+   return guarded( [&] { delete static_cast< StokesFunctionH* >( f ); } );
+}
+HYTEG_HOST_API int hyteg_host_stokes_function_component( hh_stokes_function_t f, int k, hh_function_t* out )
+{
+   return guarded( [&] {
+      auto* h = static_cast< StokesFunctionH* >( f );
+      if ( k < 0 || k > 3 )
+         throw std::runtime_error( "stokes_function_component: k = 0, 1, 2 (velocity) or 3 (pressure)" );
+      // aliasing pointer: shares ownership with the Stokes function, points at the component
+      const P1Function< double >& c = k < 3 ? h->p->uvw()[(uint_t) k] : h->p->p();
+      h->comp[k].p                  = std::shared_ptr< P1Function< double > >( h->p, const_cast< P1Function< double >* >( &c ) );
+      *out                          = &h->comp[k];
+   } );
+}
+HYTEG_HOST_API int hyteg_host_stokes_function_assign( hh_stokes_function_t dst, int n, const double* scalars, const hh_stokes_function_t* fs, int level, int flag )
+{
+   return guarded( [&] {
+      std::vector< std::reference_wrapper< const P1StokesFunction< double > > > r;
+      for ( int i = 0; i < n; ++i )
+         r.push_back( std::cref( *static_cast< StokesFunctionH* >( fs[i] )->p ) );
+      static_cast< StokesFunctionH* >( dst )->p->assign( std::vector< double >( scalars, scalars + n ), r, (uint_t) level, DoFType( flag ) );
+   } );
+}
+HYTEG_HOST_API int hyteg_host_stokes_function_dot( hh_stokes_function_t a, hh_stokes_function_t b, int level, int flag, double* out )
+{
+   return guarded( [&] {
+      *out = static_cast< StokesFunctionH* >( a )->p->dotGlobal( *static_cast< StokesFunctionH* >( b )->p, (uint_t) level, DoFType( flag ) );
+   } );
+}
+HYTEG_HOST_API int hyteg_host_project_mean( hh_function_t pressure, int level )
+{
+   return guarded( [&] { projectMean( F( pressure ), (uint_t) level ); } );
+}
+HYTEG_HOST_API int hyteg_host_stokes_operator_create( hh_storage_t s, int minL, int maxL, hh_stokes_operator_t* out )
+{
+   return guarded( [&] {
+      *out = new StokesOperatorH{ std::make_shared< P1P1StokesOperator >( static_cast< StorageH* >( s )->p, (uint_t) minL, (uint_t) maxL ) };
+   } );
+}
+HYTEG_HOST_API int hyteg_host_stokes_operator_destroy( hh_stokes_operator_t op )
+{
+   return guarded( [&] { delete static_cast< StokesOperatorH* >( op ); } );
+}
+HYTEG_HOST_API int hyteg_host_stokes_operator_apply( hh_stokes_operator_t op, hh_stokes_function_t src, hh_stokes_function_t dst, int level, int flag )
+{
+   return guarded( [&] {
+      static_cast< StokesOperatorH* >( op )->p->apply( *static_cast< StokesFunctionH* >( src )->p, *static_cast< StokesFunctionH* >( dst )->p,
+                                                       (uint_t) level, DoFType( flag ) );
+   } );
+}
+HYTEG_HOST_API int hyteg_host_stokes_uzawa_create( hh_storage_t s, int minL, int maxL, double relax, int velocity_iterations, int velocity_smoother,
+                                                   double velocity_relax, hh_stokes_solver_t* out )
+{
+   return guarded( [&] {
+      using Op     = P1P1StokesOperator;
+      auto storage = static_cast< StorageH* >( s )->p;
+      std::shared_ptr< Solver< P1ConstantLaplaceOperator > > scalar;
+      if ( velocity_smoother == 0 )
+         scalar = std::make_shared< WeightedJacobiSmoother< P1ConstantLaplaceOperator > >( storage, (uint_t) minL, (uint_t) maxL, velocity_relax );
+      else if ( velocity_smoother == 1 )
+         scalar = std::make_shared< GaussSeidelSmoother< P1ConstantLaplaceOperator > >();
+      else
+         scalar = std::make_shared< SORSmoother< P1ConstantLaplaceOperator > >( velocity_relax );
+      auto velocity = std::make_shared< StokesVelocityBlockBlockDiagonalPreconditioner< Op > >( storage, scalar );
+      *out          = new StokesSolverH{ std::make_shared< UzawaSmoother< Op > >( storage, velocity, (uint_t) minL, (uint_t) maxL, relax,
+                                                                                  Inner | NeumannBoundary | FreeslipBoundary,
+                                                                                  (uint_t) velocity_iterations ) };
+   } );
+}
+HYTEG_HOST_API int hyteg_host_stokes_gmg_create( hh_storage_t s, hh_stokes_solver_t smoother, int minL, int maxL, int pre, int post, int increment,
+                                                 int project_mean_after_restriction, hh_stokes_solver_t* out )
+{
+   return guarded( [&] {
+      using Op     = P1P1StokesOperator;
+      auto storage = static_cast< StorageH* >( s )->p;
+      auto coarse  = std::make_shared< DenseCoarseGridSolver< Op > >( storage, (uint_t) minL );
+      *out         = new StokesSolverH{
+          std::make_shared< GeometricMultigridSolver< Op, P1P1StokesToP1P1StokesRestriction, P1P1StokesToP1P1StokesProlongation > >(
+              storage, static_cast< StokesSolverH* >( smoother )->p, coarse,
+              std::make_shared< P1P1StokesToP1P1StokesRestriction >( project_mean_after_restriction != 0 ),
+              std::make_shared< P1P1StokesToP1P1StokesProlongation >(), (uint_t) minL, (uint_t) maxL, (uint_t) pre, (uint_t) post,
+              (uint_t) increment ) };
+   } );
+}
+HYTEG_HOST_API int hyteg_host_stokes_solver_solve( hh_stokes_solver_t solver, hh_stokes_operator_t op, hh_stokes_function_t x, hh_stokes_function_t b, int level )
+{
+   return guarded( [&] {
+      static_cast< StokesSolverH* >( solver )->p->solve( *static_cast< StokesOperatorH* >( op )->p, *static_cast< StokesFunctionH* >( x )->p,
+                                                         *static_cast< StokesFunctionH* >( b )->p, (uint_t) level );
+   } );
+}
+HYTEG_HOST_API int hyteg_host_stokes_solver_destroy( hh_stokes_solver_t solver )
+{
+   return guarded( [&] { delete static_cast< StokesSolverH* >( solver ); } );
 }
 
 /* ---- P2 (single macro-cell) ---- */

@@ -20,6 +20,15 @@ class P1Function
 
    uint64_t uid() const { return uid_; }
 
+   // BoundaryCondition::createAllInnerBC() (the pressure of P1StokesFunction, composites/P1StokesFunction.hpp:41-42): every
+   // point of this function counts as Inner, whatever the storage says about the macro-primitive it lies on.  Default:
+   // the storage's boundary types (create0123BC).  Operators, grid transfer and the function's own methods translate the
+   // DoFType flag they are given with the destination function's boundary condition, as the reference does with
+   // dst.getBoundaryCondition().getBoundaryType( primitive.getMeshBoundaryFlag() ) (P1Operator.hpp:301-303).
+   void    setBoundaryConditionAllInner( bool on = true ) { allInner_ = on; }
+   bool    hasAllInnerBoundaryCondition() const { return allInner_; }
+   DoFType effectiveFlag( DoFType flag ) const { return allInner_ ? ( testFlag( flag, Inner ) ? All : DoFType( 0 ) ) : flag; }
+
    // scratch = true: arrays come from (and return to) the storage's scratch pool and are NOT zero-initialised
    P1Function( const std::string& name, const std::shared_ptr< PrimitiveStorage >& storage, uint_t minLevel, uint_t maxLevel,
                bool scratch = false )
@@ -84,8 +93,9 @@ class P1Function
    }
 
    // ---- interpolate ( VertexDoFFunction.cpp:380-392, :395-470 ) ----
-   void interpolate( ValueType constant, uint_t level, DoFType flag = All ) const
+   void interpolate( ValueType constant, uint_t level, DoFType flagIn = All ) const
    {
+      const DoFType flag = effectiveFlag( flagIn ); // the function's boundary condition decides what `Inner` means
       if ( storage_->useBatch( level ) )
       {
          const auto masks = storage_->masksFor( flag );
@@ -103,8 +113,9 @@ class P1Function
                    "interpolate" );
       } );
    }
-   void interpolate( const std::function< ValueType( const Point3D& ) >& expr, uint_t level, DoFType flag = All ) const
+   void interpolate( const std::function< ValueType( const Point3D& ) >& expr, uint_t level, DoFType flagIn = All ) const
    {
+      const DoFType flag = effectiveFlag( flagIn ); // the function's boundary condition decides what `Inner` means
       // evaluated on the host at the micro-vertex coordinates of VertexDoFMacroCell.hpp:70-77, then uploaded
       const int64_t N = layout::width( (int) level ), size = layout::cellSize( (int) level );
       P1Function    tmp( "interpolate_tmp", storage_, level, level, true );
@@ -159,8 +170,9 @@ class P1Function
    void setToZero( uint_t level ) const { interpolate( ValueType( 0 ), level, All ); }
 
    // ---- dot ( VertexDoFFunction.cpp:1710-1793 ) ----
-   ValueType dotLocal( const P1Function< ValueType >& rhs, uint_t level, DoFType flag = All ) const
+   ValueType dotLocal( const P1Function< ValueType >& rhs, uint_t level, DoFType flagIn = All ) const
    {
+      const DoFType flag = effectiveFlag( flagIn ); // the function's boundary condition decides what `Inner` means
       // one result slot per local cell, a single download (= one host synchronisation) per dot product; the
       // workspace is reused cell after cell, which is safe because all launches are ordered on one stream
       const uint_t nLocal = storage_->getNumberOfLocalCells();
@@ -252,8 +264,9 @@ class P1Function
                   const std::vector< ValueType >&                                           scalars,
                   const std::vector< std::reference_wrapper< const P1Function< ValueType > > >& functions,
                   uint_t                                                                    level,
-                  DoFType                                                                   flag ) const
+                  DoFType                                                                   flagIn ) const
    {
+      const DoFType flag = effectiveFlag( flagIn ); // the function's boundary condition decides what `Inner` means
       if ( functions.empty() || functions.size() > HYTEG_HIP_MAX_SRCS || ( op != 2 && scalars.size() != functions.size() ) )
          throw std::runtime_error( "P1Function::assign/add/multElementwise: bad number of functions or scalars" );
       if ( storage_->useBatch( level ) )
@@ -287,8 +300,9 @@ class P1Function
    // with at most HYTEG_HIP_MAX_BATCH local cells (one launch)
    void vectorOpDeviceScalars( int op, const std::vector< const double* >& scalarPtrs,
                                const std::vector< std::reference_wrapper< const P1Function< ValueType > > >& functions, uint_t level,
-                               DoFType flag ) const
+                               DoFType flagIn ) const
    {
+      const DoFType flag = effectiveFlag( flagIn ); // the function's boundary condition decides what `Inner` means
       const int  count = (int) storage_->getNumberOfLocalCells();
       const auto masks = storage_->masksFor( flag );
       const auto dst   = cellPointers( level, 0, count );
@@ -302,9 +316,10 @@ class P1Function
    }
    // cgScalars[slot] = <this, rhs> over the points `flag` selects (each shared point counted once), then phase `phase` of
    // the conjugate gradient recurrences (hyteg_hip_cg_scalars), in one launch; no host synchronisation
-   void dotLocalToCgScalars( const P1Function< ValueType >& rhs, uint_t level, DoFType flag, double* cgScalars, int slot, int phase,
+   void dotLocalToCgScalars( const P1Function< ValueType >& rhs, uint_t level, DoFType flagIn, double* cgScalars, int slot, int phase,
                              double relTol, double absTol ) const
    {
+      const DoFType flag = effectiveFlag( flagIn ); // the function's boundary condition decides what `Inner` means
       const int  count = (int) storage_->getNumberOfLocalCells();
       const auto masks = storage_->masksFor( flag, true );
       const auto a = cellPointers( level, 0, count ), b = rhs.cellPointers( level, 0, count );
@@ -321,13 +336,15 @@ class P1Function
          a.push_back( getCellPointer( c, level ) );
       return a;
    }
-   void exchangeBegin( uint_t level, DoFType flag ) const
+   void exchangeBegin( uint_t level, DoFType flagIn ) const
    {
+      const DoFType flag = effectiveFlag( flagIn ); // the function's boundary condition decides what `Inner` means
       checkLevel( level );
       storage_->sharedExchangeBegin( cellArrays( level ), (int) level, flag, 0 );
    }
-   void exchangeEnd( uint_t level, DoFType flag, bool additive ) const
+   void exchangeEnd( uint_t level, DoFType flagIn, bool additive ) const
    {
+      const DoFType flag = effectiveFlag( flagIn ); // the function's boundary condition decides what `Inner` means
       storage_->sharedExchangeEnd( cellArrays( level ), (int) level, flag, 0, additive );
    }
 
@@ -335,6 +352,7 @@ class P1Function
    std::shared_ptr< PrimitiveStorage >                                   storage_;
    uint_t                                                                minLevel_, maxLevel_;
    bool                                                                  scratch_ = false;
+   bool                                                                  allInner_ = false;
    uint64_t                                                              uid_     = nextUid();
    std::vector< std::vector< double* > >                                 data_;
 };

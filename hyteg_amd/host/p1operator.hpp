@@ -43,8 +43,9 @@ class P1ConstantOperator
    const stencil::CellStencils&        getCellStencils( int globalCellID, uint_t level ) const { return stencils_.at( level ).at( globalCellID ); }
 
    // Operator::apply, P1Operator.hpp:192-320
-   void apply( const P1Function< double >& src, const P1Function< double >& dst, uint_t level, DoFType flag, UpdateType updateType = Replace ) const
+   void apply( const P1Function< double >& src, const P1Function< double >& dst, uint_t level, DoFType flagIn, UpdateType updateType = Replace ) const
    {
+      const DoFType flag = dst.effectiveFlag( flagIn ); // the function's boundary condition decides what `Inner` means
       if ( &src == &dst )
          throw std::runtime_error( "P1ConstantOperator::apply: src and dst must differ (P1Operator.hpp:198)" );
       if ( storage_->useBatch( level ) )
@@ -96,8 +97,9 @@ class P1ConstantOperator
 
    // P1Operator::smooth_jac, P1Operator.hpp:429-447
    void smooth_jac( const P1Function< double >& dst, const P1Function< double >& rhs, const P1Function< double >& src, double relax,
-                    uint_t level, DoFType flag ) const
+                    uint_t level, DoFType flagIn ) const
    {
+      const DoFType flag = dst.effectiveFlag( flagIn ); // the function's boundary condition decides what `Inner` means
       if ( &src == &dst )
          throw std::runtime_error( "smooth_jac: src and dst must differ" );
       const auto& invDiag = *getInverseDiagonalValues();
@@ -156,9 +158,10 @@ class P1ConstantOperator
    //  sweep = every cell runs the vertex / edge / face sweeps on its own copies with the total weights (bit-identical
    //          copies, no further exchange), then the lexicographic macro-cell sweep.
    // Backwards the reference communicates before every class, so `rest` is rebuilt (and exchanged) per class.
-   void smooth_sor( const P1Function< double >& dst, const P1Function< double >& rhs, double relax, uint_t level, DoFType flag,
+   void smooth_sor( const P1Function< double >& dst, const P1Function< double >& rhs, double relax, uint_t level, DoFType flagIn,
                     bool backwards = false ) const
    {
+      const DoFType flag = dst.effectiveFlag( flagIn ); // the function's boundary condition decides what `Inner` means
       if ( &dst == &rhs )
          throw std::runtime_error( "smooth_sor: dst and rhs must differ" );
       bool anyShell = false;
@@ -367,9 +370,10 @@ class P1ConstantOperator
       return storage_->numRanks() == 1 && n >= 1 && n <= HYTEG_HIP_MAX_BATCH &&
              (int64_t) n * layout::cellSize( (int) level ) <= hyteg_hip_p1_cg_small_max_entries();
    }
-   void cgSolveSmall( const P1Function< double >& x, const P1Function< double >& b, uint_t level, DoFType flag, uint_t maxIter, double relTol,
+   void cgSolveSmall( const P1Function< double >& x, const P1Function< double >& b, uint_t level, DoFType flagIn, uint_t maxIter, double relTol,
                       double absTol, double* infoDev ) const
    {
+      const DoFType flag = x.effectiveFlag( flagIn ); // the function's boundary condition decides what `Inner` means
       const int  count = (int) storage_->getNumberOfLocalCells();
       const auto masks = storage_->masksFor( flag ), owned = storage_->masksFor( flag, true );
       const auto xs = x.cellPointers( level, 0, count ), bs = b.cellPointers( level, 0, count );

@@ -254,15 +254,19 @@ class CGSolver : public Solver< OperatorType >
 };
 
 // GeometricMultigridSolver.hpp:40-330
-template < class OperatorType >
+// Generic over the operator's function type and the grid-transfer operators, like the reference (which takes
+// RestrictionOperator< FunctionType > / ProlongationOperator< FunctionType >): P1 functions with the linear transfer by
+// default, P1StokesFunction with P1P1StokesToP1P1Stokes{Restriction,Prolongation} (stokes.hpp).
+template < class OperatorType, class RestrictionType = P1toP1LinearRestriction, class ProlongationType = P1toP1LinearProlongation >
 class GeometricMultigridSolver : public Solver< OperatorType >
 {
  public:
+   using FunctionType = typename OperatorType::srcType;
    GeometricMultigridSolver( const std::shared_ptr< PrimitiveStorage >&         storage,
                              std::shared_ptr< Solver< OperatorType > >          smoother,
                              std::shared_ptr< Solver< OperatorType > >          coarseSolver,
-                             std::shared_ptr< P1toP1LinearRestriction >         restrictionOperator,
-                             std::shared_ptr< P1toP1LinearProlongation >        prolongationOperator,
+                             std::shared_ptr< RestrictionType >                 restrictionOperator,
+                             std::shared_ptr< ProlongationType >                prolongationOperator,
                              uint_t                                             minLevel,
                              uint_t                                             maxLevel,
                              uint_t                                             preSmoothSteps  = 3,
@@ -308,7 +312,7 @@ class GeometricMultigridSolver : public Solver< OperatorType >
    // number of cycles that were replayed from a recording (tests)
    uint_t replayedCycles() const { return replayed_; }
 
-   void solve( const OperatorType& A, const P1Function< double >& x, const P1Function< double >& b, uint_t level ) override
+   void solve( const OperatorType& A, const FunctionType& x, const FunctionType& b, uint_t level ) override
    {
       invokedLevel_ = level;
       if ( !graphsUsable() )
@@ -384,7 +388,7 @@ class GeometricMultigridSolver : public Solver< OperatorType >
       capturing_ = true;
    }
 
-   void record( Recording& rec, const OperatorType& A, const P1Function< double >& x, const P1Function< double >& b, uint_t level )
+   void record( Recording& rec, const OperatorType& A, const FunctionType& x, const FunctionType& b, uint_t level )
    {
       const hyteg_hip_stream_t user = storage_->stream();
       try
@@ -412,7 +416,7 @@ class GeometricMultigridSolver : public Solver< OperatorType >
       storage_->setStream( user );
    }
 
-   void solveRecursively( const OperatorType& A, const P1Function< double >& x, const P1Function< double >& b, uint_t level )
+   void solveRecursively( const OperatorType& A, const FunctionType& x, const FunctionType& b, uint_t level )
    {
       if ( level == minLevel_ )
       {
@@ -445,9 +449,9 @@ class GeometricMultigridSolver : public Solver< OperatorType >
    DoFType                                      flag_;
    CycleType                                    cycleType_;
    std::shared_ptr< Solver< OperatorType > >    smoother_, coarseSolver_;
-   std::shared_ptr< P1toP1LinearRestriction >   restrictionOperator_;
-   std::shared_ptr< P1toP1LinearProlongation >  prolongationOperator_;
-   P1Function< double >                         tmp_;
+   std::shared_ptr< RestrictionType >           restrictionOperator_;
+   std::shared_ptr< ProlongationType >          prolongationOperator_;
+   FunctionType                                 tmp_;
    std::shared_ptr< PrimitiveStorage >          storage_;
    bool                                         useGraphs_ = false, capturing_ = false;
    hyteg_hip_stream_t                           captureStream_ = nullptr;

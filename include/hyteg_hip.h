@@ -639,7 +639,8 @@ HYTEG_HIP_API int hyteg_hip_comm_unique_id( unsigned char* id );
 HYTEG_HIP_API int hyteg_hip_comm_create( hyteg_hip_comm_t* comm, int nranks, int rank, const unsigned char* id );
 HYTEG_HIP_API int hyteg_hip_comm_destroy( hyteg_hip_comm_t comm );
 /* send[ sum of send_count[0..k) ... ) goes to peers[k], recv[ sum of recv_count[0..k) ... ) comes from peers[k]
- * (device buffers, counts in doubles, host arrays of length npeers); stream-ordered */
+ * (device buffers, counts in doubles, host arrays of length npeers); stream-ordered.  A peer may be the calling rank
+ * itself (loop-back inside the group; what the single-GPU tests use). */
 HYTEG_HIP_API int hyteg_hip_comm_exchange( hyteg_hip_comm_t   comm,
                                            int                npeers,
                                            const int*         peers,

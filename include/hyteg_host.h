@@ -28,6 +28,9 @@ typedef void* hh_operator_t;
 typedef void* hh_solver_t;
 typedef void* hh_p2function_t;
 typedef void* hh_p2operator_t;
+typedef void* hh_stokes_function_t;
+typedef void* hh_stokes_operator_t;
+typedef void* hh_stokes_solver_t;
 
 HYTEG_HOST_API const char* hyteg_host_last_error( void );
 
@@ -81,8 +84,11 @@ HYTEG_HOST_API int hyteg_host_function_mult_elementwise( hh_function_t dst, int 
 HYTEG_HOST_API int hyteg_host_function_dot( hh_function_t a, hh_function_t b, int level, int flag, int global, double* result );
 HYTEG_HOST_API int hyteg_host_function_sum_shared( hh_function_t f, int level, int flag );
 HYTEG_HOST_API int hyteg_host_function_sync_shared( hh_function_t f, int level, int flag );
+/* BoundaryCondition::createAllInnerBC() for this function (the pressure of a Stokes function): every point counts as Inner */
+HYTEG_HOST_API int hyteg_host_function_set_all_inner( hh_function_t f, int on );
 
-/* ---- P1ConstantOperator (form 0: Laplace, 1: mass) ---- */
+/* ---- P1ConstantOperator< Form > (src/constant_stencil_operator/P1ConstantOperator.hpp:165-210)
+ * form 0: Laplace, 1: mass, 2-4: P1Div{x,y,z}Operator, 5-7: P1DivT{x,y,z}Operator, 8: P1PSPGOperator ---- */
 HYTEG_HOST_API int hyteg_host_operator_create( hh_storage_t s, int min_level, int max_level, int form, hh_operator_t* out );
 HYTEG_HOST_API int hyteg_host_operator_destroy( hh_operator_t op );
 /* inner[15], slots[14*15] of a GLOBAL cell id */
@@ -120,6 +126,29 @@ HYTEG_HOST_API int hyteg_host_cg_iterations( hh_solver_t solver, int* iterations
 HYTEG_HOST_API int hyteg_host_cg_create( hh_storage_t s, int min_level, int max_level, int max_iter, double tol, hh_solver_t* out );
 HYTEG_HOST_API int hyteg_host_solver_solve( hh_solver_t solver, hh_operator_t laplace, hh_function_t x, hh_function_t b, int level );
 HYTEG_HOST_API int hyteg_host_solver_destroy( hh_solver_t solver );
+
+/* ---- P1-P1 Stokes: P1StokesFunction (composites/P1StokesFunction.hpp: velocity with the storage's boundary types, pressure
+ * with createAllInnerBC), P1P1StokesOperator::apply (mixed_operator/P1P1StokesOperator.hpp:51-64), UzawaSmoother
+ * (solvers/UzawaSmoother.hpp:262-288) over StokesVelocityBlockBlockDiagonalPreconditioner, geometric multigrid with
+ * P1P1StokesToP1P1Stokes{Restriction,Prolongation} and a dense direct coarse-grid solver standing in for PETScLUSolver ---- */
+HYTEG_HOST_API int hyteg_host_stokes_function_create( hh_storage_t s, const char* name, int min_level, int max_level, hh_stokes_function_t* out );
+HYTEG_HOST_API int hyteg_host_stokes_function_destroy( hh_stokes_function_t f );
+/* k = 0, 1, 2: velocity components, 3: pressure; the handle is a view owned by the Stokes function (do not destroy it) */
+HYTEG_HOST_API int hyteg_host_stokes_function_component( hh_stokes_function_t f, int k, hh_function_t* out );
+HYTEG_HOST_API int hyteg_host_stokes_function_assign( hh_stokes_function_t dst, int n, const double* scalars, const hh_stokes_function_t* fs, int level, int flag );
+HYTEG_HOST_API int hyteg_host_stokes_function_dot( hh_stokes_function_t a, hh_stokes_function_t b, int level, int flag, double* out );
+/* vertexdof::projectMean (VertexDoFFunction.hpp:586-592) */
+HYTEG_HOST_API int hyteg_host_project_mean( hh_function_t pressure, int level );
+HYTEG_HOST_API int hyteg_host_stokes_operator_create( hh_storage_t s, int min_level, int max_level, hh_stokes_operator_t* out );
+HYTEG_HOST_API int hyteg_host_stokes_operator_destroy( hh_stokes_operator_t op );
+HYTEG_HOST_API int hyteg_host_stokes_operator_apply( hh_stokes_operator_t op, hh_stokes_function_t src, hh_stokes_function_t dst, int level, int flag );
+/* velocity_smoother: 0 weighted Jacobi, 1 Gauss-Seidel, 2 SOR (relaxation velocity_relax) on every velocity component */
+HYTEG_HOST_API int hyteg_host_stokes_uzawa_create( hh_storage_t s, int min_level, int max_level, double relax, int velocity_iterations,
+                                                   int velocity_smoother, double velocity_relax, hh_stokes_solver_t* out );
+HYTEG_HOST_API int hyteg_host_stokes_gmg_create( hh_storage_t s, hh_stokes_solver_t smoother, int min_level, int max_level, int pre, int post,
+                                                 int increment, int project_mean_after_restriction, hh_stokes_solver_t* out );
+HYTEG_HOST_API int hyteg_host_stokes_solver_solve( hh_stokes_solver_t solver, hh_stokes_operator_t op, hh_stokes_function_t x, hh_stokes_function_t b, int level );
+HYTEG_HOST_API int hyteg_host_stokes_solver_destroy( hh_stokes_solver_t solver );
 
 /* ---- P2Function / P2ElementwiseLaplaceOperator (first version): any number of macro-cells on ONE rank ----
  * vertex part: the P1 cell array; edge part: hyteg_hip_p2_edge_array_size( level ) doubles (EdgeDoFIndexing.hpp:920-985) */

@@ -485,6 +485,80 @@ HO_API void ho_p1_tet_mass( double* A, const double* c )
          A[4 * i + j] = fabs( det ) / 120.0 * ( i == j ? 2.0 : 1.0 );
 }
 
+/* barycentric gradients g[4][3] and volume of a tetrahedron (shared by the first-order forms below) */
+static double tet_gradients( double g[4][3], const double* c )
+{
+   double J[3][3];
+   for ( int r = 0; r < 3; ++r )
+      for ( int k = 0; k < 3; ++k )
+         J[r][k] = c[3 * ( k + 1 ) + r] - c[r];
+   const double det = J[0][0] * ( J[1][1] * J[2][2] - J[1][2] * J[2][1] ) - J[0][1] * ( J[1][0] * J[2][2] - J[1][2] * J[2][0] ) +
+                      J[0][2] * ( J[1][0] * J[2][1] - J[1][1] * J[2][0] );
+   double Ji[3][3];
+   Ji[0][0] = ( J[1][1] * J[2][2] - J[1][2] * J[2][1] ) / det;
+   Ji[0][1] = ( J[0][2] * J[2][1] - J[0][1] * J[2][2] ) / det;
+   Ji[0][2] = ( J[0][1] * J[1][2] - J[0][2] * J[1][1] ) / det;
+   Ji[1][0] = ( J[1][2] * J[2][0] - J[1][0] * J[2][2] ) / det;
+   Ji[1][1] = ( J[0][0] * J[2][2] - J[0][2] * J[2][0] ) / det;
+   Ji[1][2] = ( J[0][2] * J[1][0] - J[0][0] * J[1][2] ) / det;
+   Ji[2][0] = ( J[1][0] * J[2][1] - J[1][1] * J[2][0] ) / det;
+   Ji[2][1] = ( J[0][1] * J[2][0] - J[0][0] * J[2][1] ) / det;
+   Ji[2][2] = ( J[0][0] * J[1][1] - J[0][1] * J[1][0] ) / det;
+   for ( int r = 0; r < 3; ++r )
+   {
+      g[1][r] = Ji[0][r];
+      g[2][r] = Ji[1][r];
+      g[3][r] = Ji[2][r];
+      g[0][r] = -( Ji[0][r] + Ji[1][r] + Ji[2][r] );
+   }
+   return fabs( det ) / 6.0;
+}
+
+/* Blocks of the P1-P1 Stokes operator (src/mixed_operator/P1P1StokesOperator.hpp:51-64), element matrices A[test i][trial j]
+ * as the FEniCS-generated code writes them (row-major; P1FenicsForm.hpp:96-124 reads row 0 of the row-major hyteg::Matrix):
+ *   div_k   data/operators/form_div_tet.ufl   -u.dx(k) q dx     -> -(g_j)_k V/4   (p1_tet_div_tet.h, cell_integral_k)
+ *   divT_k  data/operators/form_divt_tet.ufl  -v.dx(k) p dx     -> -(g_i)_k V/4   (p1_tet_divt_tet.h, cell_integral_k)
+ *   pspg    data/operators/form_pspg_tet.ufl  -tau grad p.grad q dx, tau = V^(2/3)/12  (p1_tet_pspg_tet.h) */
+HO_API void ho_p1_tet_div( double* A, const double* c, int k )
+{
+   double       g[4][3];
+   const double V = tet_gradients( g, c );
+   for ( int i = 0; i < 4; ++i )
+      for ( int j = 0; j < 4; ++j )
+         A[4 * i + j] = -g[j][k] * V / 4.0;
+}
+HO_API void ho_p1_tet_divt( double* A, const double* c, int k )
+{
+   double       g[4][3];
+   const double V = tet_gradients( g, c );
+   for ( int i = 0; i < 4; ++i )
+      for ( int j = 0; j < 4; ++j )
+         A[4 * i + j] = -g[i][k] * V / 4.0;
+}
+HO_API void ho_p1_tet_pspg( double* A, const double* c )
+{
+   double       g[4][3];
+   const double V   = tet_gradients( g, c );
+   const double tau = pow( V, 2.0 / 3.0 ) / 12.0;
+   for ( int i = 0; i < 4; ++i )
+      for ( int j = 0; j < 4; ++j )
+         A[4 * i + j] = -tau * V * ( g[i][0] * g[j][0] + g[i][1] * g[j][1] + g[i][2] * g[j][2] );
+}
+/* form ids shared with the host layer's facade: 0 Laplace, 1 mass, 2-4 div x/y/z, 5-7 divT x/y/z, 8 PSPG */
+static void element_matrix( int form, double* A, const double* coords )
+{
+   if ( form == 0 )
+      ho_p1_tet_diffusion( A, coords );
+   else if ( form == 1 )
+      ho_p1_tet_mass( A, coords );
+   else if ( form >= 2 && form <= 4 )
+      ho_p1_tet_div( A, coords, form - 2 );
+   else if ( form >= 5 && form <= 7 )
+      ho_p1_tet_divt( A, coords, form - 5 );
+   else
+      ho_p1_tet_pspg( A, coords );
+}
+
 /* The 24 micro-tetrahedra around an interior micro-vertex, each as 4 stencil slots with the
  * centre first.  src/hyteg/p1functionspace/P1Elements.hpp:93-143 (white/blue/green up/down). */
 static const int MICRO_TETS[24][4] = {
@@ -498,7 +572,7 @@ static const int MICRO_TETS[24][4] = {
 /* Cell stencil at an interior micro-vertex (the reference assembles it at index (1,1,1),
  * src/constant_stencil_operator/P1ConstantOperator.cpp:680-693 -> P1Operator.hpp:2123-2136 ->
  * P1Elements.hpp:466-528; geometry src/hyteg/p1functionspace/VertexDoFMacroCell.hpp:70-77).
- * form: 0 = Laplace (diffusion), 1 = mass.  cellcoords = 4 macro-vertices x 3. */
+ * form: 0 = Laplace (diffusion), 1 = mass, 2-4 div x/y/z, 5-7 divT x/y/z, 8 PSPG.  cellcoords = 4 macro-vertices x 3. */
 HO_API void ho_assemble_cell_stencil( double* w, const double* cc, int level, int form )
 {
    const double step = 1.0 / (double) ( (int64_t) 1 << level );
@@ -520,10 +594,7 @@ HO_API void ho_assemble_cell_stencil( double* w, const double* cc, int level, in
          for ( int r = 0; r < 3; ++r )
             coords[3 * v + r] = cc[r] + xs[r] * (double) ( 1 + o[0] ) + ys[r] * (double) ( 1 + o[1] ) + zs[r] * (double) ( 1 + o[2] );
       }
-      if ( form == 0 )
-         ho_p1_tet_diffusion( A, coords );
-      else
-         ho_p1_tet_mass( A, coords );
+      element_matrix( form, A, coords );
       for ( int v = 0; v < 4; ++v )
          w[MICRO_TETS[t][v]] += A[v]; /* first row of the element matrix */
    }
@@ -587,10 +658,7 @@ HO_API void ho_assemble_cell_slot_stencils( double* w_slots, const double* cc, i
          for ( int r = 0; r < 3; ++r )
             coords[3 * v + r] = cc[r] + xs[r] * (double) ( 1 + o[0] ) + ys[r] * (double) ( 1 + o[1] ) + zs[r] * (double) ( 1 + o[2] );
       }
-      if ( form == 0 )
-         ho_p1_tet_diffusion( A, coords );
-      else
-         ho_p1_tet_mass( A, coords );
+      element_matrix( form, A, coords );
       for ( int v = 0; v < 4; ++v )
          rows[t][v] = A[v];
    }

@@ -63,6 +63,9 @@ def _bind(lib):
         "ho_prolongate_cell": (None, [_P, _P, i, _P]),
         "ho_p1_tet_diffusion": (None, [_P, _P]),
         "ho_p1_tet_mass": (None, [_P, _P]),
+        "ho_p1_tet_div": (None, [_P, _P, C.c_int]),
+        "ho_p1_tet_divt": (None, [_P, _P, C.c_int]),
+        "ho_p1_tet_pspg": (None, [_P, _P]),
         "ho_assemble_cell_stencil": (None, [_P, _P, i, i]),
         "ho_coordinate_from_index": (None, [_P, _P, i, i, i, i]),
         "ho_assemble_cell_slot_stencils": (None, [_P, _P, i, i]),
@@ -257,6 +260,43 @@ def p1_tet_mass(coords):
     return A.reshape(4, 4)
 
 
+FORM_LAPLACE, FORM_MASS, FORM_DIV_X, FORM_DIV_Y, FORM_DIV_Z, FORM_DIVT_X, FORM_DIVT_Y, FORM_DIVT_Z, FORM_PSPG = range(9)
+
+
+def p1_tet_div(coords, k):
+    c = np.ascontiguousarray(coords, dtype=np.float64).reshape(12)
+    A = np.empty(16)
+    lib().ho_p1_tet_div(_p(A), _p(c), k)
+    return A.reshape(4, 4)
+
+
+def p1_tet_divt(coords, k):
+    c = np.ascontiguousarray(coords, dtype=np.float64).reshape(12)
+    A = np.empty(16)
+    lib().ho_p1_tet_divt(_p(A), _p(c), k)
+    return A.reshape(4, 4)
+
+
+def p1_tet_pspg(coords):
+    c = np.ascontiguousarray(coords, dtype=np.float64).reshape(12)
+    A = np.empty(16)
+    lib().ho_p1_tet_pspg(_p(A), _p(c))
+    return A.reshape(4, 4)
+
+
+def element_matrix(coords, form):
+    """A[test i][trial j] of form id `form` (FORM_*)"""
+    if form == FORM_LAPLACE:
+        return p1_tet_diffusion(coords)
+    if form == FORM_MASS:
+        return p1_tet_mass(coords)
+    if FORM_DIV_X <= form <= FORM_DIV_Z:
+        return p1_tet_div(coords, form - FORM_DIV_X)
+    if FORM_DIVT_X <= form <= FORM_DIVT_Z:
+        return p1_tet_divt(coords, form - FORM_DIVT_X)
+    return p1_tet_pspg(coords)
+
+
 def assemble_cell_stencil(cell_vertex_coords, level, form=0):
     c = np.ascontiguousarray(cell_vertex_coords, dtype=np.float64).reshape(12)
     w = np.empty(15)
@@ -424,8 +464,28 @@ def ref_fenics():
         if not so.exists():
             return None
     l = C.CDLL(str(so))
-    for n in ("ref_p1_tet_diffusion", "ref_p1_tet_mass", "ref_p2_tet_diffusion"):
+    for n in ("ref_p1_tet_diffusion", "ref_p1_tet_mass", "ref_p2_tet_diffusion", "ref_p1_tet_pspg"):
         if not hasattr(l, n):
             continue
         getattr(l, n).restype, getattr(l, n).argtypes = None, [_P, _P]
+    for n in ("ref_p1_tet_div", "ref_p1_tet_divt"):
+        if hasattr(l, n):
+            getattr(l, n).restype, getattr(l, n).argtypes = None, [_P, _P, C.c_int]
     return l
+
+
+def ref_element_matrix(ref, coords, form):
+    """the reference's generated FEniCS tabulate_tensor for form id `form`, row-major A[test i][trial j]"""
+    c = np.ascontiguousarray(coords, dtype=np.float64).reshape(12)
+    A = np.zeros(16)
+    if form == FORM_LAPLACE:
+        ref.ref_p1_tet_diffusion(_p(A), _p(c))
+    elif form == FORM_MASS:
+        ref.ref_p1_tet_mass(_p(A), _p(c))
+    elif FORM_DIV_X <= form <= FORM_DIV_Z:
+        ref.ref_p1_tet_div(_p(A), _p(c), form - FORM_DIV_X)
+    elif FORM_DIVT_X <= form <= FORM_DIVT_Z:
+        ref.ref_p1_tet_divt(_p(A), _p(c), form - FORM_DIVT_X)
+    else:
+        ref.ref_p1_tet_pspg(_p(A), _p(c))
+    return A.reshape(4, 4)

@@ -4,12 +4,16 @@
 // routines, compiled IN PLACE from /root/reference:
 //   src/hyteg/forms/form_fenics_generated/p1_tet_diffusion.h:4093-4251  (cell_integral::tabulate_tensor)
 //   src/hyteg/forms/form_fenics_generated/p1_tet_mass.h                 (same class shape)
+//   src/hyteg/forms/form_fenics_generated/p1_tet_{div,divt,pspg}_tet.h  (blocks of the P1-P1 Stokes operator)
 // These headers depend only on the C++ standard library and the in-tree src/hyteg/fenics/ufc.h,
 // so no stand-in header is involved.  Everything else on the hot path (the pystencils-generated
 // kernels) includes waLBerla/Eigen headers that are empty submodules in the reference snapshot and
 // is therefore NOT built (see DESIGN.md "Oracle").
 #include "hyteg/forms/form_fenics_generated/p1_tet_diffusion.h"
 #include "hyteg/forms/form_fenics_generated/p1_tet_mass.h"
+#include "hyteg/forms/form_fenics_generated/p1_tet_div_tet.h"
+#include "hyteg/forms/form_fenics_generated/p1_tet_divt_tet.h"
+#include "hyteg/forms/form_fenics_generated/p1_tet_pspg_tet.h"
 #include "hyteg/forms/form_fenics_generated/p2_tet_diffusion.h"
 
 extern "C" {
@@ -32,6 +36,49 @@ __attribute__( ( visibility( "default" ) ) ) void ref_p2_tet_diffusion( double* 
 __attribute__( ( visibility( "default" ) ) ) void ref_p1_tet_mass( double* A, const double* coords )
 {
    p1_tet_mass_cell_integral_0_otherwise gen;
+   gen.tabulate_tensor( A, nullptr, coords, 0 );
+}
+
+// blocks of P1P1StokesOperator (src/constant_stencil_operator/P1ConstantOperator.hpp:178-210): k = 0, 1, 2 -> x, y, z
+__attribute__( ( visibility( "default" ) ) ) void ref_p1_tet_div( double* A, const double* coords, int k )
+{
+   if ( k == 0 )
+   {
+      p1_tet_div_tet_cell_integral_0_otherwise gen;
+      gen.tabulate_tensor( A, nullptr, coords, 0 );
+   }
+   else if ( k == 1 )
+   {
+      p1_tet_div_tet_cell_integral_1_otherwise gen;
+      gen.tabulate_tensor( A, nullptr, coords, 0 );
+   }
+   else
+   {
+      p1_tet_div_tet_cell_integral_2_otherwise gen;
+      gen.tabulate_tensor( A, nullptr, coords, 0 );
+   }
+}
+__attribute__( ( visibility( "default" ) ) ) void ref_p1_tet_divt( double* A, const double* coords, int k )
+{
+   if ( k == 0 )
+   {
+      p1_tet_divt_tet_cell_integral_0_otherwise gen;
+      gen.tabulate_tensor( A, nullptr, coords, 0 );
+   }
+   else if ( k == 1 )
+   {
+      p1_tet_divt_tet_cell_integral_1_otherwise gen;
+      gen.tabulate_tensor( A, nullptr, coords, 0 );
+   }
+   else
+   {
+      p1_tet_divt_tet_cell_integral_2_otherwise gen;
+      gen.tabulate_tensor( A, nullptr, coords, 0 );
+   }
+}
+__attribute__( ( visibility( "default" ) ) ) void ref_p1_tet_pspg( double* A, const double* coords )
+{
+   p1_tet_pspg_tet_cell_integral_0_otherwise gen;
    gen.tabulate_tensor( A, nullptr, coords, 0 );
 }
 }

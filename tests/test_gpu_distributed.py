@@ -198,8 +198,36 @@ def _worker_rccl(port, level, q):
     try:
         st = host.Storage.from_gmsh(MESH, 0, 1)
         st.set_stream(torch.cuda.current_stream().cuda_stream)
-        ctx = DistributedContext(st, [2, 3], dev)  # all_reduce(MAX) of the any-peers words on the device
-        res = _run(host, st, level, ctx)           # dotGlobal: all_reduce(SUM) of doubles through the hook
+        ctx = DistributedContext(st, [2, 3], dev)  # "nccl" backend on a device: the native RCCL transport
+        assert ctx.transport == "rccl" and st.transport == "rccl"
+        res = _run(host, st, level, ctx)
+        # the C-ABI the C++ transport is made of, on a communicator of its own: a group of ncclSend / ncclRecv on a side
+        # stream ordered against the current stream with events (loop-back: one GPU holds one RCCL rank), and the
+        # in-place all-reduce of doubles that dotGlobal uses
+        from hyteg_amd import capi
+
+        origin = capi.comm_available()
+        comm = capi.comm_create(1, 0, capi.comm_unique_id())
+        side = torch.cuda.Stream()
+        cur = torch.cuda.current_stream()
+        a = torch.arange(5000, dtype=torch.float64, device=dev) * 0.5
+        b = torch.zeros(5000, dtype=torch.float64, device=dev)
+        a.mul_(2.0)  # producer on the current stream: the exchange must see its result
+        packed, arrived = capi.event_create(), capi.event_create()
+        capi.event_record(packed, cur.cuda_stream)
+        capi.stream_wait_event(side.cuda_stream, packed)
+        capi.comm_exchange(comm, [0, 0], a.data_ptr(), [3000, 1000], b.data_ptr(), [3000, 1000], side.cuda_stream)
+        capi.event_record(arrived, side.cuda_stream)
+        capi.stream_wait_event(cur.cuda_stream, arrived)
+        c = b + 1.0  # consumer on the current stream
+        v = torch.tensor([1.5, -2.0], dtype=torch.float64, device=dev)
+        capi.comm_allreduce_sum(comm, v.data_ptr(), 2, cur.cuda_stream)
+        torch.cuda.synchronize()
+        expect = torch.arange(5000, dtype=torch.float64, device=dev)
+        native_ok = (bool(torch.equal(c[:4000], expect[:4000] + 1.0)) and float(b[4000:].abs().sum()) == 0.0
+                     and v.tolist() == [1.5, -2.0] and "rccl" in origin)
+        capi.event_destroy(packed), capi.event_destroy(arrived)
+        capi.comm_destroy(comm)
         # the transport call of the exchange hooks with the argument types they use: split all_to_all of f64 device
         # tensors, asynchronous, stream-ordered wait
         send = torch.arange(1000, dtype=torch.float64, device=dev)
@@ -209,16 +237,17 @@ def _worker_rccl(port, level, q):
         dist.barrier()
         torch.cuda.synchronize()
         ok = bool(torch.equal(recv[:700], send[:700])) and float(recv[700:].abs().sum()) == 0.0
-        q.put(res + (ok,))
+        q.put(res + (ok and native_ok,))
     finally:
         dist.destroy_process_group()
 
 
 def test_rccl_backend_single_rank():
-    """torch.distributed's "nccl" backend is RCCL on this image.  A one-GPU box can hold one RCCL rank, so this checks
-    what can be checked here: the process group comes up on the device, the collectives the hooks and bench.py issue
-    (all_reduce MAX / SUM on device tensors, split all_to_all_single with async wait, barrier) run on it, and the
-    host layer driven through DistributedContext gives the same numbers as without it."""
+    """A one-GPU box can hold one RCCL rank, so this checks what can be checked here: librccl resolves (the copy torch
+    already holds), the communicator of the C++ transport comes up on the device through DistributedContext, the
+    C-ABI's send/recv group + event ordering + all-reduce work on real RCCL (loop-back), torch's process group (used by
+    bench.py for the barrier and the timing reduction) works next to it, and the host layer gives the same numbers as
+    without any of it."""
     import torch
     import torch.multiprocessing as mp
 

@@ -76,6 +76,22 @@ def test_element_matrices_match_reference_fenics(tet):
     assert np.allclose(M, A.reshape(4, 4), rtol=0, atol=2e-14 * np.abs(A).max())
 
 
+@pytest.mark.parametrize("tet", [REF_TET, OCT_TET, SKEW_TET])
+@pytest.mark.parametrize("form", range(2, 9))
+def test_stokes_block_element_matrices_match_reference_fenics(tet, form):
+    """div x/y/z, divT x/y/z, PSPG (the blocks of src/mixed_operator/P1P1StokesOperator.hpp:51-64) against the reference's
+    generated p1_tet_div_tet.h / p1_tet_divt_tet.h / p1_tet_pspg_tet.h compiled in place; these matrices are NOT
+    symmetric, so this also pins the index convention A[test][trial] (row-major, P1FenicsForm.hpp:96-124 reads row 0)"""
+    ref = _ref_or_skip()
+    A = po.ref_element_matrix(ref, tet, form)
+    mine = po.element_matrix(tet, form)
+    assert np.abs(A).max() > 0
+    assert np.allclose(mine, A, rtol=0, atol=2e-14 * np.abs(A).max())
+    if 2 <= form <= 7:  # div_k is the transpose of divT_k
+        other = po.element_matrix(tet, form + 3 if form <= 4 else form - 3)
+        assert np.array_equal(mine, other.T)
+
+
 def test_unit_tet_element_row_known_answer():
     # SURVEY.md 8c: reference header on the unit reference tet returns row0 = [0.5,-1/6,-1/6,-1/6]
     K = po.p1_tet_diffusion(REF_TET)
@@ -120,17 +136,17 @@ _MICRO_TETS = [
 
 @pytest.mark.parametrize("tet", [REF_TET, OCT_TET, SKEW_TET])
 @pytest.mark.parametrize("level", [2, 5, 8])
-def test_cell_stencil_matches_assembly_from_reference_element_matrices(tet, level):
+@pytest.mark.parametrize("form", [0, 2, 3, 4, 5, 6, 7, 8])
+def test_cell_stencil_matches_assembly_from_reference_element_matrices(tet, level, form):
     ref = _ref_or_skip()
     w = dict.fromkeys(po.STENCIL_NAMES, 0.0)
-    A = np.empty(16)
     for cellspec in _MICRO_TETS:
         names = cellspec.split()
         coords = np.concatenate([po.coordinate_from_index(tet, level, *(1 + o for o in _SD[n])) for n in names])
-        ref.ref_p1_tet_diffusion(po._p(A), po._p(np.ascontiguousarray(coords)))
+        A = po.ref_element_matrix(ref, coords, form)
         for j, n in enumerate(names):
-            w[n] += A[4 * j]  # Eigen column-major matrix(0,j) == A[4j] (P1FenicsForm.hpp:96-124)
-    mine = po.assemble_cell_stencil(tet, level)
+            w[n] += A[0, j]  # row 0 of the row-major hyteg::Matrix: test function of the centre vertex (P1FenicsForm.hpp:96-124)
+    mine = po.assemble_cell_stencil(tet, level, form)
     expect = np.array([w[n] for n in po.STENCIL_NAMES])
     assert np.allclose(mine, expect, rtol=0, atol=1e-13 * np.abs(expect).max())
 
