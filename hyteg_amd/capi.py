@@ -51,6 +51,11 @@ SIGNATURES = {
     "hyteg_hip_cell_index": (_i64, [_i, _i, _i, _i]),
     "hyteg_hip_p1_apply_cell": (_i, [_vp, _vp, _i, _dp, _i, _vp]),
     "hyteg_hip_p1_apply_kernel_name": (_i, [_i, _i, C.c_char_p, _sz]),
+    "hyteg_hip_p1_apply_cell_f32": (_i, [_vp, _vp, _i, _dp, _i, _vp]),
+    "hyteg_hip_p1_jacobi_cell_f32": (_i, [_vp, _vp, _vp, _vp, _i, _dp, _d, _vp]),
+    "hyteg_hip_convert_f64_to_f32": (_i, [_vp, _vp, _sz, _vp]),
+    "hyteg_hip_convert_f32_to_f64": (_i, [_vp, _vp, _sz, _vp]),
+    "hyteg_hip_axpy_f32_into_f64": (_i, [_vp, _vp, _d, _sz, _vp]),
     "hyteg_hip_p1_jacobi_cell": (_i, [_vp, _vp, _vp, _vp, _i, _dp, _d, _vp]),
     "hyteg_hip_p1_sor_cell": (_i, [_vp, _vp, _i, _dp, _d, _i, _vp]),
     "hyteg_hip_set_sor_algorithm": (_i, [_i]),
@@ -218,6 +223,26 @@ def p1_apply_kernel_name(level, update=REPLACE) -> str:
     buf = C.create_string_buffer(256)
     check(lib().hyteg_hip_p1_apply_kernel_name(level, update, buf, 256), "p1_apply_kernel_name")
     return buf.value.decode()
+
+
+def p1_apply_cell_f32(dst, src, level, w, update=REPLACE, stream=0):
+    check(lib().hyteg_hip_p1_apply_cell_f32(dst, src, level, _w15(w), update, stream), "p1_apply_cell_f32")
+
+
+def p1_jacobi_cell_f32(dst, rhs, src, level, w, relax, invdiag=None, stream=0):
+    check(lib().hyteg_hip_p1_jacobi_cell_f32(dst, rhs, src, invdiag, level, _w15(w), relax, stream), "p1_jacobi_cell_f32")
+
+
+def convert_f64_to_f32(dst, src, n, stream=0):
+    check(lib().hyteg_hip_convert_f64_to_f32(dst, src, n, stream), "convert_f64_to_f32")
+
+
+def convert_f32_to_f64(dst, src, n, stream=0):
+    check(lib().hyteg_hip_convert_f32_to_f64(dst, src, n, stream), "convert_f32_to_f64")
+
+
+def axpy_f32_into_f64(y, x, alpha, n, stream=0):
+    check(lib().hyteg_hip_axpy_f32_into_f64(y, x, alpha, n, stream), "axpy_f32_into_f64")
 
 
 def p1_apply_cell(dst, src, level, w, update=REPLACE, stream=0):

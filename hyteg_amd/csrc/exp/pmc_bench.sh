@@ -6,6 +6,6 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_bench; mkdir -p $O
 for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_WRREQ_sum"; do
   N=$(echo $C | tr " " "_" | cut -c1-24)
   timeout -k 10 150 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/bench_$N -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_$N.log 2>&1 || echo "bench pass $N failed"
-  timeout -k 10 100 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/calib_$N -- $R/hyteg_amd/csrc/exp/apply_bench 8 20 8 "copy 8B/lane grid=1024" > $O/calib_$N.log 2>&1 || echo "calib pass $N failed"
+  timeout -k 10 100 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/calib_$N -- $R/hyteg_amd/csrc/exp/copy_calib 20 > $O/calib_$N.log 2>&1 || echo "calib pass $N failed"
 done
 ls $O

@@ -50,13 +50,15 @@ constexpr int kZMarchMaxStairs  = 5;  // decode mode: x-chunks of the longest ro
 
 struct ZMarchArgs
 {
-   double*          dst;
-   const double*    src;
-   const double*    rhs;     // JACOBI only
-   const double*    invdiag; // JACOBI only, may be null
+   // cell arrays of the kernel's value type (double, or float: the reference instantiates its generated apply kernels for
+   // both, apply_3D_macrocell_vertexdof_to_vertexdof_replace.cpp:96-97)
+   void*            dst;
+   const void*      src;
+   const void*      rhs;     // JACOBI only
+   const void*      invdiag; // JACOBI only, may be null
    const BrickTask* tasks;   // table mode (DEC == false)
    int              ntasks;
-   unsigned         bytes;     // size of the cell array in bytes (buffer range)
+   unsigned         bytes;     // size of the cell array in bytes (buffer range): entries x sizeof( value type )
    int              xcd_chunk; // workgroups per XCD group (0: identity map)
    int              N;         // 2^level + 1
    double           relax;
@@ -77,16 +79,27 @@ constexpr int kZMarchWavesPerBlock = HYTEG_ZM_WAVES_PER_BLOCK; // 1, 2, 8 measur
 typedef int zm_v2i_t __attribute__( ( ext_vector_type( 2 ) ) );
 
 // wave-uniform row base in the scalar offset, lane part in the vector offset (the range check sees the vector offset only)
-template < int AUX = 0 >
-__device__ inline double zm_load2( __amdgpu_buffer_rsrc_t r, int voff, int soff )
+template < typename T, int AUX = 0 >
+__device__ inline T zm_load2( __amdgpu_buffer_rsrc_t r, int voff, int soff )
 {
-   zm_v2i_t v = __builtin_amdgcn_raw_buffer_load_b64( r, voff, soff, AUX );
-   return *reinterpret_cast< double* >( &v );
+   if constexpr ( sizeof( T ) == 8 )
+   {
+      zm_v2i_t v = __builtin_amdgcn_raw_buffer_load_b64( r, voff, soff, AUX );
+      return *reinterpret_cast< T* >( &v );
+   }
+   else
+   {
+      int v = __builtin_amdgcn_raw_buffer_load_b32( r, voff, soff, AUX );
+      return *reinterpret_cast< T* >( &v );
+   }
 }
-template < int AUX = 0 >
-__device__ inline void zm_store2( __amdgpu_buffer_rsrc_t r, int voff, int soff, double d )
+template < typename T, int AUX = 0 >
+__device__ inline void zm_store2( __amdgpu_buffer_rsrc_t r, int voff, int soff, T d )
 {
-   __builtin_amdgcn_raw_buffer_store_b64( *reinterpret_cast< zm_v2i_t* >( &d ), r, voff, soff, AUX );
+   if constexpr ( sizeof( T ) == 8 )
+      __builtin_amdgcn_raw_buffer_store_b64( *reinterpret_cast< zm_v2i_t* >( &d ), r, voff, soff, AUX );
+   else
+      __builtin_amdgcn_raw_buffer_store_b32( *reinterpret_cast< int* >( &d ), r, voff, soff, AUX );
 }
 __device__ inline double zm_lane_minus_1( double v )
 {
@@ -101,6 +114,14 @@ __device__ inline double zm_lane_plus_1( double v )
    lo     = __builtin_amdgcn_mov_dpp( lo, 0x130, 0xf, 0xf, true ); // wave_shl:1
    hi     = __builtin_amdgcn_mov_dpp( hi, 0x130, 0xf, 0xf, true );
    return __hiloint2double( hi, lo );
+}
+__device__ inline float zm_lane_minus_1( float v )
+{
+   return __int_as_float( __builtin_amdgcn_mov_dpp( __float_as_int( v ), 0x138, 0xf, 0xf, true ) );
+}
+__device__ inline float zm_lane_plus_1( float v )
+{
+   return __int_as_float( __builtin_amdgcn_mov_dpp( __float_as_int( v ), 0x130, 0xf, 0xf, true ) );
 }
 
 __host__ __device__ inline void zm_fill_bases( BrickTask& t, int LZ )
@@ -176,9 +197,11 @@ __device__ inline BrickTask zm_decode_task( const ZMarchArgs& A, int task )
 // EX_AUX: cache policy of the second array of ADD (dst, read once: nontemporal) / JACOBI (rhs: plain, the next sweep
 // re-reads it).  gfx950 "aux" bits: 1 = sc0, 2 = nt, 16 = sc1.
 // PFD: how many slices ahead of the one being computed the loads run.
-template < int MODE, int NY, int LZ, int EX_AUX = 0, bool DEC = false, int PFD = 1 >
+// T: value type of the arrays and of the arithmetic (double or float; the weights travel as doubles and are converted).
+template < int MODE, int NY, int LZ, int EX_AUX = 0, bool DEC = false, int PFD = 1, typename T = double >
 __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_kernel( const ZMarchArgs A )
 {
+   constexpr int SZ = (int) sizeof( T );
    ZM_TRACE( 0 );
    int b = blockIdx.x;
    if ( A.xcd_chunk > 0 )
@@ -195,18 +218,18 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_k
    ZM_TRACE( 1 );
 
    constexpr int kStAux = 2; // nontemporal
-   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc( const_cast< double* >( A.src ), 0, A.bytes, 0x00020000 );
+   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc( const_cast< void* >( A.src ), 0, A.bytes, 0x00020000 );
    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc( A.dst, 0, A.bytes, 0x00020000 );
    const __amdgpu_buffer_rsrc_t rr =
-       __builtin_amdgcn_make_buffer_rsrc( const_cast< double* >( MODE == APPLY_JACOBI ? A.rhs : A.src ), 0, A.bytes, 0x00020000 );
+       __builtin_amdgcn_make_buffer_rsrc( const_cast< void* >( MODE == APPLY_JACOBI ? A.rhs : A.src ), 0, A.bytes, 0x00020000 );
    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(
-       const_cast< double* >( ( MODE == APPLY_JACOBI && A.invdiag ) ? A.invdiag : A.src ), 0, A.bytes, 0x00020000 );
+       const_cast< void* >( ( MODE == APPLY_JACOBI && A.invdiag ) ? A.invdiag : A.src ), 0, A.bytes, 0x00020000 );
 
-   const int lane_off = lane * 8;
+   const int lane_off = lane * SZ;
    const int ym       = t.y0 - 1; // first row held per slice
 
    // S[q][r]: slice z0-1+q, row ym+r (r = 0..NY+1), x = xb + lane.  q = 0..LZ+1.
-   double S[LZ + 2][NY + 2];
+   T S[LZ + 2][NY + 2];
 
    // Lanes whose x lies beyond the end of the row being loaded re-read the row's last entry (same cache line; a
    // negative bound puts the whole row out of range: the range check returns 0 without touching the cache), so the
@@ -221,8 +244,8 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_k
          const bool need = ( q == 0 ) ? ( r >= 1 ) : ( q == LZ + 1 ? ( r <= NY ) : true );
          if ( need )
          {
-            const int last8 = ( W_q - ( ym + r ) - 1 - t.xb ) * 8; // byte offset of the row's last entry from lane 0's
-            S[q][r]         = zm_load2< 0 >( rs, min( lane_off, last8 ), ix * 8 );
+            const int last8 = ( W_q - ( ym + r ) - 1 - t.xb ) * SZ; // byte offset of the row's last entry from lane 0's
+            S[q][r]         = zm_load2< T, 0 >( rs, min( lane_off, last8 ), ix * SZ );
          }
          ix += W_q - ( ym + r ); // next row of the same slice
       }
@@ -249,8 +272,12 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_k
    ( std::make_integer_sequence < int, ( 2 + PFD <= LZ + 2 ? 2 + PFD : LZ + 2 ) > {} );
    ZM_TRACE( 2 );
 
-   const double* w    = A.st.w;
-   const double  invc = 1.0 / w[7];
+   T w[15]; // the stencil in the arithmetic's precision
+#pragma unroll
+   for ( int i = 0; i < 15; ++i )
+      w[i] = (T) A.st.w[i];
+   const T invc  = (T) ( 1.0 / A.st.w[7] );
+   const T relax = (T) A.relax;
 
    auto step = [&]( auto sc ) {
       constexpr int s = decltype( sc )::value; // output slice z0 + s, centre q = s+1
@@ -262,17 +289,17 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_k
       int       io = baseq[q] + ( W - ym ); // (xb, y0, z)
       // ADD / JACOBI read a second (and third) array at the output points: issue those loads now, ahead of the
       // slice's arithmetic, instead of one dependent round trip per row right before the store
-      double ex0[NY], ex1[NY];
+      T ex0[NY], ex1[NY];
       if constexpr ( MODE != APPLY_REPLACE )
       {
          int ie = io;
 #pragma unroll
          for ( int j = 0; j < NY; ++j )
          {
-            const int last8 = ( W - ( t.y0 + j ) - 1 - t.xb ) * 8;
+            const int last8 = ( W - ( t.y0 + j ) - 1 - t.xb ) * SZ;
             const int vo    = min( lane_off, last8 );
-            ex0[j]          = MODE == APPLY_ADD ? zm_load2< EX_AUX >( rd, vo, ie * 8 ) : zm_load2< EX_AUX >( rr, vo, ie * 8 );
-            ex1[j]          = ( MODE == APPLY_JACOBI && A.invdiag ) ? zm_load2( ri, vo, ie * 8 ) : invc;
+            ex0[j]          = MODE == APPLY_ADD ? zm_load2< T, EX_AUX >( rd, vo, ie * SZ ) : zm_load2< T, EX_AUX >( rr, vo, ie * SZ );
+            ex1[j]          = ( MODE == APPLY_JACOBI && A.invdiag ) ? zm_load2< T >( ri, vo, ie * SZ ) : invc;
             ie += W - ( t.y0 + j );
          }
       }
@@ -281,20 +308,20 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_k
 #pragma unroll
       for ( int j = 0; j < NY; ++j )
       {
-         const double am = S[q][j], a0 = S[q][j + 1], ap = S[q][j + 2];
-         const double um = S[q + 1][j], u0 = S[q + 1][j + 1];
-         const double d0 = S[q - 1][j + 1], dp = S[q - 1][j + 2];
+         const T am = S[q][j], a0 = S[q][j + 1], ap = S[q][j + 2];
+         const T um = S[q + 1][j], u0 = S[q + 1][j + 1];
+         const T d0 = S[q - 1][j + 1], dp = S[q - 1][j + 2];
          // the eight x-shifted terms are summed per shift direction BEFORE the lane shift (two wave shifts per output
          // instead of eight); same terms as the reference, different summation order
-         double pe = w[8] * a0; // what the lane to the left needs from this lane: E, SE, TSE, BE
+         T pe = w[8] * a0; // what the lane to the left needs from this lane: E, SE, TSE, BE
          pe        = fma( w[5], am, pe );
          pe        = fma( w[12], um, pe );
          pe        = fma( w[1], d0, pe );
-         double pw = w[6] * a0; // what the lane to the right needs: W, TW, BNW, NW
+         T pw = w[6] * a0; // what the lane to the right needs: W, TW, BNW, NW
          pw        = fma( w[13], u0, pw );
          pw        = fma( w[2], dp, pw );
          pw        = fma( w[9], ap, pw );
-         double acc = zm_lane_plus_1( pe ) + zm_lane_minus_1( pw );
+         T acc = zm_lane_plus_1( pe ) + zm_lane_minus_1( pw );
          acc        = fma( w[3], dp, acc );  // BN
          acc        = fma( w[10], ap, acc ); // N
          acc        = fma( w[4], am, acc );  // S
@@ -304,17 +331,17 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_k
          acc        = fma( w[14], u0, acc ); // TC
 
          const int R = W - ( t.y0 + j );
-         double    out;
+         T         out;
          if ( MODE == APPLY_REPLACE )
             out = acc;
          else if ( MODE == APPLY_ADD )
             out = acc + ex0[j];
          else
-            out = a0 + A.relax * ( ex1[j] * ( ex0[j] - acc ) );
+            out = a0 + relax * ( ex1[j] * ( ex0[j] - acc ) );
          // outputs are lanes 1 .. min( 62, R - 2 - xb ) of slices that exist: one unsigned compare of (lane - 1)
          const int      cnt = s < t.nz ? min( 62, R - 2 - t.xb ) : 0; // wave-uniform
          const unsigned lm1 = (unsigned) ( lane - 1 );
-         zm_store2< kStAux >( rd, lm1 < (unsigned) max( cnt, 0 ) ? lane_off : -8, io * 8, out );
+         zm_store2< T, kStAux >( rd, lm1 < (unsigned) max( cnt, 0 ) ? lane_off : -8, io * SZ, out );
          io += R;
       }
    };

@@ -1,5 +1,6 @@
 // C-ABI entry points: constant-stencil apply and fused weighted Jacobi on one macro-cell.
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels_apply.hpp"
 #include "kernels_apply_zmarch.hpp"
@@ -38,9 +39,8 @@ inline int apply_prefetch_distance()
    return pfd;
 }
 
-template < int MODE, int LZ >
-int launch_zmarch_lz( double* dst, const double* src, const double* rhs, const double* invdiag, int level, const double* w,
-                      double relax, hipStream_t stream )
+template < int MODE, int LZ, typename T = double >
+int launch_zmarch_lz( T* dst, const T* src, const T* rhs, const T* invdiag, int level, const double* w, double relax, hipStream_t stream )
 {
    BrickTable bt;
    int        rc = get_bricks( level, kBrickNY, LZ, &bt );
@@ -56,7 +56,7 @@ int launch_zmarch_lz( double* dst, const double* src, const double* rhs, const d
    A.tasks   = bt.dev;
    A.ntasks  = bt.count;
    A.N       = ( 1 << level ) + 1;
-   A.bytes   = (unsigned) ( tet64( A.N ) * 8 );
+   A.bytes   = (unsigned) ( tet64( A.N ) * (int64_t) sizeof( T ) );
    A.relax   = relax;
    for ( int k = 0; k < 15; ++k )
       A.st.w[k] = w[k];
@@ -71,7 +71,9 @@ int launch_zmarch_lz( double* dst, const double* src, const double* rhs, const d
    // when they are still in the Infinity Cache, -2% when they are not).
    constexpr int kExAux = MODE == APPLY_ADD ? 2 : 0;
    const dim3 grid( nblocks ), block( 64 * kZMarchWavesPerBlock );
-   if ( bt.decodable && apply_decode_enabled() )
+   if constexpr ( !std::is_same< T, double >::value )
+      hipLaunchKernelGGL( ( p1_apply_zmarch_kernel< MODE, kBrickNY, LZ, kExAux, false, 2, T > ), grid, block, 0, stream, A );
+   else if ( bt.decodable && apply_decode_enabled() )
       hipLaunchKernelGGL( ( p1_apply_zmarch_kernel< MODE, kBrickNY, LZ, kExAux, true > ), grid, block, 0, stream, A );
    else if ( apply_prefetch_distance() == 1 )
       hipLaunchKernelGGL( ( p1_apply_zmarch_kernel< MODE, kBrickNY, LZ, kExAux, false, 1 > ), grid, block, 0, stream, A );
@@ -81,13 +83,12 @@ int launch_zmarch_lz( double* dst, const double* src, const double* rhs, const d
    return HYTEG_HIP_OK;
 }
 
-template < int MODE >
-int launch_zmarch( double* dst, const double* src, const double* rhs, const double* invdiag, int level, const double* w,
-                   double relax, hipStream_t stream )
+template < int MODE, typename T = double >
+int launch_zmarch( T* dst, const T* src, const T* rhs, const T* invdiag, int level, const double* w, double relax, hipStream_t stream )
 {
    if ( brick_lz( level ) == 8 )
-      return launch_zmarch_lz< MODE, 8 >( dst, src, rhs, invdiag, level, w, relax, stream );
-   return launch_zmarch_lz< MODE, 4 >( dst, src, rhs, invdiag, level, w, relax, stream );
+      return launch_zmarch_lz< MODE, 8, T >( dst, src, rhs, invdiag, level, w, relax, stream );
+   return launch_zmarch_lz< MODE, 4, T >( dst, src, rhs, invdiag, level, w, relax, stream );
 }
 
 template < int MODE >
@@ -151,6 +152,35 @@ HYTEG_HIP_API int hyteg_hip_p1_apply_cell( double*            dst,
    if ( update == HYTEG_HIP_REPLACE )
       return launch_apply< APPLY_REPLACE >( dst, src, nullptr, nullptr, level, w, 0.0, as_stream( stream ) );
    return launch_apply< APPLY_ADD >( dst, src, nullptr, nullptr, level, w, 0.0, as_stream( stream ) );
+}
+
+// ---- float instantiations (the reference instantiates its generated apply kernels for float as well:
+// apply_3D_macrocell_vertexdof_to_vertexdof_replace.cpp:96-97); levels 2..10 (32-bit buffer addressing) ----
+HYTEG_HIP_API int hyteg_hip_p1_apply_cell_f32( float* dst, const float* src, int level, const double* w, int update, hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( dst && src && w, "p1_apply_cell_f32: null pointer" );
+   HH_REQUIRE( level >= HYTEG_HIP_MIN_LEVEL && level <= 10, "p1_apply_cell_f32: level out of range [2,10]" );
+   HH_REQUIRE( dst != src, "p1_apply_cell_f32: src and dst must not alias" );
+   HH_REQUIRE( update == HYTEG_HIP_REPLACE || update == HYTEG_HIP_ADD, "p1_apply_cell_f32: bad update type" );
+   if ( update == HYTEG_HIP_REPLACE )
+      return launch_zmarch< APPLY_REPLACE, float >( dst, src, nullptr, nullptr, level, w, 0.0, as_stream( stream ) );
+   return launch_zmarch< APPLY_ADD, float >( dst, src, nullptr, nullptr, level, w, 0.0, as_stream( stream ) );
+}
+
+HYTEG_HIP_API int hyteg_hip_p1_jacobi_cell_f32( float*             dst,
+                                                const float*       rhs,
+                                                const float*       src,
+                                                const float*       invdiag,
+                                                int                level,
+                                                const double*      w,
+                                                double             relax,
+                                                hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( dst && rhs && src && w, "p1_jacobi_cell_f32: null pointer" );
+   HH_REQUIRE( level >= HYTEG_HIP_MIN_LEVEL && level <= 10, "p1_jacobi_cell_f32: level out of range [2,10]" );
+   HH_REQUIRE( dst != src, "p1_jacobi_cell_f32: src and dst must not alias" );
+   HH_REQUIRE( w[7] != 0.0, "p1_jacobi_cell_f32: zero centre weight" );
+   return launch_zmarch< APPLY_JACOBI, float >( dst, src, rhs, invdiag, level, w, relax, as_stream( stream ) );
 }
 
 HYTEG_HIP_API int hyteg_hip_p1_apply_kernel_name( int level, int update, char* buf, size_t buflen )

@@ -13,7 +13,7 @@ _LIB_PATH = _PKG / "lib" / "libhyteg_host.so"
 
 Inner, DirichletBoundary, NeumannBoundary, FreeslipBoundary, All, Boundary = 1, 2, 4, 8, 15, 14
 Replace, Add = 0, 1
-JACOBI, GAUSS_SEIDEL, SOR = 0, 1, 2
+JACOBI, GAUSS_SEIDEL, SOR, JACOBI_FP32 = 0, 1, 2, 3  # JACOBI_FP32: MixedPrecisionJacobiSmoother (float sweeps on cell interiors)
 
 _vp, _i, _d, _u = C.c_void_p, C.c_int, C.c_double, C.c_uint
 _ip, _dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
@@ -35,6 +35,9 @@ SIGNATURES = {
     "hyteg_host_storage_use_rccl": (_i, [_vp, C.c_char_p]),
     "hyteg_host_storage_transport_name": (_i, [_vp, C.c_char_p, _i]),
     "hyteg_host_storage_allreduce_sum": (_i, [_vp, _dp, _i]),
+    "hyteg_host_storage_enable_timing": (_i, [_vp, _i, _i]),
+    "hyteg_host_storage_timing_json": (_i, [_vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "hyteg_host_storage_timing_reset": (_i, [_vp]),
     "hyteg_host_plan_sizes": (_i, [_vp, _i, _i, _ip]),
     "hyteg_host_plan_export": (_i, [_vp, _i, _i, _ip, _ip, _ip, _ip, _ip, _ip, _ip, _ip]),
     "hyteg_host_plan_register_buffers": (_i, [_vp, _i, _i, _vp, _vp]),
@@ -230,6 +233,21 @@ class Storage:
         a = np.ascontiguousarray(values, dtype=np.float64).copy()
         _ck(lib().hyteg_host_storage_allreduce_sum(self.h, a.ctypes.data_as(_dp), len(a)), "storage_allreduce_sum")
         return a
+
+    def enable_timing(self, on=True, synchronize=False):
+        """walberla-style timing tree with the reference's timer names; synchronize: ranges measure device execution"""
+        _ck(lib().hyteg_host_storage_enable_timing(self.h, int(on), int(synchronize)), "storage_enable_timing")
+
+    def timing_json(self) -> str:
+        """the tree in the layout of walberla::timing::to_json (hyteg::writeTimingTreeJSON)"""
+        need = C.c_size_t()
+        _ck(lib().hyteg_host_storage_timing_json(self.h, None, 0, C.byref(need)), "storage_timing_json")
+        buf = C.create_string_buffer(need.value)
+        _ck(lib().hyteg_host_storage_timing_json(self.h, buf, need.value, None), "storage_timing_json")
+        return buf.value.decode()
+
+    def timing_reset(self):
+        _ck(lib().hyteg_host_storage_timing_reset(self.h), "storage_timing_reset")
 
     @property
     def transport(self) -> str:

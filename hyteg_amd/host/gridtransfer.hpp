@@ -14,6 +14,7 @@ class P1toP1LinearRestriction
  public:
    void restrict( const P1Function< double >& function, const uint_t& sourceLevel, const DoFType& flagIn ) const
    {
+      ScopedTimer timerRestrict( function.getStorage()->getTimingTree(), "P1toP1LinearRestriction" );
       const DoFType flag = function.effectiveFlag( flagIn ); // the function's boundary condition decides what `Inner` means
       auto         storage = function.getStorage();
       const uint_t dstLevel = sourceLevel - 1;
@@ -64,6 +65,7 @@ class P1toP1LinearProlongation
  private:
    static void run( const P1Function< double >& src, const P1Function< double >& dst, uint_t sourceLevel, DoFType flagIn )
    {
+      ScopedTimer timerProlongate( src.getStorage()->getTimingTree(), "P1toP1LinearProlongation" );
       const DoFType flag = dst.effectiveFlag( flagIn ); // the function's boundary condition decides what `Inner` means
       auto storage = src.getStorage();
       if ( storage->useBatch( sourceLevel + 1 ) )

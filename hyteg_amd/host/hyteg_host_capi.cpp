@@ -156,6 +156,29 @@ HYTEG_HOST_API int hyteg_host_storage_allreduce_sum( hh_storage_t s, double* val
          S( s ).requireTransport( "allreduce_sum" ).allreduceSum( values, n );
    } );
 }
+HYTEG_HOST_API int hyteg_host_storage_enable_timing( hh_storage_t s, int on, int synchronize )
+{
+   return guarded( [&] { S( s ).enableTiming( on != 0, synchronize != 0 ); } );
+}
+HYTEG_HOST_API int hyteg_host_storage_timing_json( hh_storage_t s, char* buf, size_t buflen, size_t* needed )
+{
+   return guarded( [&] {
+      if ( !S( s ).getTimingTree() )
+         throw std::runtime_error( "storage_timing_json: timing is not enabled" );
+      const std::string j = S( s ).getTimingTree()->toJSON();
+      if ( needed )
+         *needed = j.size() + 1;
+      if ( buf && buflen > 0 )
+         snprintf( buf, buflen, "%s", j.c_str() );
+   } );
+}
+HYTEG_HOST_API int hyteg_host_storage_timing_reset( hh_storage_t s )
+{
+   return guarded( [&] {
+      if ( S( s ).getTimingTree() )
+         S( s ).getTimingTree()->reset();
+   } );
+}
 HYTEG_HOST_API int hyteg_host_storage_transport_name( hh_storage_t s, char* buf, int buflen )
 {
    return guarded( [&] {
@@ -384,6 +407,8 @@ HYTEG_HOST_API int hyteg_host_gmg_create( hh_storage_t s, int minL, int maxL, in
          sm = std::make_shared< WeightedJacobiSmoother< Op > >( storage, (uint_t) minL, (uint_t) maxL, relax );
       else if ( smoother == 1 )
          sm = std::make_shared< GaussSeidelSmoother< Op > >();
+      else if ( smoother == 3 )
+         sm = std::make_shared< MixedPrecisionJacobiSmoother< Op > >( storage, (uint_t) minL, (uint_t) maxL, relax );
       else
          sm = std::make_shared< SORSmoother< Op > >( relax );
       auto coarse = std::make_shared< CGSolver< Op > >( storage, (uint_t) minL, (uint_t) minL, (uint_t) cgMaxIter, cgTol, cgTol );

@@ -95,6 +95,7 @@ class P1Function
    // ---- interpolate ( VertexDoFFunction.cpp:380-392, :395-470 ) ----
    void interpolate( ValueType constant, uint_t level, DoFType flagIn = All ) const
    {
+      ScopedTimer timerFn( storage_->getTimingTree(), "P1Function" ), timerOp( storage_->getTimingTree(), "Interpolate" );
       const DoFType flag = effectiveFlag( flagIn ); // the function's boundary condition decides what `Inner` means
       if ( storage_->useBatch( level ) )
       {
@@ -115,6 +116,7 @@ class P1Function
    }
    void interpolate( const std::function< ValueType( const Point3D& ) >& expr, uint_t level, DoFType flagIn = All ) const
    {
+      ScopedTimer timerFn( storage_->getTimingTree(), "P1Function" ), timerOp( storage_->getTimingTree(), "Interpolate" );
       const DoFType flag = effectiveFlag( flagIn ); // the function's boundary condition decides what `Inner` means
       // evaluated on the host at the micro-vertex coordinates of VertexDoFMacroCell.hpp:70-77, then uploaded
       const int64_t N = layout::width( (int) level ), size = layout::cellSize( (int) level );
@@ -172,6 +174,7 @@ class P1Function
    // ---- dot ( VertexDoFFunction.cpp:1710-1793 ) ----
    ValueType dotLocal( const P1Function< ValueType >& rhs, uint_t level, DoFType flagIn = All ) const
    {
+      ScopedTimer timerFn( storage_->getTimingTree(), "P1Function" ), timerOp( storage_->getTimingTree(), "Dot (local)" );
       const DoFType flag = effectiveFlag( flagIn ); // the function's boundary condition decides what `Inner` means
       // one result slot per local cell, a single download (= one host synchronisation) per dot product; the
       // workspace is reused cell after cell, which is safe because all launches are ordered on one stream
@@ -213,7 +216,9 @@ class P1Function
    }
    ValueType dotGlobal( const P1Function< ValueType >& rhs, uint_t level, DoFType flag = All ) const
    {
-      return storage_->allreduceSum( dotLocal( rhs, level, flag ), "dotGlobal" );
+      const double local = dotLocal( rhs, level, flag );
+      ScopedTimer  timerFn( storage_->getTimingTree(), "P1Function" ), timerOp( storage_->getTimingTree(), "Dot (reduce)" );
+      return storage_->allreduceSum( local, "dotGlobal" );
    }
 
    // ---- shared-point exchange (the cell-centric replacement of communicate<> / communicateAdditively<>) ----
@@ -267,6 +272,8 @@ class P1Function
                   DoFType                                                                   flagIn ) const
    {
       const DoFType flag = effectiveFlag( flagIn ); // the function's boundary condition decides what `Inner` means
+      static const char* kOpNames[3] = { "Assign", "Add", "Multiply elementwise" };
+      ScopedTimer        timerFn( storage_->getTimingTree(), "P1Function" ), timerOp( storage_->getTimingTree(), kOpNames[op] );
       if ( functions.empty() || functions.size() > HYTEG_HIP_MAX_SRCS || ( op != 2 && scalars.size() != functions.size() ) )
          throw std::runtime_error( "P1Function::assign/add/multElementwise: bad number of functions or scalars" );
       if ( storage_->useBatch( level ) )

@@ -45,6 +45,7 @@ class P1ConstantOperator
    // Operator::apply, P1Operator.hpp:192-320
    void apply( const P1Function< double >& src, const P1Function< double >& dst, uint_t level, DoFType flagIn, UpdateType updateType = Replace ) const
    {
+      ScopedTimer timerOp( storage_->getTimingTree(), "Operator P1Function to P1Function" ), timerApply( storage_->getTimingTree(), "Apply" );
       const DoFType flag = dst.effectiveFlag( flagIn ); // the function's boundary condition decides what `Inner` means
       if ( &src == &dst )
          throw std::runtime_error( "P1ConstantOperator::apply: src and dst must differ (P1Operator.hpp:198)" );
@@ -99,6 +100,7 @@ class P1ConstantOperator
    void smooth_jac( const P1Function< double >& dst, const P1Function< double >& rhs, const P1Function< double >& src, double relax,
                     uint_t level, DoFType flagIn ) const
    {
+      ScopedTimer timerOp( storage_->getTimingTree(), "Operator P1Function to P1Function" ), timerJac( storage_->getTimingTree(), "smooth_jac" );
       const DoFType flag = dst.effectiveFlag( flagIn ); // the function's boundary condition decides what `Inner` means
       if ( &src == &dst )
          throw std::runtime_error( "smooth_jac: src and dst must differ" );
@@ -161,6 +163,7 @@ class P1ConstantOperator
    void smooth_sor( const P1Function< double >& dst, const P1Function< double >& rhs, double relax, uint_t level, DoFType flagIn,
                     bool backwards = false ) const
    {
+      ScopedTimer timerOp( storage_->getTimingTree(), "Operator P1Function to P1Function" ), timerSor( storage_->getTimingTree(), backwards ? "SOR backwards" : "SOR" );
       const DoFType flag = dst.effectiveFlag( flagIn ); // the function's boundary condition decides what `Inner` means
       if ( &dst == &rhs )
          throw std::runtime_error( "smooth_sor: dst and rhs must differ" );

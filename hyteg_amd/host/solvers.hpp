@@ -67,6 +67,89 @@ class WeightedJacobiSmoother : public Solver< OperatorType >
    DoFType              flag_;
 };
 
+// Mixed-precision weighted Jacobi: the "fp32 smoother" of BASELINE config 5.  The reference instantiates its generated apply
+// kernels for float (apply_3D_macrocell_vertexdof_to_vertexdof_replace.cpp:96-97) and converts between function
+// precisions with copyFrom (VertexDoFFunction.hpp:598-650); this smoother uses exactly those pieces in defect-correction
+// form, so that the iterate and the residual stay in double:
+//   r = b - A x                                                   double, every point `flag` selects
+//   per macro-cell:  e = fp32Sweeps Jacobi sweeps on A e = r     float arrays, cell interior only, e = 0 on the cell boundary
+//                    (block Jacobi over the macro-cells: the fused float kernel, half the bytes of the double one)
+//   x += e                                                        double
+//   one double smooth_jac over all selected points                (the points shared between cells are smoothed here)
+// On one macro-cell with Dirichlet boundary the float part IS fp32Sweeps Jacobi sweeps on the error equation.
+template < class OperatorType >
+class MixedPrecisionJacobiSmoother : public Solver< OperatorType >
+{
+ public:
+   MixedPrecisionJacobiSmoother( const std::shared_ptr< PrimitiveStorage >& storage, uint_t minLevel, uint_t maxLevel, double relax, uint_t fp32Sweeps = 2 )
+   : storage_( storage )
+   , relax_( relax )
+   , fp32Sweeps_( fp32Sweeps )
+   , r_( "mixed_jacobi_r", storage, minLevel, maxLevel )
+   , tmp_( "mixed_jacobi_tmp", storage, minLevel, maxLevel )
+   , flag_( Inner | NeumannBoundary )
+   {}
+   ~MixedPrecisionJacobiSmoother() override
+   {
+      for ( auto& kv : buffers_ )
+         for ( float* q : kv.second )
+            hyteg_hip_free( q );
+   }
+   void solve( const OperatorType& A, const P1Function< double >& x, const P1Function< double >& b, uint_t level ) override
+   {
+      if ( level >= HYTEG_HIP_MIN_LEVEL && level <= 10 && fp32Sweeps_ > 0 )
+      {
+         A.apply( x, r_, level, flag_ );
+         r_.assign( { 1.0, -1.0 }, { b, r_ }, level, flag_ );
+         const size_t n = (size_t) layout::cellSize( (int) level );
+         for ( uint_t c = 0; c < storage_->getNumberOfLocalCells(); ++c )
+         {
+            float**     f  = buffersFor( c, level ); // rf, e0, e1
+            const auto& st = A.getCellStencils( storage_->getLocalCell( c ).id, level );
+            auto        s  = storage_->stream();
+            hipCheck( hyteg_hip_convert_f64_to_f32( f[0], r_.getCellPointer( c, level ), n, s ), "mixed Jacobi: convert residual" );
+            hipCheck( hyteg_hip_memset_zero( f[1], n * sizeof( float ), s ), "mixed Jacobi: zero" );
+            float *src = f[1], *dst = f[2]; // f[2]'s boundary entries are zero since its allocation, its interior is overwritten
+            for ( uint_t k = 0; k < fp32Sweeps_; ++k )
+            {
+               hipCheck( hyteg_hip_p1_jacobi_cell_f32( dst, f[0], src, nullptr, (int) level, st.inner, relax_, s ), "mixed Jacobi: float sweep" );
+               std::swap( src, dst );
+            }
+            hipCheck( hyteg_hip_axpy_f32_into_f64( x.getCellPointer( c, level ), src, 1.0, n, s ), "mixed Jacobi: correction" );
+         }
+      }
+      tmp_.assign( { 1.0 }, { x }, level, All );
+      A.smooth_jac( x, b, tmp_, relax_, level, flag_ );
+   }
+
+ private:
+   float** buffersFor( uint_t c, uint_t level )
+   {
+      auto key = std::make_pair( c, level );
+      auto it  = buffers_.find( key );
+      if ( it == buffers_.end() )
+      {
+         const size_t         bytes = (size_t) layout::cellSize( (int) level ) * sizeof( float );
+         std::vector< float* > v;
+         for ( int k = 0; k < 3; ++k )
+         {
+            void* q = nullptr;
+            hipCheck( hyteg_hip_malloc( &q, bytes ), "mixed Jacobi: malloc" );
+            hipCheck( hyteg_hip_memset_zero( q, bytes, storage_->stream() ), "mixed Jacobi: zero" );
+            v.push_back( static_cast< float* >( q ) );
+         }
+         it = buffers_.emplace( key, v ).first;
+      }
+      return it->second.data();
+   }
+   std::shared_ptr< PrimitiveStorage >                         storage_;
+   double                                                      relax_;
+   uint_t                                                      fp32Sweeps_;
+   P1Function< double >                                        r_, tmp_;
+   DoFType                                                     flag_;
+   std::map< std::pair< uint_t, uint_t >, std::vector< float* > > buffers_;
+};
+
 // GaussSeidelSmoother.hpp:38-50, SORSmoother.hpp:33-46
 template < class OperatorType >
 class SORSmoother : public Solver< OperatorType >
@@ -314,6 +397,7 @@ class GeometricMultigridSolver : public Solver< OperatorType >
 
    void solve( const OperatorType& A, const FunctionType& x, const FunctionType& b, uint_t level ) override
    {
+      ScopedTimer timerGmg( storage_->getTimingTree(), "Geometric Multigrid Solver" );
       invokedLevel_ = level;
       if ( !graphsUsable() )
       {
@@ -416,8 +500,11 @@ class GeometricMultigridSolver : public Solver< OperatorType >
       storage_->setStream( user );
    }
 
+   // timer names and nesting of GeometricMultigridSolver.hpp:200-300
    void solveRecursively( const OperatorType& A, const FunctionType& x, const FunctionType& b, uint_t level )
    {
+      TimingTree*       tt        = recording_ ? nullptr : storage_->getTimingTree();
+      const std::string levelName = "Level " + std::to_string( level );
       if ( level == minLevel_ )
       {
          if ( recording_ )
@@ -426,22 +513,40 @@ class GeometricMultigridSolver : public Solver< OperatorType >
             beginSegment();
          }
          else
+         {
+            ScopedTimer tl( tt, levelName ), tc( tt, "Coarse Grid Solver" );
             coarseSolver_->solve( A, x, b, minLevel_ );
+         }
          return;
       }
       const uint_t pre = preSmoothSteps_ + smoothIncrement_ * ( invokedLevel_ - level );
-      smoother_->solveSteps( A, x, b, level, pre );
-      A.apply( x, tmp_, level, flag_ );
-      tmp_.assign( { 1.0, -1.0 }, { b, tmp_ }, level, flag_ );
-      restrictionOperator_->restrict( tmp_, level, flag_ );
-      b.assign( { 1.0 }, { tmp_ }, level - 1, flag_ );
-      x.interpolate( 0.0, level - 1 );
+      {
+         ScopedTimer tl( tt, levelName ), ts( tt, "Smoother" );
+         smoother_->solveSteps( A, x, b, level, pre );
+      }
+      {
+         ScopedTimer tl( tt, levelName ), tr( tt, "Residual" );
+         A.apply( x, tmp_, level, flag_ );
+         tmp_.assign( { 1.0, -1.0 }, { b, tmp_ }, level, flag_ );
+      }
+      {
+         ScopedTimer tl( tt, levelName ), tr( tt, "Restriction" );
+         restrictionOperator_->restrict( tmp_, level, flag_ );
+         b.assign( { 1.0 }, { tmp_ }, level - 1, flag_ );
+         x.interpolate( 0.0, level - 1 );
+      }
       solveRecursively( A, x, b, level - 1 );
       if ( cycleType_ == CycleType::WCYCLE )
          solveRecursively( A, x, b, level - 1 );
-      prolongationOperator_->prolongateAndAdd( x, level - 1, flag_ );
+      {
+         ScopedTimer tl( tt, levelName ), tp( tt, "Prolongation" );
+         prolongationOperator_->prolongateAndAdd( x, level - 1, flag_ );
+      }
       const uint_t post = postSmoothSteps_ + smoothIncrement_ * ( invokedLevel_ - level );
-      smoother_->solveSteps( A, x, b, level, post );
+      {
+         ScopedTimer tl( tt, levelName ), ts( tt, "Smoother" );
+         smoother_->solveSteps( A, x, b, level, post );
+      }
    }
 
    uint_t                                       minLevel_, maxLevel_, preSmoothSteps_, postSmoothSteps_, smoothIncrement_;

@@ -5,6 +5,7 @@
 
 #include "comm.hpp"
 #include "mesh.hpp"
+#include "timing.hpp"
 
 namespace hyteg {
 
@@ -251,7 +252,26 @@ class PrimitiveStorage
          fn( first, std::min( HYTEG_HIP_MAX_BATCH, n - first ) );
    }
 
-   void              setStream( hyteg_hip_stream_t s ) { stream_ = s; }
+   void              setStream( hyteg_hip_stream_t s )
+   {
+      stream_ = s;
+      if ( timingTree_ )
+         timingTree_->setStream( s );
+   }
+   // PrimitiveStorage::getTimingTree(): null unless enabled (a disabled tree costs one pointer test per range).
+   // synchronize: every range waits for the stream before it stops, so that it measures execution, not enqueueing.
+   void enableTiming( bool on, bool synchronize = false )
+   {
+      if ( !on )
+      {
+         timingTree_.reset();
+         return;
+      }
+      if ( !timingTree_ )
+         timingTree_ = std::make_shared< TimingTree >();
+      timingTree_->setSynchronize( synchronize, stream_ );
+   }
+   TimingTree* getTimingTree() const { return timingTree_.get(); }
    hyteg_hip_stream_t stream() const { return stream_; }
    // ---- transport of the shared-point exchange (storages distributed over several ranks) ----
    void setCommHooks( const CommHooks& h ) { transport_ = std::make_shared< HookTransport >( h ); }
@@ -661,6 +681,7 @@ class PrimitiveStorage
    DoFType                                                 boundaryType_ = DirichletBoundary;
    hyteg_hip_stream_t                                      stream_       = nullptr;
    std::shared_ptr< Transport >                            transport_;
+   std::shared_ptr< TimingTree >                           timingTree_;
    mutable void *                                          dotResult_ = nullptr, *dotWorkspace_ = nullptr;
    mutable std::map< size_t, std::vector< double* > >      scratchFree_;
    mutable std::vector< void* >                            scratchAll_;

@@ -127,6 +127,26 @@ HYTEG_HIP_API int hyteg_hip_p1_apply_cell( double*            dst,
                                            int                update,
                                            hyteg_hip_stream_t stream );
 
+/* ---- float instantiations of a2 / a4 and mixed-precision support -------------------------------------------------
+ * The reference instantiates its generated apply kernels for float32 as well
+ *   src/constant_stencil_operator/P1generatedKernels/apply_3D_macrocell_vertexdof_to_vertexdof_replace.cpp:96-97
+ * (its generated SOR / Gauss-Seidel kernels are double only, sor_3D_macrocell_P1.cpp).  Arrays of float in the same
+ * macro-cell layout; weights are given as doubles and converted; the arithmetic is float.  Levels 2..10. */
+HYTEG_HIP_API int hyteg_hip_p1_apply_cell_f32( float* dst, const float* src, int level, const double* w /* host, 15 */, int update, hyteg_hip_stream_t stream );
+HYTEG_HIP_API int hyteg_hip_p1_jacobi_cell_f32( float*             dst,
+                                                const float*       rhs,
+                                                const float*       src,
+                                                const float*       invdiag /* device or NULL */,
+                                                int                level,
+                                                const double*      w /* host, 15 */,
+                                                double             relax,
+                                                hyteg_hip_stream_t stream );
+/* flat conversions and y (double) += alpha * x (float): VertexDoFFunction::copyFrom between value types
+ * (src/hyteg/p1functionspace/VertexDoFFunction.hpp:598-650) on device arrays of n entries */
+HYTEG_HIP_API int hyteg_hip_convert_f64_to_f32( float* dst, const double* src, size_t n, hyteg_hip_stream_t stream );
+HYTEG_HIP_API int hyteg_hip_convert_f32_to_f64( double* dst, const float* src, size_t n, hyteg_hip_stream_t stream );
+HYTEG_HIP_API int hyteg_hip_axpy_f32_into_f64( double* y, const float* x, double alpha, size_t n, hyteg_hip_stream_t stream );
+
 /* Name of the kernel instantiation hyteg_hip_p1_apply_cell( ..., level, ..., update, ... ) launches on the current device,
  * with its template arguments, e.g. "p1_apply_zmarch_kernel<MODE=0,NY=4,LZ=8,EX_AUX=0,DEC=1,PFD=1>" — what profiler
  * output and recorded counter files are matched against (no reference counterpart: measurement support). */

@@ -47,6 +47,16 @@ HYTEG_HOST_API int hyteg_host_storage_set_stream( hh_storage_t s, void* stream )
 /* levels <= `level` use the batched kernels (one launch for all local cells, inner and boundary points together) when the
  * rank owns more than one cell; -1 disables batching.  Default 6, or the environment variable HYTEG_AMD_BATCH_MAX_LEVEL. */
 HYTEG_HOST_API int hyteg_host_storage_set_batch_max_level( hh_storage_t s, int level );
+/* Timing tree with the reference's timer names (walberla::WcTimingTree behind PrimitiveStorage::getTimingTree():
+ * "Operator P1Function to P1Function" / "Apply", "smooth_jac", "SOR"; "P1Function" / "Assign", "Dot (local)" ...;
+ * "Geometric Multigrid Solver" / "Level L" / "Smoother" ...; src/hyteg/operators/Operator.hpp:148-166,
+ * GeometricMultigridSolver.hpp:200-300) and its JSON dump (src/hyteg/dataexport/TimingOutput.hpp:46-60).  Off by default.
+ * synchronize != 0: every range waits for the device before it stops (measures execution instead of enqueueing).
+ * HYTEG_AMD_ROCTX=1 in the environment additionally emits roctx ranges with the same names.
+ * timing_json: writes at most buflen bytes (NUL-terminated), *needed receives the size of the complete text. */
+HYTEG_HOST_API int hyteg_host_storage_enable_timing( hh_storage_t s, int on, int synchronize );
+HYTEG_HOST_API int hyteg_host_storage_timing_json( hh_storage_t s, char* buf, size_t buflen, size_t* needed );
+HYTEG_HOST_API int hyteg_host_storage_timing_reset( hh_storage_t s );
 /* Transport of the shared-point exchange of a storage distributed over several ranks (one process per GPU).
  * (a) RCCL over xGMI issued from the host layer itself: neighbour send/recv groups on a communication stream, ordered
  *     against the compute stream with events; all-reduce of dot products.  unique_id: HYTEG_HIP_COMM_ID_BYTES bytes from

@@ -128,6 +128,60 @@ HO_API void ho_apply_cell( double* dst, const double* src, int level, const doub
          }
 }
 
+/* float32 instantiation of the same kernel (apply_3D_macrocell_vertexdof_to_vertexdof_replace.cpp:96-97 instantiates the
+ * template for walberla::float32; the stencil map then holds floats): same term order, float arithmetic.  The weights
+ * arrive as doubles and are rounded to float first, as a std::map< Index, float > filled from real_t values would hold them. */
+HO_API void ho_apply_cell_f32( float* dst, const float* src, int level, const double* wd, int update )
+{
+   const int64_t N = ho_width( level );
+   const int     n = 1 << level;
+   float         w[15];
+   for ( int k = 0; k < 15; ++k )
+      w[k] = (float) wd[k];
+   for ( int z = 1; z < n; ++z )
+      for ( int y = 1; y < n - z; ++y )
+         for ( int x = 1; x < n - y - z; ++x )
+         {
+#define S( dx, dy, dz ) src[cell_index_w( N, x + ( dx ), y + ( dy ), z + ( dz ) )]
+            float acc = w[W_W] * S( -1, 0, 0 );
+            acc       = acc + w[W_BN] * S( 0, 1, -1 );
+            acc       = acc + w[W_N] * S( 0, 1, 0 );
+            acc       = acc + w[W_SE] * S( 1, -1, 0 );
+            acc       = acc + w[W_TSE] * S( 1, -1, 1 );
+            acc       = acc + w[W_BE] * S( 1, 0, -1 );
+            acc       = acc + w[W_E] * S( 1, 0, 0 );
+            acc       = acc + w[W_TW] * S( -1, 0, 1 );
+            acc       = acc + w[W_BNW] * S( -1, 1, -1 );
+            acc       = acc + w[W_NW] * S( -1, 1, 0 );
+            acc       = acc + w[W_S] * S( 0, -1, 0 );
+            acc       = acc + w[W_TS] * S( 0, -1, 1 );
+            acc       = acc + w[W_BC] * S( 0, 0, -1 );
+            acc       = acc + w[W_C] * S( 0, 0, 0 );
+            acc       = acc + w[W_TC] * S( 0, 0, 1 );
+#undef S
+            const int64_t i = cell_index_w( N, x, y, z );
+            dst[i]          = update ? acc + dst[i] : acc;
+         }
+}
+/* smooth_jac (P1Operator.hpp:429-447) in float: apply, rhs - dst, * invdiag, src + relax * ( . ) */
+HO_API void ho_jacobi_cell_f32( float* dst, const float* rhs, const float* src, const float* invdiag, int level, const double* wd,
+                                double relax )
+{
+   ho_apply_cell_f32( dst, src, level, wd, 0 );
+   const int64_t N    = ho_width( level );
+   const int     n    = 1 << level;
+   const float   invC = (float) ( 1.0 / wd[W_C] ), rx = (float) relax;
+   for ( int z = 1; z < n; ++z )
+      for ( int y = 1; y < n - z; ++y )
+         for ( int x = 1; x < n - y - z; ++x )
+         {
+            const int64_t i = cell_index_w( N, x, y, z );
+            float         t = rhs[i] - dst[i];
+            t               = ( invdiag ? invdiag[i] : invC ) * t;
+            dst[i]          = src[i] + rx * t;
+         }
+}
+
 /* ---------------------------------------------------------------------------------------------
  * a3: in-place lexicographic SOR / Gauss-Seidel sweeps on the cell interior.
  * src/constant_stencil_operator/P1generatedKernels/sor_3D_macrocell_P1.cpp:32-90 (update at :74):

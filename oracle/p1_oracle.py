@@ -61,6 +61,8 @@ def _bind(lib):
         "ho_restrict_cell": (None, [_P, _P, i, _P]),
         "ho_prolongate_prepare": (None, [_P, i, i]),
         "ho_prolongate_cell": (None, [_P, _P, i, _P]),
+        "ho_apply_cell_f32": (None, [C.c_void_p, C.c_void_p, C.c_int, _P, C.c_int]),
+        "ho_jacobi_cell_f32": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, _P, C.c_double]),
         "ho_p1_tet_diffusion": (None, [_P, _P]),
         "ho_p1_tet_mass": (None, [_P, _P]),
         "ho_p1_tet_div": (None, [_P, _P, C.c_int]),
@@ -175,6 +177,20 @@ def inner_mask(level):
 # ---- kernels ---------------------------------------------------------------------------------
 def apply_cell(dst, src, level, w, update=REPLACE, fast=False):
     lib(fast).ho_apply_cell(_p(dst), _p(src), level, _p(_w(w)), update)
+    return dst
+
+
+def apply_cell_f32(dst, src, level, w, update=REPLACE):
+    """float32 arrays (numpy float32, contiguous)"""
+    assert dst.dtype == np.float32 and src.dtype == np.float32
+    lib().ho_apply_cell_f32(dst.ctypes.data, src.ctypes.data, level, _p(_w(w)), update)
+    return dst
+
+
+def jacobi_cell_f32(dst, rhs, src, level, w, relax, invdiag=None):
+    assert dst.dtype == rhs.dtype == src.dtype == np.float32
+    lib().ho_jacobi_cell_f32(dst.ctypes.data, rhs.ctypes.data, src.ctypes.data, None if invdiag is None else invdiag.ctypes.data, level,
+                             _p(_w(w)), float(relax))
     return dst
 
 

@@ -1,0 +1,139 @@
+"""float32 instantiations of the apply / fused Jacobi kernels and the mixed-precision smoother (BASELINE config 5's "fp32
+smoother"; VERDICT r01 missing item 5).  The reference instantiates its generated apply kernels for float
+(apply_3D_macrocell_vertexdof_to_vertexdof_replace.cpp:96-97); the oracle restates that instantiation in C with float
+arithmetic in the reference's term order.  Tolerance: float arithmetic, 15-term sums in another order and FMA contraction
+on the GPU -> relative L2 <= 2e-6 against the float oracle (written here because north_star's 1e-12 is the fp64 bar)."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+REF_TET = ((0.0, 0.0, 0.0), (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0))
+SKEW_TET = ((0.1, -0.2, 0.05), (1.3, 0.1, -0.1), (0.4, 1.1, 0.2), (-0.2, 0.3, 0.9))
+F32_TOL = 2e-6
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    from hyteg_amd import capi, host
+    from oracle import p1_oracle as po
+
+    assert torch.cuda.is_available()
+    capi.lib()
+    host.lib()
+    return torch, capi, host, po
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("level", [2, 3, 5, 7, 8])
+@pytest.mark.parametrize("tet", [REF_TET, SKEW_TET])
+def test_apply_f32_matches_the_float_oracle(env, level, tet):
+    torch, capi, host, po = env
+    n = po.cell_size(level)
+    rng = np.random.default_rng(level)
+    w = po.assemble_cell_stencil(tet, level) if level < 8 else rng.random(15) - 0.5
+    src_h = rng.random(n).astype(np.float32)
+    dst0 = rng.random(n).astype(np.float32)
+    src = torch.from_numpy(src_h).cuda()
+    for update in (capi.REPLACE, capi.ADD):
+        dst = torch.from_numpy(dst0).cuda()
+        capi.p1_apply_cell_f32(dst.data_ptr(), src.data_ptr(), level, w, update)
+        torch.cuda.synchronize()
+        ref = dst0.copy()
+        po.apply_cell_f32(ref, src_h, level, w, update)
+        got = dst.cpu().numpy()
+        inner = (po.slot_of_points(level) == 14) if level <= 5 else None
+        if inner is not None:
+            assert np.array_equal(got[~inner], dst0[~inner])  # boundary entries untouched
+        assert _rel(got, ref) < F32_TOL
+    # and the float result is the double result to float accuracy
+    d = np.zeros(n)
+    po.apply_cell(d, src_h.astype(np.float64), level, w)
+    dst = torch.zeros(n, dtype=torch.float32, device="cuda")
+    capi.p1_apply_cell_f32(dst.data_ptr(), src.data_ptr(), level, w, capi.REPLACE)
+    assert _rel(dst.cpu().numpy(), d) < 5e-6
+
+
+@pytest.mark.parametrize("level", [3, 6, 8])
+def test_jacobi_f32_matches_the_float_oracle(env, level):
+    torch, capi, host, po = env
+    n = po.cell_size(level)
+    rng = np.random.default_rng(10 + level)
+    w = po.assemble_cell_stencil(SKEW_TET, level)
+    src_h, rhs_h = rng.random(n).astype(np.float32), (rng.random(n) * w[7]).astype(np.float32)
+    inv_h = (1.0 / (w[7] * (1.0 + 0.1 * rng.random(n)))).astype(np.float32)
+    src, rhs, inv = (torch.from_numpy(a).cuda() for a in (src_h, rhs_h, inv_h))
+    for invdiag_t, invdiag_h in ((None, None), (inv, inv_h)):
+        dst = torch.zeros(n, dtype=torch.float32, device="cuda")
+        capi.p1_jacobi_cell_f32(dst.data_ptr(), rhs.data_ptr(), src.data_ptr(), level, w, 2.0 / 3.0,
+                                None if invdiag_t is None else invdiag_t.data_ptr())
+        torch.cuda.synchronize()
+        ref = np.zeros(n, dtype=np.float32)
+        po.jacobi_cell_f32(ref, rhs_h, src_h, level, w, 2.0 / 3.0, invdiag_h)
+        assert _rel(dst.cpu().numpy(), ref) < F32_TOL
+
+
+def test_conversions_and_mixed_axpy(env):
+    torch, capi, host, po = env
+    n = 100003
+    rng = np.random.default_rng(3)
+    a = torch.from_numpy(rng.random(n) * 1e3 - 500.0).cuda()
+    f = torch.zeros(n, dtype=torch.float32, device="cuda")
+    capi.convert_f64_to_f32(f.data_ptr(), a.data_ptr(), n)
+    assert torch.equal(f, a.to(torch.float32))  # round to nearest, like a C cast
+    b = torch.zeros(n, dtype=torch.float64, device="cuda")
+    capi.convert_f32_to_f64(b.data_ptr(), f.data_ptr(), n)
+    assert torch.equal(b, f.to(torch.float64))
+    y = torch.from_numpy(rng.random(n)).cuda()
+    y0 = y.clone()
+    capi.axpy_f32_into_f64(y.data_ptr(), f.data_ptr(), -0.25, n)
+    assert torch.allclose(y, y0 - 0.25 * f.to(torch.float64), rtol=0, atol=1e-13 * 500)
+
+
+@pytest.mark.parametrize("mesh", ["tet_1el", "regular_octahedron_8el"])
+def test_multigrid_with_the_fp32_smoother_converges_like_the_fp64_one(env, mesh):
+    """V(3,3) cycles with MixedPrecisionJacobiSmoother against the same cycles with the double Jacobi smoother: the
+    iterate and the residual are kept in double (defect correction), so the residual keeps falling far below float
+    accuracy, and a cycle is at least as effective as with 3 plain double sweeps (it does more work per step)"""
+    torch, capi, host, po = env
+    from hostutil import MultiCellOracle, upload
+
+    max_level = 5
+    st = host.Storage.from_gmsh(ROOT / "hyteg_amd" / "data" / "meshes" / f"{mesh}.msh")
+    mo = MultiCellOracle(st)
+    A = host.P1ConstantOperator(st, 2, max_level)
+    A.compute_inverse_diagonal()
+    hist = {}
+    for smoother in (host.JACOBI, host.JACOBI_FP32):
+        u, b, r = (host.P1Function(st, n_, 2, max_level) for n_ in ("u", "b", "r"))
+        upload(u, mo.interpolate(lambda x, y, z: np.sin(7 * x) * np.cos(5 * y) + z, max_level), max_level)
+        u.interpolate(0.0, max_level, host.DirichletBoundary)
+        b.interpolate(0.0, max_level, host.All)
+        gmg = host.Solver.gmg(st, 2, max_level, smoother=smoother, relax=2.0 / 3.0, pre=3, post=3)
+        res = []
+        for _ in range(8):
+            A.apply(u, r, max_level, host.Inner)
+            res.append(np.sqrt(r.dot(r, max_level, host.Inner)))
+            gmg.solve(A, u, b, max_level)
+        A.apply(u, r, max_level, host.Inner)
+        res.append(np.sqrt(r.dot(r, max_level, host.Inner)))
+        hist[smoother] = res
+        for o in (gmg, u, b, r):
+            o.close()
+    f64, f32 = hist[host.JACOBI], hist[host.JACOBI_FP32]
+    assert f32[-1] < 2e-8 * f32[0], f32           # below float accuracy (6e-8): the float part only computes corrections
+    assert all(f32[i + 1] < 0.2 * f32[i] for i in range(8)), f32  # and still falling at the same rate in the last cycle
+    assert f32[-1] <= 1.05 * f64[-1], (f32, f64)  # at least as effective per cycle as the double smoother
+    for o in (A, st):
+        o.close()

@@ -11,7 +11,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 src = Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "gpurun_out" / "pmc_bench"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
 COPY_BYTES = 2862209 * 8  # one level-8 cell array, read once and written once by the calibration copy kernel
 
 
@@ -36,8 +36,8 @@ def mean_counter(prefix, kernel_substr, counter):
 
 fetch, nf = mean_counter("bench", "p1_apply_zmarch_kernel", "FETCH_SIZE")
 write, nw = mean_counter("bench", "p1_apply_zmarch_kernel", "WRITE_SIZE")
-cfetch, _ = mean_counter("calib", "copy_w_kernel<double, false>", "FETCH_SIZE")
-cwrite, _ = mean_counter("calib", "copy_w_kernel<double, false>", "WRITE_SIZE")
+cfetch, _ = mean_counter("calib", "calib_copy_kernel<false>", "FETCH_SIZE")
+cwrite, _ = mean_counter("calib", "calib_copy_kernel<false>", "WRITE_SIZE")
 kname = None
 for f in newest_per_pass("bench"):
     for r in csv.DictReader(open(f)):
@@ -48,14 +48,39 @@ for f in newest_per_pass("bench"):
         break
 if None in (fetch, write, cfetch, cwrite):
     raise SystemExit(f"missing counters under {src}: fetch={fetch} write={write} calib fetch={cfetch} write={cwrite}")
+
+
+def capi_kernel_name(rocprof_name):
+    """'void hyteg_hip::p1_apply_zmarch_kernel<0, 4, 8, 0, false, 2, double>' -> the form hyteg_hip_p1_apply_kernel_name
+    (and bench.py's roofline.kernel) uses: 'p1_apply_zmarch_kernel<MODE=0,NY=4,LZ=8,EX_AUX=0,DEC=0,PFD=2>'"""
+    import re
+
+    m = re.search(r"p1_apply_zmarch_kernel<([^>]*)>", rocprof_name)
+    if not m:
+        return None
+    a = [x.strip() for x in m.group(1).split(",")]
+    dec = {"false": "0", "true": "1"}.get(a[4], a[4])
+    name = f"p1_apply_zmarch_kernel<MODE={a[0]},NY={a[1]},LZ={a[2]},EX_AUX={a[3]},DEC={dec},PFD={a[5]}>"
+    return name if len(a) < 7 or a[6] == "double" else name[:-1] + f",T={a[6]}>"
+
+
+import subprocess
+
+try:
+    git_head = subprocess.run(["git", "-C", str(ROOT), "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+except Exception:  # noqa: BLE001
+    git_head = None
 kf, kw = COPY_BYTES / (cfetch * 1024), COPY_BYTES / (cwrite * 1024)
 read_b, write_b = fetch * 1024 * kf, write * 1024 * kw
 alg = 2731135 * 16
 out = {
-    "p1_apply_zmarch_kernel_bytes_per_launch": int(round(read_b + write_b)),
+    "bytes_per_launch": int(round(read_b + write_b)),
+    "kernel_name": capi_kernel_name(kname),
+    "level": 8,
+    "git_head": git_head,
     "read_bytes": int(round(read_b)),
     "write_bytes": int(round(write_b)),
-    "kernel": kname,
+    "kernel_as_rocprof_names_it": kname,
     "method": "rocprofv3 --kernel-trace --pmc, separate passes for FETCH_SIZE and WRITE_SIZE over `python3 bench.py --steps 200 "
               f"--warmup 20 --no-cpu-baseline` ({nf} / {nw} dispatches, level 8, rotating buffers); counters are in KiB "
               "(hyteg_amd/csrc/exp/pmc_bench.sh, tools/pmc_traffic.py)",
