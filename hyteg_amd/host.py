@@ -96,6 +96,7 @@ SIGNATURES = {
     "hyteg_host_p2function_assign": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(_vp), _i, _i]),
     "hyteg_host_p2function_add": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(_vp), _i, _i]),
     "hyteg_host_p2function_dot": (_i, [_vp, _vp, _i, _i, C.POINTER(_d)]),
+    "hyteg_host_p2operator_create_constant": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
     "hyteg_host_p2operator_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
     "hyteg_host_p2operator_destroy": (_i, [_vp]),
     "hyteg_host_p2operator_element_matrices": (_i, [_vp, _i, _i, _vp]),
@@ -598,10 +599,12 @@ class P2Function:
 
 
 class P2ElementwiseLaplaceOperator:
+    _create = "hyteg_host_p2operator_create"
+
     def __init__(self, storage: Storage, min_level: int, max_level: int):
         self.storage = storage
         h = _vp()
-        _ck(lib().hyteg_host_p2operator_create(storage.h, min_level, max_level, C.byref(h)), "P2ElementwiseLaplaceOperator")
+        _ck(getattr(lib(), self._create)(storage.h, min_level, max_level, C.byref(h)), type(self).__name__)
         self.h = h
 
     def element_matrices(self, level, cell=0):
@@ -621,3 +624,8 @@ class P2ElementwiseLaplaceOperator:
         if self.h:
             lib().hyteg_host_p2operator_destroy(self.h)
             self.h = None
+
+
+class P2ConstantLaplaceOperator(P2ElementwiseLaplaceOperator):
+    """hyteg::P2ConstantLaplaceOperator: the four constant-stencil sub-operators in one kernel pass"""
+    _create = "hyteg_host_p2operator_create_constant"

@@ -659,6 +659,12 @@ HYTEG_HOST_API int hyteg_host_p2operator_create( hh_storage_t s, int minL, int m
       *out = new P2OperatorH{ std::make_shared< P2ElementwiseLaplaceOperator >( static_cast< StorageH* >( s )->p, (uint_t) minL, (uint_t) maxL ) };
    } );
 }
+HYTEG_HOST_API int hyteg_host_p2operator_create_constant( hh_storage_t s, int minL, int maxL, hh_p2operator_t* out )
+{
+   return guarded( [&] {
+      *out = new P2OperatorH{ std::make_shared< P2ConstantLaplaceOperator >( static_cast< StorageH* >( s )->p, (uint_t) minL, (uint_t) maxL ) };
+   } );
+}
 HYTEG_HOST_API int hyteg_host_p2operator_destroy( hh_p2operator_t op )
 {
    return guarded( [&] { delete static_cast< P2OperatorH* >( op ); } );

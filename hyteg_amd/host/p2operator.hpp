@@ -85,8 +85,6 @@ class P2ElementwiseOperator
    , minLevel_( minLevel )
    , maxLevel_( maxLevel )
    {
-      if ( storage->numRanks() != 1 )
-         throw std::runtime_error( "P2ElementwiseOperator: storages distributed over several ranks are not supported in this version" );
       // micro-cell vertex offsets of the six cell types, celldof::macrocell::getMicroVerticesFromMicroCell (CellDoFIndexing.hpp:155-198)
       static const int verts[6][4][3] = {
           { { 0, 0, 0 }, { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } }, { { 1, 0, 0 }, { 1, 1, 0 }, { 0, 1, 0 }, { 1, 0, 1 } },
@@ -128,7 +126,7 @@ class P2ElementwiseOperator
    {
       if ( &src == &dst )
          throw std::runtime_error( "P2ElementwiseOperator::gemv: src and dst must differ" );
-      const bool shared = storage_->getNumberOfLocalCells() > 1;
+      const bool shared = storage_->getCells().size() > 1; // also a rank with one cell shares DoFs with cells of other ranks
       if ( !shared )
       {
          if ( beta != 0.0 && beta != 1.0 )
@@ -171,5 +169,22 @@ class P2ElementwiseOperator
    std::map< uint_t, std::vector< std::vector< double > > >     hostMatrices_;
 };
 using P2ElementwiseLaplaceOperator = P2ElementwiseOperator< forms::P2LaplaceForm >; // P2ElementwiseOperator.hpp:454
+
+// P2ConstantOperator< P2Form > (src/constant_stencil_operator/P2ConstantOperator.hpp; apply = the four sub-operators
+// VertexToVertex, EdgeToVertex, VertexToEdge, EdgeToEdge, P2ConstantOperator.cpp:100-112, each a constant stencil per
+// macro-primitive assembled from the element matrices of the adjacent micro-cells).  On the affine macro-cells of this
+// path those stencils are exactly what hyteg_hip_p2_build_operator_table sums for the gather kernel -- one constant stencil
+// per destination kind (vertex DoF, edge DoF of each of the 7 orientations) and point class, covering all four
+// sub-operators in one pass over the DoFs -- so the constant-stencil operator launches the same kernel as the elementwise
+// one and gives the same numbers (the reference pins that equivalence in tests/hyteg/convergence/P2JacobiConvergenceTest.cpp
+// and operators/ElementwiseOperatorAdditiveApplyTest.cpp).  A separate type so that code written against
+// P2ConstantLaplaceOperator compiles unchanged.
+template < class P2Form >
+class P2ConstantOperator : public P2ElementwiseOperator< P2Form >
+{
+ public:
+   using P2ElementwiseOperator< P2Form >::P2ElementwiseOperator;
+};
+using P2ConstantLaplaceOperator = P2ConstantOperator< forms::P2LaplaceForm >; // P2ConstantOperator.hpp
 
 } // namespace hyteg

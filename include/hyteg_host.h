@@ -172,6 +172,9 @@ HYTEG_HOST_API int hyteg_host_p2function_assign( hh_p2function_t dst, int n, con
 HYTEG_HOST_API int hyteg_host_p2function_add( hh_p2function_t dst, int n, const double* scalars, const hh_p2function_t* srcs, int level, int flag );
 HYTEG_HOST_API int hyteg_host_p2function_dot( hh_p2function_t a, hh_p2function_t b, int level, int flag, double* result );
 HYTEG_HOST_API int hyteg_host_p2operator_create( hh_storage_t s, int min_level, int max_level, hh_p2operator_t* out );
+/* P2ConstantLaplaceOperator (src/constant_stencil_operator/P2ConstantOperator.hpp): same handle type and calls as the
+ * elementwise operator; on affine macro-cells the assembled constant stencils ARE what the kernel's operator table holds */
+HYTEG_HOST_API int hyteg_host_p2operator_create_constant( hh_storage_t s, int min_level, int max_level, hh_p2operator_t* out );
 HYTEG_HOST_API int hyteg_host_p2operator_destroy( hh_p2operator_t op );
 /* the six 10 x 10 element matrices (FEniCS ordering) of a local cell at `level` */
 HYTEG_HOST_API int hyteg_host_p2operator_element_matrices( hh_p2operator_t op, int local_cell, int level, double* out600 );
