@@ -86,6 +86,8 @@ SIGNATURES = {
     "hyteg_hip_p2_edge_array_size": (C.c_size_t, [_i]),
     "hyteg_hip_p2_operator_table_size": (C.c_size_t, []),
     "hyteg_hip_p2_build_operator_table": (_i, [_dp, _dp]),
+    "hyteg_hip_p2_prolongate_cell": (_i, [_vp, _vp, _vp, _vp, _i, _i, C.c_uint, _vp]),
+    "hyteg_hip_p2_restrict_cell": (_i, [_vp, _vp, _vp, _vp, _i, _dp, C.c_uint, _vp]),
     "hyteg_hip_p2_edge_vector_cell_masked": (_i, [_i, _vp, _i, C.POINTER(_vp), _dp, _i, C.c_uint, _vp]),
     "hyteg_hip_p2_edge_dot_cell_masked": (_i, [_vp, _vp, _i, C.c_uint, _vp, _vp, _vp]),
     "hyteg_hip_p2_elementwise_apply_cell": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _d, _i, C.c_uint, _vp]),
@@ -223,6 +225,15 @@ def p1_apply_kernel_name(level, update=REPLACE) -> str:
     buf = C.create_string_buffer(256)
     check(lib().hyteg_hip_p1_apply_kernel_name(level, update, buf, 256), "p1_apply_kernel_name")
     return buf.value.decode()
+
+
+def p2_prolongate_cell(fine_v, fine_e, coarse_v, coarse_e, coarse_level, update=REPLACE, mask=0x7FFF, stream=0):
+    check(lib().hyteg_hip_p2_prolongate_cell(fine_v, fine_e, coarse_v, coarse_e, coarse_level, update, mask, stream), "p2_prolongate_cell")
+
+
+def p2_restrict_cell(coarse_v, coarse_e, fine_v, fine_e, coarse_level, nnc, mask=0x7FFF, stream=0):
+    a = (C.c_double * 14)(*[float(x) for x in nnc])
+    check(lib().hyteg_hip_p2_restrict_cell(coarse_v, coarse_e, fine_v, fine_e, coarse_level, a, mask, stream), "p2_restrict_cell")
 
 
 def p1_apply_cell_f32(dst, src, level, w, update=REPLACE, stream=0):

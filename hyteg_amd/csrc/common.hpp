@@ -84,7 +84,8 @@ static_assert( sizeof( Tile ) == 32, "Tile must be 32 bytes" );
 enum TileKind
 {
    TILES_INNER = 0, // cover rows 1..W-3 of slices 1..N-3 (the range the interior kernels loop over)
-   TILES_FULL  = 1  // cover every entry of the array
+   TILES_FULL  = 1, // cover every entry of the array
+   TILES_ROWS  = 2  // one tile = up to `capacity` consecutive entries of ONE row: a = index of (x0, y, z), ya = y, yb = x0
 };
 
 struct TileTable

@@ -405,7 +405,7 @@ HYTEG_HIP_API int hyteg_hip_prepare_level( int level )
    rc = get_tiles( level, TILES_FULL, kTile, &tt );
    if ( rc != HYTEG_HIP_OK )
       return rc;
-   rc = get_tiles( level, TILES_FULL, 256, &tt ); // restriction onto this level (p1_transfer.hip, kRestrictTile)
+   rc = get_tiles( level, TILES_ROWS, 64, &tt ); // restriction onto this level (p1_transfer.hip, kRestrictRow)
    if ( rc != HYTEG_HIP_OK )
       return rc;
    BrickTable bt; // same shapes as p1_apply.hip: 4 x 8 for Replace from level 8 on, 4 x 4 otherwise

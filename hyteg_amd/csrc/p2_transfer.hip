@@ -1,0 +1,402 @@
+// Quadratic (P2) grid transfer on one macro-cell:
+//   P2toP2QuadraticProlongation::prolongateAdditively3D  (src/hyteg/gridtransferoperators/P2toP2QuadraticProlongation.cpp:217-424,
+//       generatedKernels/prolongate_3D_macrocell_P2_push_from_{vertexdofs,edgedofs}.cpp: a scatter over the coarse DoFs)
+//   P2toP2QuadraticRestriction::restrictAdditively3D    (P2toP2QuadraticRestriction.cpp:131-286,
+//       generatedKernels/restrict_3D_macrocell_P2_update_{vertexdofs,edgedofs}.cpp)
+// Both are GATHERS here (no atomics, fixed summation order), driven by two small tables that do not depend on the level:
+//  * prolongation: a fine DoF (vertex DoF, or edge DoF of one of the seven orientations) with index parities (px,py,pz)
+//    lies in the relative interior of exactly one coarse micro-simplex (a coarse micro-vertex, -edge, -face or -cell);
+//    its value is the coarse function's quadratic interpolant there: sum of shape-function values
+//    lambda_i ( 2 lambda_i - 1 ) (coarse vertex DoFs) and 4 lambda_i lambda_j (coarse edge DoFs) over that simplex' DoFs,
+//    at most ten terms, with offsets relative to ( x/2, y/2, z/2 ).  64 patterns (8 kinds x 8 parities).  All DoFs of
+//    that simplex belong to this macro-cell whenever the fine DoF does, so no neighbour data is needed;
+//  * restriction = the transpose: a coarse DoF sums the fine DoFs of its basis function's support (125 for a vertex
+//    DoF, 27 for an edge DoF inside the cell) with the same weights; fine DoFs outside the macro-cell are skipped and
+//    fine DoFs on a macro-face / -edge / -vertex shared by k cells are scaled by 1/k, so that the additive exchange over
+//    the cells counts every fine DoF once (the numNeighborCells* arguments of the reference kernels).
+// The tables are built on the host from the micro-cell geometry (six micro-cell types, seven edge orientations) and the
+// shape functions -- nothing is transcribed from the generated kernels.
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace hyteg_hip;
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct TEntry
+{
+   signed char kind; // 0: vertex array, 1..7: edge array block X, Y, Z, XY, XZ, YZ, XYZ
+   signed char dx, dy, dz;
+   float       pad;
+   double      w;
+};
+static_assert( sizeof( TEntry ) == 16, "TEntry" );
+constexpr int kMaxProlong  = 10;
+constexpr int kMaxRestrict = 128;
+struct TransferTables
+{
+   TEntry      prolong[64][kMaxProlong]; // pattern = fine kind * 8 + px + 2 py + 4 pz; offsets relative to ( x>>1, y>>1, z>>1 )
+   int         nprolong[64];
+   TEntry      restrict_[8][kMaxRestrict]; // per coarse kind; offsets relative to 2 * ( coarse index )
+   int         nrestrict[8];
+};
+
+// micro-vertices of the six micro-cell types (celldof::macrocell::getMicroVerticesFromMicroCell, CellDoFIndexing.hpp:155-198)
+const int kMicroVerts[6][4][3] = { { { 0, 0, 0 }, { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } }, { { 1, 0, 0 }, { 1, 1, 0 }, { 0, 1, 0 }, { 1, 0, 1 } },
+                                   { { 1, 0, 0 }, { 0, 1, 0 }, { 1, 0, 1 }, { 0, 0, 1 } }, { { 1, 1, 0 }, { 1, 1, 1 }, { 0, 1, 1 }, { 1, 0, 1 } },
+                                   { { 1, 0, 1 }, { 0, 1, 1 }, { 0, 0, 1 }, { 0, 1, 0 } }, { { 0, 1, 0 }, { 1, 1, 0 }, { 1, 0, 1 }, { 0, 1, 1 } } };
+// end points of an edge DoF relative to its logical index, by orientation X, Y, Z, XY, XZ, YZ, XYZ (EdgeDoFIndexing.hpp)
+const int            kEnds[7][2][3] = { { { 0, 0, 0 }, { 1, 0, 0 } }, { { 0, 0, 0 }, { 0, 1, 0 } }, { { 0, 0, 0 }, { 0, 0, 1 } },
+                                        { { 1, 0, 0 }, { 0, 1, 0 } }, { { 1, 0, 0 }, { 0, 0, 1 } }, { { 0, 1, 0 }, { 0, 0, 1 } },
+                                        { { 0, 1, 0 }, { 1, 0, 1 } } };
+__constant__ int kEndsDev[7][2][3] = { { { 0, 0, 0 }, { 1, 0, 0 } }, { { 0, 0, 0 }, { 0, 1, 0 } }, { { 0, 0, 0 }, { 0, 0, 1 } },
+                                        { { 1, 0, 0 }, { 0, 1, 0 } }, { { 1, 0, 0 }, { 0, 0, 1 } }, { { 0, 1, 0 }, { 0, 0, 1 } },
+                                        { { 0, 1, 0 }, { 1, 0, 1 } } };
+
+// the edge DoF between the micro-vertices a and b: orientation (1..7) and logical index
+bool edge_between( const int* a, const int* b, int& kind, int* idx )
+{
+   for ( int o = 0; o < 7; ++o )
+   {
+      const int d[3] = { kEnds[o][1][0] - kEnds[o][0][0], kEnds[o][1][1] - kEnds[o][0][1], kEnds[o][1][2] - kEnds[o][0][2] };
+      for ( int s = 0; s < 2; ++s )
+      {
+         const int* p = s ? b : a;
+         const int* q = s ? a : b;
+         if ( q[0] - p[0] == d[0] && q[1] - p[1] == d[1] && q[2] - p[2] == d[2] )
+         {
+            kind = o + 1;
+            for ( int r = 0; r < 3; ++r )
+               idx[r] = p[r] - kEnds[o][0][r];
+            return true;
+         }
+      }
+   }
+   return false;
+}
+
+void build_tables( TransferTables& T )
+{
+   std::memset( &T, 0, sizeof( T ) );
+   for ( int kf = 0; kf < 8; ++kf )
+      for ( int par = 0; par < 8; ++par )
+      {
+         const int p[3] = { par & 1, ( par >> 1 ) & 1, ( par >> 2 ) & 1 };
+         // position of the fine DoF relative to the coarse index ( x>>1, y>>1, z>>1 ), in quarters of a coarse cell
+         int Q[3];
+         for ( int r = 0; r < 3; ++r )
+            Q[r] = 2 * p[r] + ( kf == 0 ? 0 : kEnds[kf - 1][0][r] + kEnds[kf - 1][1][r] );
+         // a coarse micro-cell that contains it (any: the interpolant is continuous, and the terms with non-zero weight are
+         // those of the smallest sub-simplex containing the point)
+         bool found = false;
+         for ( int dz = -1; dz <= 1 && !found; ++dz )
+            for ( int dy = -1; dy <= 1 && !found; ++dy )
+               for ( int dx = -1; dx <= 1 && !found; ++dx )
+                  for ( int t = 0; t < 6 && !found; ++t )
+                  {
+                     int V[4][3];
+                     for ( int k = 0; k < 4; ++k )
+                     {
+                        V[k][0] = dx + kMicroVerts[t][k][0];
+                        V[k][1] = dy + kMicroVerts[t][k][1];
+                        V[k][2] = dz + kMicroVerts[t][k][2];
+                     }
+                     // barycentric coordinates of Q / 4 in the micro-cell V: solve with Cramer's rule (small integers: exact)
+                     double M[3][3], rhs[3];
+                     for ( int r = 0; r < 3; ++r )
+                     {
+                        for ( int k = 0; k < 3; ++k )
+                           M[r][k] = 4.0 * ( V[k + 1][r] - V[0][r] );
+                        rhs[r] = Q[r] - 4.0 * V[0][r];
+                     }
+                     auto det3 = []( const double A[3][3] ) {
+                        return A[0][0] * ( A[1][1] * A[2][2] - A[1][2] * A[2][1] ) - A[0][1] * ( A[1][0] * A[2][2] - A[1][2] * A[2][0] ) +
+                               A[0][2] * ( A[1][0] * A[2][1] - A[1][1] * A[2][0] );
+                     };
+                     const double D = det3( M );
+                     double       lam[4];
+                     for ( int k = 0; k < 3; ++k )
+                     {
+                        double Mk[3][3];
+                        for ( int r = 0; r < 3; ++r )
+                           for ( int c = 0; c < 3; ++c )
+                              Mk[r][c] = c == k ? rhs[r] : M[r][c];
+                        lam[k + 1] = det3( Mk ) / D;
+                     }
+                     lam[0] = 1.0 - lam[1] - lam[2] - lam[3];
+                     if ( lam[0] < -1e-12 || lam[1] < -1e-12 || lam[2] < -1e-12 || lam[3] < -1e-12 )
+                        continue;
+                     found         = true;
+                     const int pat = kf * 8 + par;
+                     int&      n   = T.nprolong[pat];
+                     for ( int k = 0; k < 4; ++k )
+                     {
+                        const double w = lam[k] * ( 2.0 * lam[k] - 1.0 );
+                        if ( std::fabs( w ) > 1e-14 )
+                           T.prolong[pat][n++] = TEntry{ 0, (signed char) V[k][0], (signed char) V[k][1], (signed char) V[k][2], 0.0f, w };
+                     }
+                     for ( int a = 0; a < 4; ++a )
+                        for ( int b = a + 1; b < 4; ++b )
+                        {
+                           const double w = 4.0 * lam[a] * lam[b];
+                           if ( std::fabs( w ) <= 1e-14 )
+                              continue;
+                           int kind, idx[3];
+                           if ( !edge_between( V[a], V[b], kind, idx ) )
+                              continue; // cannot happen: every pair of micro-cell vertices is joined by a micro-edge
+                           T.prolong[pat][n++] = TEntry{ (signed char) kind, (signed char) idx[0], (signed char) idx[1], (signed char) idx[2], 0.0f, w };
+                        }
+                  }
+      }
+   // transpose: the fine DoF ( kf, 2 b + p ) takes w from the coarse DoF ( kc, b + d )  =>  the coarse DoF ( kc, C ) gives w to
+   // the fine DoF ( kf, 2 C - 2 d + p )
+   for ( int kf = 0; kf < 8; ++kf )
+      for ( int par = 0; par < 8; ++par )
+      {
+         const int pat = kf * 8 + par;
+         for ( int e = 0; e < T.nprolong[pat]; ++e )
+         {
+            const TEntry& s = T.prolong[pat][e];
+            int&          n = T.nrestrict[(int) s.kind];
+            if ( n >= kMaxRestrict )
+               continue; // checked by the caller (support sizes are 125 / <= 45)
+            T.restrict_[(int) s.kind][n++] = TEntry{ (signed char) kf,
+                                                     (signed char) ( -2 * s.dx + ( par & 1 ) ),
+                                                     (signed char) ( -2 * s.dy + ( ( par >> 1 ) & 1 ) ),
+                                                     (signed char) ( -2 * s.dz + ( ( par >> 2 ) & 1 ) ),
+                                                     0.0f,
+                                                     s.w };
+         }
+      }
+}
+
+// device copy of the tables, one per device, built on first use
+int get_tables( const TransferTables** out )
+{
+   static std::mutex                                 mtx;
+   static std::vector< std::pair< int, TransferTables* > > cache;
+   int                                               dev = 0;
+   HH_CHECK_HIP( hipGetDevice( &dev ) );
+   std::lock_guard< std::mutex > lock( mtx );
+   for ( auto& kv : cache )
+      if ( kv.first == dev )
+      {
+         *out = kv.second;
+         return HYTEG_HIP_OK;
+      }
+   static TransferTables host;
+   build_tables( host );
+   for ( int k = 0; k < 8; ++k )
+      if ( host.nrestrict[k] >= kMaxRestrict )
+         return fail( HYTEG_HIP_EINVAL, "p2 transfer: restriction table overflow" );
+   void* d = nullptr;
+   HH_CHECK_HIP( hipMalloc( &d, sizeof( TransferTables ) ) );
+   HH_CHECK_HIP( hipMemcpy( d, &host, sizeof( TransferTables ), hipMemcpyHostToDevice ) );
+   cache.push_back( { dev, static_cast< TransferTables* >( d ) } );
+   *out = static_cast< TransferTables* >( d );
+   return HYTEG_HIP_OK;
+}
+
+// ---- layout helpers (vertex array of width N; edge array: seven tetrahedral blocks of width n = N - 1, n - 1 for XYZ) ----
+__device__ inline int width_of_kind( int N, int kind ) { return kind == 0 ? N : ( kind == 7 ? N - 2 : N - 1 ); }
+__device__ inline bool dof_exists( int N, int kind, int x, int y, int z )
+{
+   const int W = width_of_kind( N, kind );
+   return x >= 0 && y >= 0 && z >= 0 && x + y + z <= W - 1;
+}
+__device__ inline int64_t dof_offset( int N, int kind, int x, int y, int z )
+{
+   const int W = width_of_kind( N, kind );
+   return ( kind == 0 ? 0 : (int64_t) ( kind - 1 ) * tet64( N - 1 ) ) + cell_index( W, x, y, z );
+}
+// slice z of entry i of a tetrahedral array of width W
+__device__ inline int slice_of( int W, int64_t i )
+{
+   const int64_t rest = tet64( W ) - i;
+   int           m    = (int) cbrtf( 6.0f * (float) rest );
+   m                  = m < 1 ? 1 : ( m > W ? W : m );
+   while ( m > 1 && tet64( m - 1 ) >= rest )
+      --m;
+   while ( tet64( m ) < rest )
+      ++m;
+   return W - m;
+}
+__device__ inline void decode( int W, int64_t i, int& x, int& y, int& z )
+{
+   z           = slice_of( W, i );
+   const int j = (int) ( i - ( tet64( W ) - tet64( W - z ) ) );
+   y           = row_of( W - z, j );
+   x           = j - row_start( W - z, y );
+}
+// point class 0..13 (slot of the macro-primitive: edge0..5, face0..3, vertex0..3) or 14 (inside the cell)
+__device__ inline int class_from_flags( int f0, int f1, int f2, int f3 )
+{
+   const int cnt = f0 + f1 + f2 + f3;
+   if ( cnt == 0 )
+      return 14;
+   if ( cnt == 1 )
+      return 6 + ( f0 ? 0 : f1 ? 1 : f2 ? 2 : 3 );
+   if ( cnt == 2 )
+   {
+      if ( f0 )
+         return f1 ? 0 : ( f2 ? 1 : 2 );
+      if ( f1 )
+         return f2 ? 3 : 4;
+      return 5;
+   }
+   if ( f0 && f1 && f2 )
+      return 10;
+   if ( f0 && f1 && f3 )
+      return 11;
+   if ( f0 && f2 && f3 )
+      return 12;
+   return 13;
+}
+__device__ inline int dof_class( int N, int kind, int x, int y, int z )
+{
+   if ( kind == 0 )
+      return class_from_flags( z == 0, y == 0, x == 0, x + y + z == N - 1 );
+   int f0 = 1, f1 = 1, f2 = 1, f3 = 1;
+#pragma unroll
+   for ( int e = 0; e < 2; ++e )
+   {
+      const int px = x + kEndsDev[kind - 1][e][0], py = y + kEndsDev[kind - 1][e][1], pz = z + kEndsDev[kind - 1][e][2];
+      f0 &= pz == 0, f1 &= py == 0, f2 &= px == 0, f3 &= px + py + pz == N - 1;
+   }
+   return class_from_flags( f0, f1, f2, f3 );
+}
+
+struct P2TransferArgs
+{
+   double*               dstV;
+   double*               dstE;
+   const double*         srcV;
+   const double*         srcE;
+   const TransferTables* T;
+   int                   Nc, Nf; // widths of the coarse / fine vertex arrays
+   int                   update;
+   unsigned              mask;
+   Nnc14                 nncInv;
+};
+
+// grid.y = fine kind; one thread per fine DoF of that kind
+__global__ __launch_bounds__( kThreads ) void p2_prolongate_kernel( const P2TransferArgs A )
+{
+   const int     kind = blockIdx.y;
+   const int     W    = width_of_kind( A.Nf, kind );
+   const int64_t i    = (int64_t) blockIdx.x * kThreads + threadIdx.x;
+   if ( W <= 0 || i >= tet64( W ) )
+      return;
+   int x, y, z;
+   decode( W, i, x, y, z );
+   if ( !( ( A.mask >> dof_class( A.Nf, kind, x, y, z ) ) & 1u ) )
+      return;
+   const int     pat = kind * 8 + ( x & 1 ) + 2 * ( y & 1 ) + 4 * ( z & 1 );
+   const int     bx = x >> 1, by = y >> 1, bz = z >> 1;
+   const TEntry* e   = A.T->prolong[pat];
+   const int     n   = A.T->nprolong[pat];
+   double        acc = 0.0;
+   for ( int k = 0; k < n; ++k )
+   {
+      const int     kc  = e[k].kind;
+      const int64_t off = dof_offset( A.Nc, kc, bx + e[k].dx, by + e[k].dy, bz + e[k].dz );
+      acc               = fma( e[k].w, kc == 0 ? A.srcV[off] : A.srcE[off], acc );
+   }
+   double* out = kind == 0 ? A.dstV + i : A.dstE + (int64_t) ( kind - 1 ) * tet64( A.Nf - 1 ) + i;
+   *out        = A.update == HYTEG_HIP_ADD ? *out + acc : acc;
+}
+
+// grid.y = coarse kind; one thread per coarse DoF of that kind
+__global__ __launch_bounds__( kThreads ) void p2_restrict_kernel( const P2TransferArgs A )
+{
+   const int     kind = blockIdx.y;
+   const int     W    = width_of_kind( A.Nc, kind );
+   const int64_t i    = (int64_t) blockIdx.x * kThreads + threadIdx.x;
+   if ( W <= 0 || i >= tet64( W ) )
+      return;
+   int x, y, z;
+   decode( W, i, x, y, z );
+   if ( !( ( A.mask >> dof_class( A.Nc, kind, x, y, z ) ) & 1u ) )
+      return;
+   const TEntry* e   = A.T->restrict_[kind];
+   const int     n   = A.T->nrestrict[kind];
+   double        acc = 0.0;
+   for ( int k = 0; k < n; ++k )
+   {
+      const int kf = e[k].kind;
+      const int fx = 2 * x + e[k].dx, fy = 2 * y + e[k].dy, fz = 2 * z + e[k].dz;
+      if ( !dof_exists( A.Nf, kf, fx, fy, fz ) )
+         continue;
+      const int     cls   = dof_class( A.Nf, kf, fx, fy, fz );
+      const double  scale = cls == 14 ? 1.0 : A.nncInv.inv[cls];
+      const int64_t off   = dof_offset( A.Nf, kf, fx, fy, fz );
+      acc                 = fma( e[k].w * scale, kf == 0 ? A.srcV[off] : A.srcE[off], acc );
+   }
+   double* out = kind == 0 ? A.dstV + i : A.dstE + (int64_t) ( kind - 1 ) * tet64( A.Nc - 1 ) + i;
+   *out        = acc;
+}
+
+} // namespace
+
+extern "C" {
+
+HYTEG_HIP_API int hyteg_hip_p2_prolongate_cell( double*            fine_vertex,
+                                                double*            fine_edge,
+                                                const double*      coarse_vertex,
+                                                const double*      coarse_edge,
+                                                int                coarse_level,
+                                                int                update,
+                                                unsigned           mask,
+                                                hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( fine_vertex && fine_edge && coarse_vertex && coarse_edge, "p2_prolongate_cell: null pointer" );
+   HH_REQUIRE( coarse_level >= 0 && coarse_level + 1 <= 10, "p2_prolongate_cell: coarse level out of range [0,9]" );
+   HH_REQUIRE( update == HYTEG_HIP_REPLACE || update == HYTEG_HIP_ADD, "p2_prolongate_cell: bad update type" );
+   P2TransferArgs A{};
+   int            rc = get_tables( &A.T );
+   if ( rc != HYTEG_HIP_OK )
+      return rc;
+   A.dstV = fine_vertex, A.dstE = fine_edge, A.srcV = coarse_vertex, A.srcE = coarse_edge;
+   A.Nc = ( 1 << coarse_level ) + 1, A.Nf = ( 1 << ( coarse_level + 1 ) ) + 1;
+   A.update = update, A.mask = mask;
+   const int64_t most = tet64( A.Nf );
+   hipLaunchKernelGGL( p2_prolongate_kernel, dim3( (unsigned) ( ( most + kThreads - 1 ) / kThreads ), 8 ), dim3( kThreads ), 0, as_stream( stream ), A );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_p2_restrict_cell( double*            coarse_vertex,
+                                              double*            coarse_edge,
+                                              const double*      fine_vertex,
+                                              const double*      fine_edge,
+                                              int                coarse_level,
+                                              const double*      nnc,
+                                              unsigned           mask,
+                                              hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( fine_vertex && fine_edge && coarse_vertex && coarse_edge && nnc, "p2_restrict_cell: null pointer" );
+   HH_REQUIRE( coarse_level >= 0 && coarse_level + 1 <= 10, "p2_restrict_cell: coarse level out of range [0,9]" );
+   P2TransferArgs A{};
+   int            rc = get_tables( &A.T );
+   if ( rc != HYTEG_HIP_OK )
+      return rc;
+   A.dstV = coarse_vertex, A.dstE = coarse_edge, A.srcV = fine_vertex, A.srcE = fine_edge;
+   A.Nc = ( 1 << coarse_level ) + 1, A.Nf = ( 1 << ( coarse_level + 1 ) ) + 1;
+   A.mask = mask;
+   for ( int k = 0; k < 14; ++k )
+   {
+      HH_REQUIRE( nnc[k] > 0.0, "p2_restrict_cell: neighbour counts must be positive" );
+      A.nncInv.inv[k] = 1.0 / nnc[k];
+   }
+   const int64_t most = tet64( A.Nc );
+   hipLaunchKernelGGL( p2_restrict_kernel, dim3( (unsigned) ( ( most + kThreads - 1 ) / kThreads ), 8 ), dim3( kThreads ), 0, as_stream( stream ), A );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+}

@@ -23,6 +23,25 @@ static std::vector< Tile > build_tiles( int level, TileKind kind, int capacity )
 {
    const int           N = ( 1 << level ) + 1;
    std::vector< Tile > tiles;
+   if ( kind == TILES_ROWS )
+   {
+      for ( int z = 0; z < N; ++z )
+         for ( int y = 0; y < N - z; ++y )
+         {
+            const int R = N - z - y;
+            for ( int x0 = 0; x0 < R; x0 += capacity )
+            {
+               Tile tl{};
+               tl.a   = cell_index( N, x0, y, z );
+               tl.cnt = std::min( capacity, R - x0 );
+               tl.z   = z;
+               tl.ya  = y;
+               tl.yb  = x0;
+               tiles.push_back( tl );
+            }
+         }
+      return tiles;
+   }
    const int           zlo = kind == TILES_INNER ? 1 : 0;
    const int           zhi = kind == TILES_INNER ? N - 4 : N - 1;
    for ( int z = zlo; z <= zhi; ++z )

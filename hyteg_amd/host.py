@@ -97,6 +97,8 @@ SIGNATURES = {
     "hyteg_host_p2function_add": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(_vp), _i, _i]),
     "hyteg_host_p2function_dot": (_i, [_vp, _vp, _i, _i, C.POINTER(_d)]),
     "hyteg_host_p2operator_create_constant": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "hyteg_host_p2_prolongate": (_i, [_vp, _i, _i, _i]),
+    "hyteg_host_p2_restrict": (_i, [_vp, _i, _i]),
     "hyteg_host_p2operator_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
     "hyteg_host_p2operator_destroy": (_i, [_vp]),
     "hyteg_host_p2operator_element_matrices": (_i, [_vp, _i, _i, _vp]),
@@ -596,6 +598,16 @@ class P2Function:
         if self.h:
             lib().hyteg_host_p2function_destroy(self.h)
             self.h = None
+
+
+def p2_prolongate(f: "P2Function", source_level, flag, add=False):
+    """hyteg::P2toP2QuadraticProlongation::prolongate / prolongateAndAdd"""
+    _ck(lib().hyteg_host_p2_prolongate(f.h, source_level, flag, int(add)), "p2_prolongate")
+
+
+def p2_restrict(f: "P2Function", source_level, flag):
+    """hyteg::P2toP2QuadraticRestriction::restrict"""
+    _ck(lib().hyteg_host_p2_restrict(f.h, source_level, flag), "p2_restrict")
 
 
 class P2ElementwiseLaplaceOperator:

@@ -27,6 +27,7 @@
 #include "forms.hpp"
 #include "p1operator.hpp"
 #include "p2operator.hpp"
+#include "p2gridtransfer.hpp"
 #include "gridtransfer.hpp"
 #include "solvers.hpp"
 #include "stokes.hpp"

@@ -659,6 +659,20 @@ HYTEG_HOST_API int hyteg_host_p2operator_create( hh_storage_t s, int minL, int m
       *out = new P2OperatorH{ std::make_shared< P2ElementwiseLaplaceOperator >( static_cast< StorageH* >( s )->p, (uint_t) minL, (uint_t) maxL ) };
    } );
 }
+HYTEG_HOST_API int hyteg_host_p2_prolongate( hh_p2function_t f, int sourceLevel, int flag, int add )
+{
+   return guarded( [&] {
+      auto& fn = *static_cast< P2FunctionH* >( f )->p;
+      if ( add )
+         P2toP2QuadraticProlongation().prolongateAndAdd( fn, (uint_t) sourceLevel, DoFType( flag ) );
+      else
+         P2toP2QuadraticProlongation().prolongate( fn, (uint_t) sourceLevel, DoFType( flag ) );
+   } );
+}
+HYTEG_HOST_API int hyteg_host_p2_restrict( hh_p2function_t f, int sourceLevel, int flag )
+{
+   return guarded( [&] { P2toP2QuadraticRestriction().restrict( *static_cast< P2FunctionH* >( f )->p, (uint_t) sourceLevel, DoFType( flag ) ); } );
+}
 HYTEG_HOST_API int hyteg_host_p2operator_create_constant( hh_storage_t s, int minL, int maxL, hh_p2operator_t* out )
 {
    return guarded( [&] {

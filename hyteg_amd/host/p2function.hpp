@@ -23,8 +23,6 @@ class P2Function
    , maxLevel_( maxLevel )
    , vertexDoFFunction_( name + "_VertexDoF", storage, minLevel, maxLevel )
    {
-      if ( storage->numRanks() != 1 )
-         throw std::runtime_error( "P2Function: storages distributed over several ranks are not supported in this version" );
       if ( maxLevel > HYTEG_HIP_P2_MAX_LEVEL )
          throw std::runtime_error( "P2Function: level out of range" );
       edge_.resize( storage->getNumberOfLocalCells() );
@@ -159,6 +157,14 @@ class P2Function
       std::vector< double* > arrays;
       forCells( [&]( uint_t c, const MacroCell& ) { arrays.push_back( getEdgeCellPointer( c, level ) ); } );
       exchangeEdges( arrays, level, flag, true );
+   }
+
+   // every copy := the copy held by the lowest-numbered neighbour cell
+   void syncSharedEdgeCopies( uint_t level, DoFType flag = All ) const
+   {
+      std::vector< double* > arrays;
+      forCells( [&]( uint_t c, const MacroCell& ) { arrays.push_back( getEdgeCellPointer( c, level ) ); } );
+      exchangeEdges( arrays, level, flag, false );
    }
 
    void copyEdgeToHost( uint_t c, uint_t level, double* host ) const

@@ -633,6 +633,38 @@ HYTEG_HIP_API int hyteg_hip_p1_apply_face3d( double*            dst_face,
                                              int                update,
                                              hyteg_hip_stream_t stream );
 
+/* ---- f1: quadratic (P2) grid transfer on one macro-cell -----------------------------------------------------------
+ * replaces P2toP2QuadraticProlongation::prolongateAdditively3D and P2toP2QuadraticRestriction::restrictAdditively3D
+ *   src/hyteg/gridtransferoperators/P2toP2QuadraticProlongation.cpp:217-424,
+ *   generatedKernels/prolongate_3D_macrocell_P2_push_from_{vertexdofs,edgedofs}.cpp
+ *   src/hyteg/gridtransferoperators/P2toP2QuadraticRestriction.cpp:131-286,
+ *   generatedKernels/restrict_3D_macrocell_P2_update_{vertexdofs,edgedofs}.cpp
+ * vertex arrays: macro-cell layout of width 2^level + 1; edge arrays: hyteg_hip_p2_edge_array_size( level ) entries, seven
+ * orientation blocks (X, Y, Z, XY, XZ, YZ, XYZ).  mask: 15-bit point-class mask of the DESTINATION DoFs (bits 0..13: the
+ * macro-primitive slots edge0..5, face0..3, vertex0..3; bit 14: inside the cell), as for the elementwise apply.
+ * prolongate: fine = (update == ADD ? fine : 0) + quadratic interpolant of the coarse function at the fine DoFs.  Every
+ *   cell computes the complete value of the fine DoFs on its boundary (the interpolant is continuous), so the copies of
+ *   several cells agree up to rounding; the host layer makes them bit-identical with a copy, not a sum.
+ * restrict: coarse = P^T fine, where fine DoFs on a macro-primitive shared by nnc[slot] cells are scaled by 1 / nnc[slot]
+ *   (nnc: host, 14 values in slot order, the numNeighborCells* arguments of the reference kernels); the additive exchange
+ *   over the cells completes the coarse DoFs on shared primitives. */
+HYTEG_HIP_API int hyteg_hip_p2_prolongate_cell( double*            fine_vertex,
+                                                double*            fine_edge,
+                                                const double*      coarse_vertex,
+                                                const double*      coarse_edge,
+                                                int                coarse_level,
+                                                int                update,
+                                                unsigned           mask,
+                                                hyteg_hip_stream_t stream );
+HYTEG_HIP_API int hyteg_hip_p2_restrict_cell( double*            coarse_vertex,
+                                              double*            coarse_edge,
+                                              const double*      fine_vertex,
+                                              const double*      fine_edge,
+                                              int                coarse_level,
+                                              const double*      nnc /* host, 14 */,
+                                              unsigned           mask,
+                                              hyteg_hip_stream_t stream );
+
 /* ---- events and the neighbour exchange over RCCL (xGMI) --------------------------------------------------------
  * One process per GPU.  Replaces, on this path, what the reference does through waLBerla's BufferSystem over MPI:
  *   src/hyteg/communication/BufferedCommunication.cpp:181-470   start/endCommunication: pack, Isend/Irecv, wait, unpack

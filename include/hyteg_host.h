@@ -172,6 +172,10 @@ HYTEG_HOST_API int hyteg_host_p2function_assign( hh_p2function_t dst, int n, con
 HYTEG_HOST_API int hyteg_host_p2function_add( hh_p2function_t dst, int n, const double* scalars, const hh_p2function_t* srcs, int level, int flag );
 HYTEG_HOST_API int hyteg_host_p2function_dot( hh_p2function_t a, hh_p2function_t b, int level, int flag, double* result );
 HYTEG_HOST_API int hyteg_host_p2operator_create( hh_storage_t s, int min_level, int max_level, hh_p2operator_t* out );
+/* P2toP2QuadraticProlongation::prolongate / prolongateAndAdd (add != 0) from source_level to source_level + 1 and
+ * P2toP2QuadraticRestriction::restrict from source_level to source_level - 1 (src/hyteg/gridtransferoperators/) */
+HYTEG_HOST_API int hyteg_host_p2_prolongate( hh_p2function_t f, int source_level, int flag, int add );
+HYTEG_HOST_API int hyteg_host_p2_restrict( hh_p2function_t f, int source_level, int flag );
 /* P2ConstantLaplaceOperator (src/constant_stencil_operator/P2ConstantOperator.hpp): same handle type and calls as the
  * elementwise operator; on affine macro-cells the assembled constant stencils ARE what the kernel's operator table holds */
 HYTEG_HOST_API int hyteg_host_p2operator_create_constant( hh_storage_t s, int min_level, int max_level, hh_p2operator_t* out );

@@ -10,6 +10,7 @@ p1_oracle.c.  Arrays are float64, C-contiguous, in HyTeG's linear tetrahedral ce
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import os
 import subprocess
 from pathlib import Path
@@ -378,20 +379,26 @@ def edge_index(level, x, y, z, o): return int(lib().ho_edge_index(level, x, y, z
 def edge_dof_class(level, x, y, z, o): return int(lib().ho_edge_dof_class(level, x, y, z, o))
 
 
+@functools.lru_cache(maxsize=None)
 def edge_coords(level):
-    """(edge array size, 4) int array: x, y, z, orientation of every edge DoF in array order"""
+    """(edge array size, 4) int array: x, y, z, orientation of every edge DoF in array order (cached: treat as read-only)"""
     n = 1 << level
     out = []
     for o in range(7):
         w = n - 1 if o == 6 else n
         for z in range(w):
             for y in range(w - z):
-                for x in range(w - z - y):
-                    out.append((x, y, z, o))
-    return np.array(out, dtype=np.int64).reshape(-1, 4)
+                m = w - z - y
+                if m > 0:
+                    blk = np.empty((m, 4), dtype=np.int64)
+                    blk[:, 0], blk[:, 1], blk[:, 2], blk[:, 3] = np.arange(m), y, z, o
+                    out.append(blk)
+    return np.concatenate(out).reshape(-1, 4) if out else np.zeros((0, 4), dtype=np.int64)
 
 
+@functools.lru_cache(maxsize=None)
 def edge_classes(level):
+    """point class (0..13: the macro-primitive slot, 14: inside the cell) of every edge DoF in array order (cached)"""
     return np.array([edge_dof_class(level, int(x), int(y), int(z), int(o)) for x, y, z, o in edge_coords(level)], dtype=np.int64)
 
 
@@ -446,8 +453,9 @@ def sor_shell_cell(dst, rhs, rest, level, edge_verts, edge_w, face_verts, face_w
     return dst
 
 
+@functools.lru_cache(maxsize=None)
 def slot_of_points(level):
-    """per array entry: slot 0..13 of the macro-primitive it lies on, 14 for interior points"""
+    """per array entry: slot 0..13 of the macro-primitive it lies on, 14 for interior points (cached: treat as read-only)"""
     c = cell_coords(level)
     return np.array([14 if prim_slot(level, *map(int, p)) < 0 else prim_slot(level, *map(int, p)) for p in c])
 
