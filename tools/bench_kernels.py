@@ -71,6 +71,14 @@ def main():
     timeit("restrict (fine L -> coarse L-1)", lambda k: capi.p1_restrict_cell(p(Co, k), p(A, k), L - 1, ones, sh), 8 * (n + nc), nc)
     timeit("prolongate Replace (coarse L-1 -> fine L)", lambda k: capi.p1_prolongate_cell(p(Co, k), p(B, k), L - 1, ones, 0, sh),
            8 * (n + nc), n)
+    # float32 instantiations: algorithmic bytes halve
+    Af = [t.to(torch.float32) for t in A[:max(2, nbuf // 2)]]
+    Bf = [t.to(torch.float32) for t in B[:max(2, nbuf // 2)]]
+    Cf = [t.to(torch.float32) for t in Cc[:max(2, nbuf // 2)]]
+    pf = lambda t, k: t[k % len(t)].data_ptr()  # noqa: E731
+    timeit("apply Replace, float32", lambda k: capi.p1_apply_cell_f32(pf(Bf, k), pf(Af, k), L, w, 0, sh), 8 * inner, inner)
+    timeit("Jacobi fused, float32 (scalar inverse diagonal)",
+           lambda k: capi.p1_jacobi_cell_f32(pf(Bf, k), pf(Cf, k), pf(Af, k), L, w, 0.66, None, sh), 12 * inner, inner)
     for name, alg in (("dataflow, one launch", capi.SOR_DATAFLOW), ("16^3 blocks, one launch per block wavefront", capi.SOR_BLOCKS)):
         capi.set_sor_algorithm(alg)
         timeit(f"SOR forward sweep ({name})", lambda k: capi.p1_sor_cell(p(B, k), p(A, k), L, w, 1.0, False, sh), 24 * inner, inner,
@@ -105,6 +113,16 @@ def main():
            lambda k: capi.p2_elementwise_apply_cell(DV[k % nb2].data_ptr(), DE[k % nb2].data_ptr(), SV[k % nb2].data_ptr(),
                                                     SE[k % nb2].data_ptr(), L2, em.data_ptr(), 1.0, 0, 0x7FFF, sh),
            16 * (nv2 + ne2), nv2 + ne2, r=max(3, reps // 10))
+    # P2 quadratic grid transfer between level L2 - 1 and L2
+    nvc, nec = capi.cell_size(L2 - 1), capi.p2_edge_array_size(L2 - 1)
+    CV = [torch.rand(nvc, dtype=torch.float64, device="cuda") for _ in range(nb2)]
+    CE = [torch.rand(nec, dtype=torch.float64, device="cuda") for _ in range(nb2)]
+    timeit(f"P2 prolongate level {L2 - 1} -> {L2}",
+           lambda k: capi.p2_prolongate_cell(DV[k % nb2].data_ptr(), DE[k % nb2].data_ptr(), CV[k % nb2].data_ptr(), CE[k % nb2].data_ptr(),
+                                             L2 - 1, 0, 0x7FFF, sh), 8 * (nv2 + ne2 + nvc + nec), nv2 + ne2, r=max(3, reps // 10))
+    timeit(f"P2 restrict level {L2} -> {L2 - 1}",
+           lambda k: capi.p2_restrict_cell(CV[k % nb2].data_ptr(), CE[k % nb2].data_ptr(), SV[k % nb2].data_ptr(), SE[k % nb2].data_ptr(),
+                                           L2 - 1, ones, 0x7FFF, sh), 8 * (nv2 + ne2 + nvc + nec), nvc + nec, r=max(3, reps // 10))
     # BASELINE config 4 shape on one GPU: P2 Laplace, level 7, the 6 macro-cells one GPU holds (cube_6el = the unit cube)
     if L >= 7:
         s6 = host.Storage.from_gmsh(ROOT / "hyteg_amd/data/meshes/cube_6el.msh")
@@ -128,7 +146,8 @@ def main():
         for o in (u6, r6, A6, s6):
             o.close()
     # V-cycles through the host layer
-    for mesh, lo, hi, smoother, name in (("tet_1el", 2, L, host.JACOBI, "Jacobi(2/3)"), ("tet_1el", 2, min(L, 7), host.GAUSS_SEIDEL, "GS"),
+    for mesh, lo, hi, smoother, name in (("tet_1el", 2, L, host.JACOBI, "Jacobi(2/3)"), ("tet_1el", 2, L, host.JACOBI_FP32, "Jacobi fp32"),
+                                          ("tet_1el", 2, min(L, 7), host.GAUSS_SEIDEL, "GS"),
                                           ("regular_octahedron_8el", 2, min(L, 6), host.JACOBI, "Jacobi(2/3)"),
                                           ("regular_octahedron_8el", 0, min(L, 6), host.GAUSS_SEIDEL, "GS")):
         s2 = host.Storage.from_gmsh(ROOT / f"hyteg_amd/data/meshes/{mesh}.msh")
@@ -156,6 +175,33 @@ def main():
         rows.append(dict(kernel=f"V(3,3) {name} {mesh} L{lo}-{hi}", ms=ms, inner_dofs=dofs))
         print(f"V(3,3) {name:12s} {mesh:24s} levels {lo}-{hi}: {ms:9.2f} ms/cycle, {dofs:.0f} inner DoFs "
               f"({dofs / ms * 1e-6:.2f} GDoF/s per cycle)", flush=True)
+    # P1-P1 Stokes: the reference's P1P1Stokes3DUzawaConvergenceTest configuration (cube_24el, levels 2-5, V(3,3) increment 2, Uzawa)
+    s3 = host.Storage.from_gmsh(ROOT / "hyteg_amd/data/meshes/cube_24el.msh")
+    s3.set_stream(sh)
+    Ls = host.P1P1StokesOperator(s3, 2, 5)
+    us_, fs_ = host.P1StokesFunction(s3, "u", 2, 5), host.P1StokesFunction(s3, "f", 2, 5)
+    for fn_ in (us_, fs_):
+        for comp in fn_.components:
+            comp.interpolate(0.0, 5, host.All)
+    us_.u.interpolate(1.0, 5, host.DirichletBoundary)
+    uz = host.StokesSolver.uzawa(s3, 2, 5, 0.3, velocity_iterations=2, velocity_smoother=host.GAUSS_SEIDEL)
+    sg = host.StokesSolver.gmg(s3, uz, 2, 5, pre=3, post=3, increment=2)
+    sg.solve(Ls, us_, fs_, 5)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        sg.solve(Ls, us_, fs_, 5)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / 3
+    rows.append(dict(kernel="Stokes V(3,3)+2 Uzawa/GS cube_24el L2-5", ms=ms))
+    print(f"P1-P1 Stokes V(3,3) increment 2, Uzawa(0.3) over GS, cube_24el levels 2-5: {ms:9.2f} ms/cycle", flush=True)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        Ls.apply(us_, fs_, 5, host.Inner | host.NeumannBoundary)
+    torch.cuda.synchronize()
+    us1 = (time.perf_counter() - t0) * 1e6 / 20
+    rows.append(dict(kernel="P1P1StokesOperator::apply cube_24el L5", us=us1))
+    print(f"P1P1StokesOperator::apply, cube_24el level 5 (24 cells, 10 scalar applies): {us1:9.1f} us", flush=True)
     print(json.dumps({"level": L, "device": capi.device_name(), "rows": rows}))
 
 
