@@ -32,12 +32,12 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zloop_ke
    ZM_TRACE( 1 );
 
    constexpr int kStAux = 2; // nontemporal
-   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc( const_cast< double* >( A.src ), 0, A.bytes, 0x00020000 );
-   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc( A.dst, 0, A.bytes, 0x00020000 );
+   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc( static_cast< double* >( const_cast< void* >( A.src ) ), 0, A.bytes, 0x00020000 );
+   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc( static_cast< double* >( A.dst ), 0, A.bytes, 0x00020000 );
    const __amdgpu_buffer_rsrc_t rr =
-       __builtin_amdgcn_make_buffer_rsrc( const_cast< double* >( MODE == APPLY_JACOBI ? A.rhs : A.src ), 0, A.bytes, 0x00020000 );
+       __builtin_amdgcn_make_buffer_rsrc( static_cast< double* >( const_cast< void* >( MODE == APPLY_JACOBI ? A.rhs : A.src ) ), 0, A.bytes, 0x00020000 );
    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(
-       const_cast< double* >( ( MODE == APPLY_JACOBI && A.invdiag ) ? A.invdiag : A.src ), 0, A.bytes, 0x00020000 );
+       static_cast< double* >( const_cast< void* >( ( MODE == APPLY_JACOBI && A.invdiag ) ? A.invdiag : A.src ) ), 0, A.bytes, 0x00020000 );
 
    const int lane_off = lane * 8;
    const int ym       = t.y0 - 1; // first row held per slice
@@ -51,7 +51,7 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zloop_ke
       for ( int r = 0; r < NY + 2; ++r )
       {
          const int last8 = ( W_q - ( ym + r ) - 1 - t.xb ) * 8; // byte offset of the row's last entry from lane 0's
-         Sq[r]           = zm_load2< 0 >( rs, min( lane_off, last8 ), ix * 8 );
+         Sq[r]           = zm_load2< double, 0 >( rs, min( lane_off, last8 ), ix * 8 );
          ix += W_q - ( ym + r ); // next row of the same slice
       }
    };
@@ -72,7 +72,7 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zloop_ke
             const int last8 = ( W - ( t.y0 + j ) - 1 - t.xb ) * 8;
             const int vo    = min( lane_off, last8 );
             ex0[j]          = MODE == APPLY_ADD ? zm_load2< EX_AUX >( rd, vo, ie * 8 ) : zm_load2< EX_AUX >( rr, vo, ie * 8 );
-            ex1[j]          = ( MODE == APPLY_JACOBI && A.invdiag ) ? zm_load2( ri, vo, ie * 8 ) : invc;
+            ex1[j]          = ( MODE == APPLY_JACOBI && A.invdiag ) ? zm_load2< double >( ri, vo, ie * 8 ) : invc;
             ie += W - ( t.y0 + j );
          }
       }
@@ -109,7 +109,7 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zloop_ke
             out = a0 + A.relax * ( ex1[j] * ( ex0[j] - acc ) );
          const int      cnt = min( 62, R - 2 - t.xb ); // outputs: lanes 1 .. cnt (wave-uniform)
          const unsigned lm1 = (unsigned) ( lane - 1 );
-         zm_store2< kStAux >( rd, lm1 < (unsigned) max( cnt, 0 ) ? lane_off : -8, io * 8, out );
+         zm_store2< double, kStAux >( rd, lm1 < (unsigned) max( cnt, 0 ) ? lane_off : -8, io * 8, out );
          io += R;
       }
    };

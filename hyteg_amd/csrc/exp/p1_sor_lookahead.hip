@@ -1,3 +1,17 @@
+// NEGATIVE RESULT of round 2 (kept so that the measurement can be repeated; built only by exp/build_trace.sh into
+// sor_trace_lookahead, never into the library).  A copy of ../p1_sor.hip whose blocked kernel was rewritten along the
+// lines "shorten the critical path of a plane step":
+//   * neighbours carried along p in registers (8 LDS reads per update instead of 16),
+//   * everything but the three terms written on the previous plane summed one step ahead,
+//   * a branch-free step (idle threads read clamped addresses and store to a sink) so that the compiler interleaves both sums,
+//   * blocks of a wavefront taken from the grid index instead of a table, rhs loads issued together with the u loads.
+// Level 8 on one box, same run: 1000 / 1034 us per forward / backward sweep against 844 / 844 us of the production
+// kernel (levels 6, 7: 210 / 470 against 172 / 390).  Why (exp/sor_trace.hip -DSOR_STEPS, exp/lat_probe.hip): a plane
+// step is not bound by the length of its dependent f64 chain (8.6 cycles per dependent FMA, not the 32 that round 1
+// wrote down) but by what four waves -- one per SIMD -- can push through the LDS and the issue port between two barriers:
+// ~330 cycles from the first address computation until the reads have arrived, ~125 for arithmetic and the write, ~80
+// for the barrier.  The production kernel lets whole waves skip a step when none of their points lies on the plane (only 35 %
+// of the thread-steps of a 16^3 block are active); the branch-free step makes every wave do the full work in every step.
 // C-ABI entry point: in-place SOR / Gauss-Seidel sweep on one macro-cell in the reference's
 // lexicographic order, executed as hyperplanes t = x + 2y + 3z.
 //
@@ -18,8 +32,8 @@
 
 #include <atomic>
 
-#include "common.hpp"
-#include "sor_dataflow.hpp"
+#include "../common.hpp"
+#include "../sor_dataflow.hpp"
 
 using namespace hyteg_hip;
 
@@ -95,6 +109,7 @@ __global__ __launch_bounds__( kThreads ) void p1_sor_plane_kernel( const SorArgs
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kB  = 16;     // block edge
 constexpr int kBH = kB + 2; // with halo
+constexpr int kBP = kB + 6; // LDS row length along p: halo + two padding entries per side (addresses of idle steps, never used)
 
 struct SorBlock
 {
@@ -103,27 +118,41 @@ struct SorBlock
 
 struct SorBlockArgs
 {
-   double*         u;
-   const double*   rhs;
-   const SorBlock* blocks; // blocks of this wavefront
-   int             N;
-   int             backwards;
-   double          relax, one_minus_relax, invc;
-   Stencil15       st;
+   double*       u;
+   const double* rhs;
+   int           N;
+   int           T, Q0, R0; // block wavefront P + Q + R of this launch; Q = Q0 + blockIdx.x, R = R0 + blockIdx.y
+   double        relax, one_minus_relax, invc;
+   Stencil15     st;
 };
-// batched form: blockIdx.y = cell; weights from the device table [cell][15][15] (row 14 = inner stencil)
+// batched form: blockIdx.z = cell; weights from the device table [cell][15][15] (row 14 = inner stencil)
 struct SorBlockBatchArgs
 {
-   double*         u[HYTEG_HIP_MAX_BATCH];
-   const double*   rhs[HYTEG_HIP_MAX_BATCH];
-   const double*   stencils;
-   const SorBlock* blocks;
-   int             N;
-   int             backwards;
-   double          relax, one_minus_relax;
+   double*       u[HYTEG_HIP_MAX_BATCH];
+   const double* rhs[HYTEG_HIP_MAX_BATCH];
+   const double* stencils;
+   int           N;
+   int           T, Q0, R0;
+   double        relax, one_minus_relax;
 };
 
-__device__ inline int lds_index( int pl, int ql, int rl ) { return ( ( rl + 1 ) * kBH + ( ql + 1 ) ) * kBH + ( pl + 1 ); }
+__host__ __device__ inline int lds_index( int pl, int ql, int rl ) { return ( ( rl + 1 ) * kBH + ( ql + 1 ) ) * kBP + ( pl + 3 ); }
+
+// does block (P,Q,R) of a cell with n = 2^level hold an interior point?  (r >= 1, q >= r + 1, p >= q + 1, p <= n - 1)
+__host__ __device__ inline bool sor_block_nonempty( int n, int P, int Q, int R )
+{
+   const int nb = ( n + kB - 1 ) / kB;
+   if ( R < 0 || Q < R || P < Q || P >= nb )
+      return false;
+   const int rmin = max( 1, R * kB ), rmax = min( n - 3, R * kB + kB - 1 );
+   if ( rmin > rmax )
+      return false;
+   const int qmin = max( rmin + 1, Q * kB ), qmax = min( n - 2, Q * kB + kB - 1 );
+   if ( qmin > qmax )
+      return false;
+   const int pmin = max( qmin + 1, P * kB ), pmax = min( n - 1, P * kB + kB - 1 );
+   return pmin <= pmax;
+}
 
 struct SorBlockView
 {
@@ -131,29 +160,49 @@ struct SorBlockView
    const double* rhs;
    const double* w;
    double        relax, one_minus_relax, invc;
-   int           N, backwards;
+   int           N;
 };
-__device__ inline void sor_block_body( const SorBlockView A, const SorBlock blk );
 // timestamp hook of the developer harness exp/sor_trace.hip; expands to nothing in the library
 #ifndef SOR_TRACE
 #define SOR_TRACE( slot )
 #endif
+#ifndef SOR_STEP_STAMP
+#define SOR_STEP_STAMP( k )
+#define SOR_STEP_DECL
+#define SOR_STEP_FLUSH
+#endif
 
+template < bool BW >
+__device__ inline void sor_block_body( const SorBlockView A, const SorBlock blk );
+
+// The blocks of a wavefront are the (Q,R) of a 2-D grid with P = T - Q - R: no block table to load before the first
+// useful instruction; the workgroups of empty or non-existent blocks leave at once.
+template < bool BW >
 __global__ __launch_bounds__( kB* kB ) void p1_sor_block_kernel( const SorBlockArgs A )
 {
-   sor_block_body( SorBlockView{ A.u, A.rhs, A.st.w, A.relax, A.one_minus_relax, A.invc, A.N, A.backwards }, A.blocks[blockIdx.x] );
+   const int Q = A.Q0 + blockIdx.x, R = A.R0 + blockIdx.y, P = A.T - Q - R;
+   if ( !sor_block_nonempty( A.N - 1, P, Q, R ) )
+      return;
+   sor_block_body< BW >( SorBlockView{ A.u, A.rhs, A.st.w, A.relax, A.one_minus_relax, A.invc, A.N }, SorBlock{ (short) P, (short) Q, (short) R, 0 } );
 }
+template < bool BW >
 __global__ __launch_bounds__( kB* kB ) void p1_sor_block_batch_kernel( const SorBlockBatchArgs A )
 {
-   const int     cell = blockIdx.y;
+   const int Q = A.Q0 + blockIdx.x, R = A.R0 + blockIdx.y, P = A.T - Q - R;
+   if ( !sor_block_nonempty( A.N - 1, P, Q, R ) )
+      return;
+   const int     cell = blockIdx.z;
    const double* w    = A.stencils + (size_t) cell * 225 + 14 * 15;
-   sor_block_body( SorBlockView{ A.u[cell], A.rhs[cell], w, A.relax, A.one_minus_relax, 1.0 / w[7], A.N, A.backwards }, A.blocks[blockIdx.x] );
+   sor_block_body< BW >( SorBlockView{ A.u[cell], A.rhs[cell], w, A.relax, A.one_minus_relax, 1.0 / w[7], A.N },
+                         SorBlock{ (short) P, (short) Q, (short) R, 0 } );
 }
 
+template < bool BW >
 __device__ inline void sor_block_body( const SorBlockView A, const SorBlock blk )
 {
-   __shared__ double lu[kBH * kBH * kBH];
+   __shared__ double lu[kBP * kBH * kBH];
    __shared__ double lr[kB * kB * kB]; // rhs of the block (a per-thread register row would be runtime-indexed -> scratch)
+   __shared__ double sink[kB * kB];    // where idle threads store (keeps the step free of branches)
    const int         N = A.N, n = N - 1;
    const int         p0 = blk.P * kB, q0 = blk.Q * kB, r0 = blk.R * kB;
    double*           u = A.u;
@@ -171,9 +220,9 @@ __device__ inline void sor_block_body( const SorBlockView A, const SorBlock blk 
    __syncthreads();
    SOR_TRACE( 1 );
 
-   // stage the block and its halo
-   // (constant trip counts + full unrolling: all loads of a thread are in flight together; a rolled loop waits one
-   //  memory round trip per iteration, which made staging 2/3 of the block time)
+   // stage the block with its halo, and its right-hand side
+   // (constant trip counts + full unrolling: ALL loads of a thread -- 23 of u, 16 of rhs -- are in flight together; a
+   //  rolled loop waits one memory round trip per iteration, and so did the rhs when it was loaded after u was in LDS)
    constexpr int kStageU = ( kBH * kBH * kBH + kB * kB - 1 ) / ( kB * kB );
    double        stage[kStageU];
 #pragma unroll
@@ -185,76 +234,116 @@ __device__ inline void sor_block_body( const SorBlockView A, const SorBlock blk 
       const int base = idx < kBH * kBH * kBH ? rowBase[row] : -1;
       stage[it]      = ( base >= 0 && p >= q && p <= n ) ? u[base + p] : 0.0;
    }
+   // rhs and write-back: thread handles the entries idx = it * 256 + tid of the 16^3 block: pl = tid % 16, row (tid / 16, it)
+   const int pw = p0 + threadIdx.x % kB, qw = q0 + threadIdx.x / kB;
+   double    stageR[kB];
+#pragma unroll
+   for ( int it = 0; it < kB; ++it )
+   {
+      const int  r2   = r0 + it;
+      const int  base = rowBase[( it + 1 ) * kBH + threadIdx.x / kB + 1];
+      const bool ok   = r2 >= 1 && qw >= r2 + 1 && pw >= qw + 1 && pw <= n - 1;
+      stageR[it]      = ok ? A.rhs[base + pw] : 0.0;
+   }
    SOR_TRACE( 2 );
 #pragma unroll
    for ( int it = 0; it < kStageU; ++it )
    {
       const int idx = it * ( kB * kB ) + threadIdx.x;
       if ( idx < kBH * kBH * kBH )
-         lu[idx] = stage[it];
+         lu[( idx / kBH ) * kBP + idx % kBH + 2] = stage[it];
    }
+#pragma unroll
+   for ( int it = 0; it < kB; ++it )
+      lr[it * ( kB * kB ) + threadIdx.x] = stageR[it];
    const int ql = threadIdx.x % kB, rl = threadIdx.x / kB;
    const int q = q0 + ql, r = r0 + rl;
    const int y = q - r, z = r;
    // interior row? (y >= 1, z >= 1, and at least x = 1 fits: 1 + y + z <= n - 2)
    const bool row_ok = y >= 1 && z >= 1 && y + z <= n - 2;
-   // rhs and write-back: thread handles the entries idx = it * 256 + tid of the 16^3 block: pl = tid % 16, row (tid / 16, it)
-   const int  pw = p0 + threadIdx.x % kB, qw = q0 + threadIdx.x / kB;
-   {
-      double stageR[kB];
-#pragma unroll
-      for ( int it = 0; it < kB; ++it )
-      {
-         const int  r2   = r0 + it;
-         const int  base = rowBase[( it + 1 ) * kBH + threadIdx.x / kB + 1];
-         const bool ok   = r2 >= 1 && qw >= r2 + 1 && pw >= qw + 1 && pw <= n - 1;
-         stageR[it]      = ok ? A.rhs[base + pw] : 0.0;
-      }
-#pragma unroll
-      for ( int it = 0; it < kB; ++it )
-         lr[it * ( kB * kB ) + threadIdx.x] = stageR[it];
-   }
+   // the interior points of the row inside this block: pl in [plo, phi]   (x = p - q >= 1, x + y + z = p <= n - 1)
+   const int plo = row_ok ? max( 0, q + 1 - p0 ) : 1;
+   const int phi = row_ok ? min( kB - 1, n - 1 - p0 ) : 0;
    __syncthreads();
    SOR_TRACE( 3 );
 
-   const double* w = A.w;
+   // One hyperplane per step; thread (ql,rl) updates the point C = (s - ql - rl, ql, rl) of plane s.  Two things keep
+   // the step short (measured with exp/sor_trace.hip and exp/lat_probe.hip: the step is bound by LDS
+   // bandwidth -- 64 lanes x 8 B = 4 clocks per read instruction per wave -- and by the write -> barrier -> read turn):
+   //  * values travel along p in registers.  In every (dq,dr) column of the stencil the two neighbours of C are adjacent
+   //    in p, and the leading one of step s is the trailing one of step s+1 (same version: a value is read either
+   //    before or after its one update, never across it), so a step reads only the 7 leading neighbours + rhs: 8 LDS
+   //    reads instead of 16;
+   //  * only W (the thread's own previous result), SE and BN were written on the previous plane.  Everything else of the
+   //    sum is formed one step AHEAD ("base" of the point X = C + 1), so the critical path of a step is
+   //    2 reads -> fma, fma, add -> write -> barrier.
+   // The step is branch-free (idle threads read clamped addresses and store to `sink`), so the compiler interleaves the
+   // two computations.  Backward sweep = the mirror image: all offsets negated, weight k <-> 14 - k.
+   // relax / centre weight are folded into the weights: u_new = (1-relax) u + sum_k ( -relax w_k / w_c ) u_k +
+   // ( relax / w_c ) rhs.  The ORDER OF UPDATES is the reference's; the order of the additions inside one update is not.
+   const double* w  = A.w;
+   const double  kk = A.relax * A.invc;
+#define WT( k ) ( -kk * w[BW ? 14 - ( k ) : ( k )] )
+   const double kW = WT( 6 ), kSE = WT( 5 ), kBN = WT( 3 );
+   const double kE = WT( 8 ), kN = WT( 10 ), kNW = WT( 9 ), kTC = WT( 14 ), kTW = WT( 13 ), kTSE = WT( 12 ), kTS = WT( 11 );
+   const double kS = WT( 4 ), kBC = WT( 0 ), kBE = WT( 1 ), kBNW = WT( 2 );
+#undef WT
+   constexpr int SG = BW ? -1 : 1;
+#define OFF( dp, dq, dr ) ( SG * ( ( dp ) + ( dq ) * kBP + ( dr ) * kBP * kBH ) )
+   const int cRow = lds_index( 0, ql, rl ), rRow = ( rl * kB + ql ) * kB;
+   double    base = 0.0, uW = 0.0, ownC = 0.0, ownX = 0.0, nw = 0.0, tw = 0.0, ts = 0.0, bc = 0.0;
+   SOR_STEP_DECL
+   auto      step = [&]( int s ) {
+      const int    C = s - ql - rl, X = C + SG;
+      const bool   act = C >= plo && C <= phi;
+      const int    cC = cRow + min( max( C, -3 ), kB + 2 ), cX = cRow + min( max( X, -2 ), kB + 1 );
+      const double vSE = lu[cC + OFF( 0, -1, 0 )], vBN = lu[cC + OFF( 0, 0, -1 )];
+      const double vE = lu[cX + OFF( 1, 0, 0 )], vN = lu[cX + OFF( 1, 1, 0 )], vTC = lu[cX + OFF( 1, 1, 1 )];
+      const double vTSE = lu[cX + OFF( 1, 0, 1 )], vBE = lu[cX + OFF( 0, -1, -1 )];
+      const double vR   = lr[rRow + min( max( X, 0 ), kB - 1 )];
+      SOR_STEP_STAMP( 0 );
+      // the point of this step
+      const double unew = fma( kW, uW, base ) + fma( kBN, vBN, kSE * vSE );
+      *( act ? &lu[cC] : &sink[threadIdx.x] ) = unew;
+      // everything of the next point that is known already
+      double a0 = A.one_minus_relax * ownX;
+      double a1 = kk * vR;
+      double a2 = kE * vE;
+      double a3 = kN * vN;
+      a0        = fma( kNW, nw, a0 );
+      a1        = fma( kTC, vTC, a1 );
+      a2        = fma( kTW, tw, a2 );
+      a3        = fma( kTSE, vTSE, a3 );
+      a0        = fma( kTS, ts, a0 );
+      a1        = fma( kS, vSE, a1 );
+      a2        = fma( kBC, bc, a2 );
+      a3        = fma( kBE, vBE, a3 );
+      a0        = fma( kBNW, vBN, a0 );
+      base      = ( a0 + a1 ) + ( a2 + a3 );
+      uW        = act ? unew : ownC;
+      ownC = ownX, ownX = vE, nw = vN, tw = vTC, ts = vTSE, bc = vBE;
+      SOR_STEP_STAMP( 1 );
+   };
+#undef OFF
+   // three idle steps fill the registers (every thread is idle in them: nothing is written, no barrier needed)
+   constexpr int sFirst = BW ? 3 * kB - 3 : 0;
+   step( sFirst - 3 * SG );
+   step( sFirst - 2 * SG );
+   step( sFirst - SG );
 #pragma unroll 1
-   for ( int step = 0; step < 3 * kB - 2; ++step )
+   for ( int k = 0; k < 3 * kB - 2; ++k )
    {
-      const int s  = A.backwards ? ( 3 * kB - 3 - step ) : step;
-      const int pl = s - ql - rl;
-      if ( pl >= 0 && pl < kB )
-      {
-         const int x = p0 + pl - q;
-         if ( row_ok && x >= 1 && x + y + z <= n - 1 )
-         {
-            const int c = lds_index( pl, ql, rl );
-#define LU( dp, dq, dr ) lu[c + ( dp ) + ( dq ) * kBH + ( dr ) * kBH * kBH]
-            // 14 terms -(w_k u_k) in the reference's order (sor_3D_macrocell_P1.cpp:74), rhs last
-            // three partial sums (a 15-deep dependent FMA chain per step is latency on the critical path of the
-            // whole sweep); the order of the UPDATES is the reference's, the order of additions inside one update is not
-            double a0 = -w[3] * LU( 0, 0, -1 );          // BN  ( 0, 1,-1)
-            double a1 = -w[10] * LU( 1, 1, 0 );          // N   ( 0, 1, 0)
-            double a2 = -w[5] * LU( 0, -1, 0 );          // SE  ( 1,-1, 0)
-            a0        = fma( -w[12], LU( 1, 0, 1 ), a0 );   // TSE ( 1,-1, 1)
-            a1        = fma( -w[1], LU( 0, -1, -1 ), a1 );  // BE  ( 1, 0,-1)
-            a2        = fma( -w[8], LU( 1, 0, 0 ), a2 );    // E   ( 1, 0, 0)
-            a0        = fma( -w[6], LU( -1, 0, 0 ), a0 );   // W   (-1, 0, 0)
-            a1        = fma( -w[13], LU( 0, 1, 1 ), a1 );   // TW  (-1, 0, 1)
-            a2        = fma( -w[2], LU( -1, 0, -1 ), a2 );  // BNW (-1, 1,-1)
-            a0        = fma( -w[9], LU( 0, 1, 0 ), a0 );    // NW  (-1, 1, 0)
-            a1        = fma( -w[4], LU( -1, -1, 0 ), a1 );  // S   ( 0,-1, 0)
-            a2        = fma( -w[11], LU( 0, 0, 1 ), a2 );   // TS  ( 0,-1, 1)
-            a0        = fma( -w[0], LU( -1, -1, -1 ), a0 ); // BC  ( 0, 0,-1)
-            a1        = fma( -w[14], LU( 1, 1, 1 ), a1 );   // TC  ( 0, 0, 1)
-            a2        = a2 + lr[( rl * kB + ql ) * kB + pl];
-            const double acc = ( a0 + a1 ) + a2;
-            lu[c]      = A.relax * A.invc * acc + A.one_minus_relax * lu[c];
-#undef LU
-         }
-      }
+      SOR_STEP_STAMP( 4 );
+      step( sFirst + SG * k );
+      SOR_STEP_STAMP( 2 );
+#if defined( SOR_ABLATE ) && ( SOR_ABLATE & 1 )
+      asm volatile( "s_waitcnt lgkmcnt(0)" ::: "memory" );
+#else
       __syncthreads();
+#endif
+      SOR_STEP_STAMP( 3 );
    }
+   SOR_STEP_FLUSH
    SOR_TRACE( 4 );
 
    // write the updated interior points back (coalesced along p = along x)
@@ -268,64 +357,36 @@ __device__ inline void sor_block_body( const SorBlockView A, const SorBlock blk 
    SOR_TRACE( 5 );
 }
 
-// per level: the non-empty blocks sorted by wavefront, and the wavefront offsets
-struct SorBlockTable
+// per level: the non-empty block wavefronts T = P + Q + R with the bounding box of their (Q,R) (host-side only)
+struct SorWavefront
 {
-   const SorBlock*    dev = nullptr;
-   std::vector< int > wavefrontStart; // size nwavefronts + 1
+   int T, Q0, nQ, R0, nR;
 };
 
-int get_sor_blocks( int level, const SorBlockTable** out )
+const std::vector< SorWavefront >& sor_wavefronts( int level )
 {
    static std::mutex                                   mtx;
-   static std::map< std::pair< int, int >, SorBlockTable > cache;
-   int                                                 dev = 0;
-   HH_CHECK_HIP( hipGetDevice( &dev ) );
-   std::lock_guard< std::mutex > lock( mtx );
-   auto                          key = std::make_pair( dev, level );
-   auto                          it  = cache.find( key );
+   static std::map< int, std::vector< SorWavefront > > cache;
+   std::lock_guard< std::mutex >                       lock( mtx );
+   auto                                                it = cache.find( level );
    if ( it == cache.end() )
    {
-      const int n  = 1 << level;
-      const int nb = ( n + kB - 1 ) / kB;
-      std::vector< std::vector< SorBlock > > byT( 3 * nb );
-      for ( int R = 0; R < nb; ++R )
-         for ( int Q = R; Q < nb; ++Q )
-            for ( int P = Q; P < nb; ++P )
-            {
-               // non-empty iff some interior point: r>=1, q>=r+1, p>=q+1, p<=n-1 within the block ranges
-               const int rmin = std::max( 1, R * kB ), rmax = std::min( n - 3, R * kB + kB - 1 );
-               if ( rmin > rmax )
-                  continue;
-               const int qmin = std::max( rmin + 1, Q * kB ), qmax = std::min( n - 2, Q * kB + kB - 1 );
-               if ( qmin > qmax )
-                  continue;
-               const int pmin = std::max( qmin + 1, P * kB ), pmax = std::min( n - 1, P * kB + kB - 1 );
-               if ( pmin > pmax )
-                  continue;
-               byT[P + Q + R].push_back( SorBlock{ (short) P, (short) Q, (short) R, 0 } );
-            }
-      SorBlockTable           tab;
-      std::vector< SorBlock > flat;
-      tab.wavefrontStart.push_back( 0 );
-      for ( auto& v : byT )
+      const int                   n  = 1 << level;
+      const int                   nb = ( n + kB - 1 ) / kB;
+      std::vector< SorWavefront > wf;
+      for ( int T = 0; T <= 3 * ( nb - 1 ); ++T )
       {
-         if ( v.empty() )
-            continue;
-         flat.insert( flat.end(), v.begin(), v.end() );
-         tab.wavefrontStart.push_back( (int) flat.size() );
+         int qlo = nb, qhi = -1, rlo = nb, rhi = -1;
+         for ( int R = 0; R < nb; ++R )
+            for ( int Q = R; Q < nb; ++Q )
+               if ( sor_block_nonempty( n, T - Q - R, Q, R ) )
+                  qlo = std::min( qlo, Q ), qhi = std::max( qhi, Q ), rlo = std::min( rlo, R ), rhi = std::max( rhi, R );
+         if ( qhi >= 0 )
+            wf.push_back( SorWavefront{ T, qlo, qhi - qlo + 1, rlo, rhi - rlo + 1 } );
       }
-      if ( !flat.empty() )
-      {
-         void* p = nullptr;
-         HH_CHECK_HIP( hipMalloc( &p, flat.size() * sizeof( SorBlock ) ) );
-         HH_CHECK_HIP( hipMemcpy( p, flat.data(), flat.size() * sizeof( SorBlock ), hipMemcpyHostToDevice ) );
-         tab.dev = static_cast< const SorBlock* >( p );
-      }
-      it = cache.emplace( key, std::move( tab ) ).first;
+      it = cache.emplace( level, std::move( wf ) ).first;
    }
-   *out = &it->second;
-   return HYTEG_HIP_OK;
+   return it->second;
 }
 
 
@@ -484,11 +545,8 @@ HYTEG_HIP_API int hyteg_hip_p1_sor_cells( int                  ncells,
       HH_CHECK_HIP( hipGetLastError() );
       return HYTEG_HIP_OK;
    }
-   const SorBlockTable* tab = nullptr;
-   int                  rc  = get_sor_blocks( level, &tab );
-   if ( rc != HYTEG_HIP_OK )
-      return rc;
-   int k = 0;
+   const std::vector< SorWavefront >& wf = sor_wavefronts( level );
+   int                                k  = 0;
    while ( k < m )
    {
       int e = k;
@@ -498,14 +556,17 @@ HYTEG_HIP_API int hyteg_hip_p1_sor_cells( int                  ncells,
       for ( int j = k; j <= e; ++j )
          B.u[j - k] = u[sel[j]], B.rhs[j - k] = rhs[sel[j]];
       B.stencils = stencils_dev + (size_t) sel[k] * 225;
-      B.N = N, B.backwards = backwards ? 1 : 0, B.relax = relax, B.one_minus_relax = 1.0 + ( -relax );
-      const int nw = (int) tab->wavefrontStart.size() - 1;
+      B.N = N, B.relax = relax, B.one_minus_relax = 1.0 + ( -relax );
+      const int nw = (int) wf.size();
       for ( int q = 0; q < nw; ++q )
       {
-         const int wv = backwards ? nw - 1 - q : q;
-         const int lo = tab->wavefrontStart[wv], hi = tab->wavefrontStart[wv + 1];
-         B.blocks     = tab->dev + lo;
-         hipLaunchKernelGGL( p1_sor_block_batch_kernel, dim3( hi - lo, e - k + 1 ), dim3( kB * kB ), 0, as_stream( stream ), B );
+         const SorWavefront& W = wf[backwards ? nw - 1 - q : q];
+         B.T = W.T, B.Q0 = W.Q0, B.R0 = W.R0;
+         const dim3 grid( W.nQ, W.nR, e - k + 1 );
+         if ( backwards )
+            hipLaunchKernelGGL( p1_sor_block_batch_kernel< true >, grid, dim3( kB * kB ), 0, as_stream( stream ), B );
+         else
+            hipLaunchKernelGGL( p1_sor_block_batch_kernel< false >, grid, dim3( kB * kB ), 0, as_stream( stream ), B );
       }
       k = e + 1;
    }
@@ -539,26 +600,24 @@ HYTEG_HIP_API int hyteg_hip_p1_sor_cell( double*            u,
    if ( level >= 5 && g_sorAlgorithm.load( std::memory_order_relaxed ) != HYTEG_HIP_SOR_PLANES )
    {
       // blocked sweep: one launch per block wavefront
-      const SorBlockTable* tab = nullptr;
-      int                  rc  = get_sor_blocks( level, &tab );
-      if ( rc != HYTEG_HIP_OK )
-         return rc;
-      SorBlockArgs B;
+      const std::vector< SorWavefront >& wf = sor_wavefronts( level );
+      SorBlockArgs                       B;
       B.u               = u;
       B.rhs             = rhs;
       B.N               = A.N;
-      B.backwards       = backwards ? 1 : 0;
       B.relax           = relax;
       B.one_minus_relax = A.one_minus_relax;
       B.invc            = A.invc;
       B.st              = A.st;
-      const int nw      = (int) tab->wavefrontStart.size() - 1;
+      const int nw      = (int) wf.size();
       for ( int k = 0; k < nw; ++k )
       {
-         const int wv = backwards ? nw - 1 - k : k;
-         const int lo = tab->wavefrontStart[wv], hi = tab->wavefrontStart[wv + 1];
-         B.blocks     = tab->dev + lo;
-         hipLaunchKernelGGL( p1_sor_block_kernel, dim3( hi - lo ), dim3( kB * kB ), 0, as_stream( stream ), B );
+         const SorWavefront& W = wf[backwards ? nw - 1 - k : k];
+         B.T = W.T, B.Q0 = W.Q0, B.R0 = W.R0;
+         if ( backwards )
+            hipLaunchKernelGGL( p1_sor_block_kernel< true >, dim3( W.nQ, W.nR ), dim3( kB * kB ), 0, as_stream( stream ), B );
+         else
+            hipLaunchKernelGGL( p1_sor_block_kernel< false >, dim3( W.nQ, W.nR ), dim3( kB * kB ), 0, as_stream( stream ), B );
       }
       HH_CHECK_HIP( hipGetLastError() );
       return HYTEG_HIP_OK;
