@@ -34,6 +34,19 @@ int  fail( int code, const std::string& msg );
 inline bool level_ok( int level ) { return level >= HYTEG_HIP_MIN_LEVEL && level <= HYTEG_HIP_MAX_LEVEL; }
 
 // ---- HyTeG macro-cell layout (src/hyteg/indexing/MacroCellIndexing.hpp:40-52) ----------------
+// a product / a sum rounded on its own: the compiler contracts a * b + c into an FMA wherever it sees one (-ffp-contract=fast
+// is hipcc's default, and HIP's __dmul_rn / __dadd_rn are plain operators that contract as well).  Kernels that promise the
+// bits of the reference's scalar loops, or of each other, build their sums from these two.
+__host__ __device__ inline double mul_rn( double a, double b )
+{
+#pragma clang fp contract( off )
+   return a * b;
+}
+__host__ __device__ inline double add_rn( double a, double b )
+{
+#pragma clang fp contract( off )
+   return a + b;
+}
 __host__ __device__ inline int tri( int w ) { return ( w * ( w + 1 ) ) / 2; }
 __host__ __device__ inline int64_t tet64( int64_t w ) { return ( w * ( w + 1 ) * ( w + 2 ) ) / 6; }
 // start of slice z in a cell array of width N

@@ -359,13 +359,15 @@ __global__ __launch_bounds__( kThreads ) void batch_restrict_kernel( const Trans
          if ( fx < 0 || fy < 0 || fz < 0 || fx + fy + fz > Nf - 1 )
             continue;
          const int    fc   = point_class( Nf, fx, fy, fz );
-         const double term = ( fc == 14 ? 1.0 : inv[fc] ) * 0.5 * fine[cell_index( Nf, fx, fy, fz )];
-         acc               = first ? term : acc + term;
+         // products and sums rounded separately (no FMA contraction): the per-cell kernels of p1_transfer.hip do the same, so
+         // that both give the same bits as the reference's scalar loops
+         const double term = mul_rn( ( fc == 14 ? 1.0 : inv[fc] ) * 0.5, fine[cell_index( Nf, fx, fy, fz )] );
+         acc               = first ? term : add_rn( acc, term );
          first             = false;
       }
       const int    fc   = point_class( Nf, 2 * p.x, 2 * p.y, 2 * p.z );
-      const double term = ( fc == 14 ? 1.0 : inv[fc] ) * fine[cell_index( Nf, 2 * p.x, 2 * p.y, 2 * p.z )];
-      coarse[p.i]       = first ? term : acc + term;
+      const double term = mul_rn( fc == 14 ? 1.0 : inv[fc], fine[cell_index( Nf, 2 * p.x, 2 * p.y, 2 * p.z )] );
+      coarse[p.i]       = first ? term : add_rn( acc, term );
    }
 }
 
@@ -389,14 +391,15 @@ __global__ __launch_bounds__( kThreads ) void batch_prolongate_kernel( const Tra
       const double old  = ( A.update == HYTEG_HIP_ADD && p.cls == 14 ) ? fine[p.i] : 0.0;
       double       v;
       if ( code == 0 )
-         v = old + sc * coarse[cell_index( Nc, p.x >> 1, p.y >> 1, p.z >> 1 )];
+         v = add_rn( old, mul_rn( sc, coarse[cell_index( Nc, p.x >> 1, p.y >> 1, p.z >> 1 )] ) );
       else
       {
          const int    ex = kAxisB[code][0], ey = kAxisB[code][1], ez = kAxisB[code][2];
          const double lo = coarse[cell_index( Nc, ( p.x - ex ) >> 1, ( p.y - ey ) >> 1, ( p.z - ez ) >> 1 )];
          const double hi = coarse[cell_index( Nc, ( p.x + ex ) >> 1, ( p.y + ey ) >> 1, ( p.z + ez ) >> 1 )];
          const double h  = sc * 0.5;
-         v               = kLoFirstB[code] ? ( old + h * lo ) + h * hi : ( old + h * hi ) + h * lo;
+         const double tl = mul_rn( h, lo ), th = mul_rn( h, hi );
+         v               = kLoFirstB[code] ? add_rn( add_rn( old, tl ), th ) : add_rn( add_rn( old, th ), tl );
       }
       fine[p.i] = v;
    }

@@ -291,7 +291,7 @@ def test_dot(env, level):
 _NNC_MIXED = [3, 4, 5, 6, 7, 8, 2, 1, 2, 2, 9, 10, 11, 12]
 
 
-@pytest.mark.parametrize("coarse_level", [0, 1, 2, 3, 5])
+@pytest.mark.parametrize("coarse_level", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("nnc", [[1] * 14, _NNC_MIXED])
 def test_restrict(env, coarse_level, nnc):
     torch, capi, po = env
@@ -306,7 +306,7 @@ def test_restrict(env, coarse_level, nnc):
     assert _rel(coarse.cpu().numpy(), ref) < TOL
 
 
-@pytest.mark.parametrize("coarse_level", [0, 1, 2, 3, 5])
+@pytest.mark.parametrize("coarse_level", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("nnc", [[1] * 14, _NNC_MIXED])
 @pytest.mark.parametrize("update", [0, 1])
 def test_prolongate_gather_equals_reference_scatter(env, coarse_level, nnc, update):

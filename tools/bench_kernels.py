@@ -21,6 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--level", type=int, default=8)
     ap.add_argument("--reps", type=int, default=200)
+    ap.add_argument("--only", default=None, help="time only the kernel rows whose name contains this text (skips the cycles)")
     args = ap.parse_args()
     L, reps = args.level, args.reps
     n, inner = capi.cell_size(L), capi.cell_inner_size(L)
@@ -42,6 +43,8 @@ def main():
     rows = []
 
     def timeit(name, fn, bytes_per_call, updates, r=reps):
+        if args.only and args.only not in name:
+            return
         for k in range(5):
             fn(k)
         torch.cuda.synchronize()
@@ -123,6 +126,9 @@ def main():
     timeit(f"P2 restrict level {L2} -> {L2 - 1}",
            lambda k: capi.p2_restrict_cell(CV[k % nb2].data_ptr(), CE[k % nb2].data_ptr(), SV[k % nb2].data_ptr(), SE[k % nb2].data_ptr(),
                                            L2 - 1, ones, 0x7FFF, sh), 8 * (nv2 + ne2 + nvc + nec), nvc + nec, r=max(3, reps // 10))
+    if args.only:
+        print(json.dumps({"level": L, "kernels": rows}))
+        return
     # BASELINE config 4 shape on one GPU: P2 Laplace, level 7, the 6 macro-cells one GPU holds (cube_6el = the unit cube)
     if L >= 7:
         s6 = host.Storage.from_gmsh(ROOT / "hyteg_amd/data/meshes/cube_6el.msh")
