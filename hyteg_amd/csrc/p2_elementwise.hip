@@ -13,6 +13,8 @@
 #include <mutex>
 #include <utility>
 
+#include <cstdlib>
+
 #include "common.hpp"
 
 using namespace hyteg_hip;
@@ -709,6 +711,157 @@ __global__ __launch_bounds__( kThreads ) void p2_inner_kernel( const P2FastArgs 
    }
 }
 
+// =====================================================================================================================
+// Row form of the inner stencils (levels >= 3).  p2_inner_kernel above spends ~90 % of its ~900 instructions per
+// DoF on index arithmetic (decoding (x, y, z) from the flat index, eight array indices, 64-bit addresses).  Here ONE WAVE
+// owns a run of <= 64 consecutive micro-vertex positions x of one row (y, z) -- a TILES_ROWS tile of the vertex array -- and
+// produces ALL EIGHT destination kinds at those positions:
+//   * y, z are wave-uniform, so every row base is scalar arithmetic: the index of (x0, y, z) in the three array widths
+//     (N, N-1, N-2) comes with the tile, the nine neighbour rows (y+dy, z+dz) of each width are layout-algebra deltas;
+//   * the union of the sources of all eight stencils (kSrc: distinct (kind, dx, dy, dz); 230 stencil entries share them) is
+//     loaded ONCE into registers by buffer loads whose whole byte offset sits in the vector offset -- a row that does not
+//     exist or a position beyond the end of a row gives an offset that is either out of range (the descriptor returns 0) or
+//     inside the array (a wrong value that only lanes use whose result is not stored): no clamping, no faults;
+//   * each destination kind sums its entries in the same order with the same FMAs as p2_inner_kernel (bit-identical
+//     results) and stores where p2_inner< C > holds.
+// =====================================================================================================================
+struct SrcList
+{
+   int n;
+   int kind[160], dx[160], dy[160], dz[160];
+};
+constexpr SrcList build_src_list()
+{
+   SrcList U{};
+   for ( int c = 0; c < 8; ++c )
+   {
+      const KindStencil S = build_kind_stencil( c );
+      for ( int q = 0; q < S.n; ++q )
+      {
+         bool found = false;
+         for ( int i = 0; i < U.n; ++i )
+            found = found || ( U.kind[i] == S.kind[q] && U.dx[i] == S.dx[q] && U.dy[i] == S.dy[q] && U.dz[i] == S.dz[q] );
+         if ( !found )
+         {
+            U.kind[U.n] = S.kind[q], U.dx[U.n] = S.dx[q], U.dy[U.n] = S.dy[q], U.dz[U.n] = S.dz[q];
+            ++U.n;
+         }
+      }
+   }
+   return U;
+}
+constexpr SrcList kSrc = build_src_list();
+static_assert( kSrc.n <= 160, "source list" );
+template < int C >
+struct SrcIndexOf
+{
+   int idx[kMaxStencil];
+};
+template < int C >
+constexpr SrcIndexOf< C > build_src_index()
+{
+   SrcIndexOf< C >       R{};
+   constexpr KindStencil S = KindStencilOf< C >::value;
+   for ( int q = 0; q < S.n; ++q )
+      for ( int i = 0; i < kSrc.n; ++i )
+         if ( kSrc.kind[i] == S.kind[q] && kSrc.dx[i] == S.dx[q] && kSrc.dy[i] == S.dy[q] && kSrc.dz[i] == S.dz[q] )
+            R.idx[q] = i;
+   return R;
+}
+template < int C >
+struct SrcIndex
+{
+   static constexpr SrcIndexOf< C > value = build_src_index< C >();
+};
+
+struct P2RowsArgs
+{
+   P2FastArgs  F;
+   const Tile* tiles; // TILES_ROWS of the vertex array, capacity 64; pad[0], pad[1] = the tile's first index at widths N-1, N-2
+   int         ntiles;
+   unsigned    vbytes, ebytes; // sizes of the vertex- and edge-DoF arrays
+};
+constexpr int kRowsWaves = 4;
+
+typedef int p2_v2i __attribute__( ( ext_vector_type( 2 ) ) );
+
+// byte offset (without the lane part, biased by -8 so that dx = -1, 0, 1 become the instruction offsets 0, 8, 16) of row
+// (y + DY, z + DZ) of source kind K, from the tile's indices i0[width class] of (x0, y, z)
+template < int K, int DY, int DZ >
+__device__ inline int p2_rows_base( const int ( &i0 )[3], int N, int y, int z )
+{
+   constexpr int c  = K == 0 ? 0 : ( K == 7 ? 2 : 1 );
+   const int     n  = N - 1;
+   const int     W  = N - c;
+   const int     bk = K == 0 ? 0 : ( K - 1 ) * (int) tet32( (unsigned) n );
+   return ( bk + p2_neighbour_row< DY, DZ >( i0[c], W - z, y ) - 1 ) * 8;
+}
+
+template < int C, int UPDATE >
+__device__ inline void p2_rows_kind( const P2RowsArgs& A, const double ( &U )[kSrc.n], const int ( &i0 )[3], int lane, int x, int y, int z,
+                                     int cnt, __amdgpu_buffer_rsrc_t rdV, __amdgpu_buffer_rsrc_t rdE )
+{
+   constexpr int NQ  = KindStencilOf< C >::value.n;
+   constexpr int OFF = stencil_offset( C );
+   // constant address space: the weights are read by scalar loads and enter the FMAs as SGPR operands
+   typedef const __attribute__( ( address_space( 4 ) ) ) double* cptr_t;
+   const cptr_t w   = (cptr_t) ( A.F.table + OFF );
+   double       acc = 0.0;
+   [&]< int... Q >( std::integer_sequence< int, Q... > ) { ( ( acc = fma( w[Q], U[SrcIndex< C >::value.idx[Q]], acc ) ), ... ); }
+   ( std::make_integer_sequence< int, NQ >{} );
+   acc                 = A.F.alpha * acc;
+   const int  N        = A.F.N, n = N - 1;
+   constexpr int c     = C == 0 ? 0 : ( C == 7 ? 2 : 1 );
+   const int  bk       = C == 0 ? 0 : ( C - 1 ) * (int) tet32( (unsigned) n );
+   const bool on       = lane < cnt && p2_inner< C >( N, x, y, z );
+   const int  voff     = on ? ( bk + i0[c] + lane ) * 8 : -8;
+   const __amdgpu_buffer_rsrc_t rd = C == 0 ? rdV : rdE;
+   if constexpr ( UPDATE == HYTEG_HIP_ADD ) // compile-time: a run-time branch made every kind wait for the previous kind's store
+   {
+      const p2_v2i o = __builtin_amdgcn_raw_buffer_load_b64( rd, voff, 0, 0 );
+      acc            = __hiloint2double( o.y, o.x ) + acc;
+   }
+   __builtin_amdgcn_raw_buffer_store_b64( p2_v2i{ __double2loint( acc ), __double2hiint( acc ) }, rd, voff, 0, 0 );
+}
+
+template < int UPDATE >
+__device__ inline void p2_rows_body( const P2RowsArgs& A, int block )
+{
+   const int t = __builtin_amdgcn_readfirstlane( block * kRowsWaves + ( (int) threadIdx.x >> 6 ) );
+   if ( t >= A.ntiles )
+      return;
+   const Tile tl   = A.tiles[t];
+   const int  lane = threadIdx.x & 63;
+   const int  N    = A.F.N;
+   const int  y = tl.ya, z = tl.z, x = tl.yb + lane;
+   const int  i0[3] = { tl.a, tl.pad[0], tl.pad[1] };
+   const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc( const_cast< double* >( A.F.srcV ), 0, A.vbytes, 0x00020000 );
+   const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc( const_cast< double* >( A.F.srcE ), 0, A.ebytes, 0x00020000 );
+   const __amdgpu_buffer_rsrc_t rdV = __builtin_amdgcn_make_buffer_rsrc( A.F.dstV, 0, A.vbytes, 0x00020000 );
+   const __amdgpu_buffer_rsrc_t rdE = __builtin_amdgcn_make_buffer_rsrc( A.F.dstE, 0, A.ebytes, 0x00020000 );
+   const int lane8 = lane * 8;
+
+   double U[kSrc.n];
+   [&]< int... I >( std::integer_sequence< int, I... > ) {
+      ( ( [&] {
+           constexpr int K = kSrc.kind[I], DX = kSrc.dx[I], DY = kSrc.dy[I], DZ = kSrc.dz[I];
+           const int     voff = p2_rows_base< K, DY, DZ >( i0, N, y, z ) + lane8 + ( DX + 1 ) * 8;
+           const p2_v2i  v    = __builtin_amdgcn_raw_buffer_load_b64( K == 0 ? rsV : rsE, voff, 0, 0 );
+           U[I]               = __hiloint2double( v.y, v.x );
+        }() ),
+        ... );
+   }
+   ( std::make_integer_sequence< int, kSrc.n >{} );
+
+   [&]< int... C >( std::integer_sequence< int, C... > ) { ( p2_rows_kind< C, UPDATE >( A, U, i0, lane, x, y, z, tl.cnt, rdV, rdE ), ... ); }
+   ( std::make_integer_sequence< int, 8 >{} );
+}
+template < int UPDATE >
+__global__ __launch_bounds__( 64 * kRowsWaves, 2 ) void p2_rows_kernel( const P2RowsArgs A )
+{
+   p2_rows_body< UPDATE >( A, (int) blockIdx.x );
+}
+
 // Boundary DoFs in stencil form (levels >= 2): which adjacent micro-cells exist depends only on the macro-primitive the DoF
 // lies on, so every (destination kind, point class) has its own weight row over the SAME compile-time entry list; entries
 // whose weight is zero (neighbour outside the macro-cell, or a genuinely vanishing coupling) are skipped.  Dense enumeration
@@ -729,7 +882,7 @@ struct P2ClassArgs
    unsigned   mask;
 };
 template < int C >
-__device__ inline void p2_boundary_body( const P2ClassArgs& B )
+__device__ inline void p2_boundary_body( const P2ClassArgs& B, int bx )
 {
    constexpr int     NQ  = KindStencilOf< C >::value.n;
    constexpr int     OFF = class_offset( C );
@@ -739,7 +892,7 @@ __device__ inline void p2_boundary_body( const P2ClassArgs& B )
    if ( W <= 0 )
       return;
    const int T = tri( W );
-   const int q = blockIdx.x * kThreads + threadIdx.x;
+   const int q = bx * kThreads + threadIdx.x;
    if ( q >= 4 * T )
       return;
    int x, y, z;
@@ -785,35 +938,38 @@ __device__ inline void p2_boundary_body( const P2ClassArgs& B )
    double*   out  = C == 0 ? A.dstV + i : A.dstE + edge_block_start( n, C ) + i;
    *out           = A.update == HYTEG_HIP_ADD ? *out + acc : acc;
 }
-__global__ __launch_bounds__( kThreads ) void p2_boundary_kernel( const P2ClassArgs B )
+__device__ inline void p2_boundary_dispatch( const P2ClassArgs& B, int kind, int bx )
 {
-   switch ( blockIdx.y )
+   switch ( kind )
    {
-   case 0:
-      p2_boundary_body< 0 >( B );
-      break;
-   case 1:
-      p2_boundary_body< 1 >( B );
-      break;
-   case 2:
-      p2_boundary_body< 2 >( B );
-      break;
-   case 3:
-      p2_boundary_body< 3 >( B );
-      break;
-   case 4:
-      p2_boundary_body< 4 >( B );
-      break;
-   case 5:
-      p2_boundary_body< 5 >( B );
-      break;
-   case 6:
-      p2_boundary_body< 6 >( B );
-      break;
-   default:
-      p2_boundary_body< 7 >( B );
-      break;
+   case 0: p2_boundary_body< 0 >( B, bx ); break;
+   case 1: p2_boundary_body< 1 >( B, bx ); break;
+   case 2: p2_boundary_body< 2 >( B, bx ); break;
+   case 3: p2_boundary_body< 3 >( B, bx ); break;
+   case 4: p2_boundary_body< 4 >( B, bx ); break;
+   case 5: p2_boundary_body< 5 >( B, bx ); break;
+   case 6: p2_boundary_body< 6 >( B, bx ); break;
+   default: p2_boundary_body< 7 >( B, bx ); break;
    }
+}
+__global__ __launch_bounds__( kThreads ) void p2_boundary_kernel( const P2ClassArgs B ) { p2_boundary_dispatch( B, blockIdx.y, blockIdx.x ); }
+
+// inner rows and boundary DoFs in ONE launch (they write disjoint DoFs and read the same sources): the boundary workgroups
+// -- thread per DoF, a long chain of index arithmetic and dependent loads -- come first and run beside the row waves
+// instead of after them
+static_assert( kThreads == 64 * kRowsWaves, "the fused launch uses one block shape" );
+template < int UPDATE >
+__global__ __launch_bounds__( kThreads, 2 ) void p2_apply_fused_kernel( const P2RowsArgs A, unsigned shellMask, int nbx )
+{
+   if ( (int) blockIdx.x < 8 * nbx )
+   {
+      P2ClassArgs B;
+      B.F    = A.F;
+      B.mask = shellMask;
+      p2_boundary_dispatch( B, (int) blockIdx.x / nbx, (int) blockIdx.x % nbx );
+      return;
+   }
+   p2_rows_body< UPDATE >( A, (int) blockIdx.x - 8 * nbx );
 }
 
 // host: does micro-cell (type t, index m) lie inside a macro-cell of width N?
@@ -1011,13 +1167,49 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell( double*            dst_ve
    mask &= HYTEG_HIP_MASK_ALL;
    if ( mask == 0 )
       return HYTEG_HIP_OK;
-   hipStream_t s = as_stream( stream );
+   hipStream_t       s = as_stream( stream );
+   static const bool perThread = [] {
+      const char* e = std::getenv( "HYTEG_HIP_P2_INNER_THREADS" ); // measurement switch: round 1's thread-per-DoF kernel, two launches
+      return e && e[0] == '1';
+   }();
+   P2FastArgs F;
+   F.dstV = dst_vertex, F.dstE = dst_edge, F.srcV = src_vertex, F.srcE = src_edge, F.table = optable_dev, F.alpha = alpha;
+   F.N = ( 1 << level ) + 1, F.update = update;
+   const int  faces = 4 * tri( F.N );
+   const int  nbx   = ( faces + kThreads - 1 ) / kThreads;
+   const bool rows  = ( mask & HYTEG_HIP_MASK_INNER ) && level >= 3 && !perThread;
+   if ( rows )
+   {
+      // inner DoFs by rows (p2_rows_body); the boundary DoFs, if asked for, in the same launch
+      TileTable tt;
+      const int rc = get_tiles( level, TILES_ROWS, 64, &tt );
+      if ( rc != HYTEG_HIP_OK )
+         return rc;
+      P2RowsArgs R;
+      R.F = F, R.tiles = tt.dev, R.ntiles = tt.count;
+      const int n = F.N - 1;
+      R.vbytes    = (unsigned) ( tet64( F.N ) * 8 );
+      R.ebytes    = (unsigned) ( ( 6 * tet64( n ) + tet64( n - 1 ) ) * 8 );
+      const unsigned rowBlocks = (unsigned) ( ( tt.count + kRowsWaves - 1 ) / kRowsWaves );
+      const unsigned shell     = mask & HYTEG_HIP_MASK_SHELL;
+      const int      nb        = shell ? nbx : 0;
+      if ( nb == 0 )
+      {
+         if ( update == HYTEG_HIP_ADD )
+            hipLaunchKernelGGL( p2_rows_kernel< HYTEG_HIP_ADD >, dim3( rowBlocks ), dim3( kThreads ), 0, s, R );
+         else
+            hipLaunchKernelGGL( p2_rows_kernel< HYTEG_HIP_REPLACE >, dim3( rowBlocks ), dim3( kThreads ), 0, s, R );
+      }
+      else if ( update == HYTEG_HIP_ADD )
+         hipLaunchKernelGGL( p2_apply_fused_kernel< HYTEG_HIP_ADD >, dim3( 8 * nb + rowBlocks ), dim3( kThreads ), 0, s, R, shell, nb );
+      else
+         hipLaunchKernelGGL( p2_apply_fused_kernel< HYTEG_HIP_REPLACE >, dim3( 8 * nb + rowBlocks ), dim3( kThreads ), 0, s, R, shell, nb );
+      HH_CHECK_HIP( hipGetLastError() );
+      return HYTEG_HIP_OK;
+   }
    if ( mask & HYTEG_HIP_MASK_INNER )
    {
-      // inner DoFs: compile-time stencils, all destination kinds in one launch
-      P2FastArgs F;
-      F.dstV = dst_vertex, F.dstE = dst_edge, F.srcV = src_vertex, F.srcE = src_edge, F.table = optable_dev, F.alpha = alpha;
-      F.N = ( 1 << level ) + 1, F.update = update;
+      // inner DoFs: compile-time stencils, one thread per DoF, all destination kinds in one launch
       const int64_t largest = tet64( F.N );
       hipLaunchKernelGGL( p2_inner_kernel, dim3( (unsigned) ( ( largest + kThreads - 1 ) / kThreads ), 8 ), dim3( kThreads ), 0, s, F );
    }
@@ -1025,10 +1217,8 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell( double*            dst_ve
    {
       // DoFs on the macro-cell boundary: per-class constant stencils
       P2ClassArgs B;
-      B.F.dstV = dst_vertex, B.F.dstE = dst_edge, B.F.srcV = src_vertex, B.F.srcE = src_edge, B.F.table = optable_dev, B.F.alpha = alpha;
-      B.F.N = ( 1 << level ) + 1, B.F.update = update, B.mask = mask & HYTEG_HIP_MASK_SHELL;
-      const int faces = 4 * tri( B.F.N );
-      hipLaunchKernelGGL( p2_boundary_kernel, dim3( (unsigned) ( ( faces + kThreads - 1 ) / kThreads ), 8 ), dim3( kThreads ), 0, s, B );
+      B.F = F, B.mask = mask & HYTEG_HIP_MASK_SHELL;
+      hipLaunchKernelGGL( p2_boundary_kernel, dim3( (unsigned) nbx, 8 ), dim3( kThreads ), 0, s, B );
    }
    else if ( mask & HYTEG_HIP_MASK_SHELL )
    {

@@ -37,6 +37,10 @@ static std::vector< Tile > build_tiles( int level, TileKind kind, int capacity )
                tl.z   = z;
                tl.ya  = y;
                tl.yb  = x0;
+               // the same (x0, y, z) in tetrahedral arrays of width N-1 and N-2 (the P2 edge-DoF kinds; plain index algebra,
+               // meaningful only where the point exists there)
+               tl.pad[0] = N >= 2 ? cell_index( N - 1, x0, y, z ) : 0;
+               tl.pad[1] = N >= 3 ? cell_index( N - 2, x0, y, z ) : 0;
                tiles.push_back( tl );
             }
          }
