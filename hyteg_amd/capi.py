@@ -101,6 +101,8 @@ SIGNATURES = {
     "hyteg_hip_p1_sor_shell_cells": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i, _vp, _d, C.POINTER(C.c_uint), _i, _vp]),
     "hyteg_hip_p1_sor_shell_cell": (_i, [_vp, _vp, _vp, _i, C.POINTER(_i), _dp, C.POINTER(_i), _dp, _dp, _d, C.c_uint, _i, _vp]),
     "hyteg_hip_p1_apply_face3d": (_i, [_vp, _vp, _i, _i, C.POINTER(_i), _dp, _i, _vp]),
+    "hyteg_hip_p1_sor_face3d_workspace": (C.c_size_t, [_i]),
+    "hyteg_hip_p1_sor_face3d": (_i, [_vp, _vp, _vp, _i, _i, C.POINTER(_i), _dp, C.c_double, _i, _vp]),
     "hyteg_hip_gather_entries": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
 }
 MASK_INNER, MASK_SHELL, MASK_ALL = 1 << 14, 0x3FFF, 0x7FFF
@@ -456,6 +458,19 @@ def p1_sor_shell_cell(dst, rhs, rest, level, edge_verts, edge_w, face_verts, fac
     check(lib().hyteg_hip_p1_sor_shell_cell(dst, rhs, rest, level, (C.c_int * 12)(*ev), (C.c_double * 18)(*ew), (C.c_int * 12)(*fv),
                                             (C.c_double * 28)(*fw), (C.c_double * 4)(*vw), float(relax), mask, 1 if backwards else 0,
                                             stream), "p1_sor_shell_cell")
+
+
+def p1_sor_face3d_workspace(level):
+    return int(lib().hyteg_hip_p1_sor_face3d_workspace(level))
+
+
+def p1_sor_face3d(dst, rhs, work, level, vmaps, ws, relax, backwards=False, stream=0):
+    """SOR sweep over one macro-face in HyTeG's face layout (sor_3D_macroface_P1*); work: p1_sor_face3d_workspace(level) bytes."""
+    n = len(vmaps)
+    flat_v = [int(v) for m in vmaps for v in m]
+    flat_w = [float(x) for w in ws for x in w]
+    check(lib().hyteg_hip_p1_sor_face3d(dst, rhs, work, level, n, (C.c_int * len(flat_v))(*flat_v), (C.c_double * len(flat_w))(*flat_w),
+                                        float(relax), int(bool(backwards)), stream), "p1_sor_face3d")
 
 
 def p1_apply_face3d(dst, src, level, vmaps, ws, update=REPLACE, stream=0):

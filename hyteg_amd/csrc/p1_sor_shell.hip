@@ -256,6 +256,114 @@ __global__ __launch_bounds__( 1024 ) void p1_sor_face_sweep_kernel( const SorShe
    }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same sweep in HyTeG's OWN macro-face layout [ tri(N) face DoFs | ghost layer of cell 0 | ghost layer of cell 1 ]
+// (hyteg_hip_p1_sor_face3d; replaces sor_3D_macroface_P1{,_one_sided}{,_backwards}, reference loop
+// P1Operator::smooth_sor_face3D, P1Operator.hpp:1424-1503).  Which face-array entry a stencil leaf of a neighbour cell lands on
+// is a property of the leaf and the cell's vertex map alone (the map is linear), so the host folds the 2 x 14 leaves into
+// seven in-plane weights (centre + W E S N SE NW, summed over the cells) and a list of ghost-layer leaves; the preparation
+// kernel forms  a = (1 - relax) u + relax / c ( rhs - ghost leaves - in-plane neighbours that are not updated before the
+// point ), the sweep kernel is the hyperplane wavefront above with the face array's own index function.
+// ---------------------------------------------------------------------------------------------------------------------
+struct FaceSorArgs
+{
+   double*       dst;
+   const double* rhs;
+   double*       work; // tri(N) doubles
+   int           N, backwards;
+   double        relax;
+   double        W[7]; // centre, then W E S N SE NW (kFaceDirs order), each summed over the neighbour cells
+   int           nghost;
+   int           gk[32], gdx[32], gdy[32]; // ghost-layer leaves: neighbour cell, offset in face coordinates
+   double        gw[32];
+};
+
+__global__ __launch_bounds__( kPrepThreads ) void p1_sor_face3d_prep_kernel( const FaceSorArgs A )
+{
+   const int    N = A.N, j = blockIdx.x + 1;
+   const double sc = A.relax / A.W[0];
+   for ( int i = 1 + (int) threadIdx.x; i <= N - 2 - j; i += kPrepThreads )
+   {
+      const int idx = row_start( N, j ) + i;
+      double    t   = A.rhs[idx];
+      for ( int g = 0; g < A.nghost; ++g )
+         t -= A.gw[g] * A.dst[tri( N ) + A.gk[g] * tri( N - 1 ) + row_start( N - 1, j + A.gdy[g] ) + i + A.gdx[g]];
+#pragma unroll
+      for ( int d = 0; d < 6; ++d )
+      {
+         // forward: W, S, SE are updated before (i,j); backwards: E, N, NW
+         const bool prev = A.backwards ? ( d & 1 ) : !( d & 1 );
+         const int  ni = i + kFaceDirs[d][0], nj = j + kFaceDirs[d][1];
+         if ( !prev || !face_interior( N, ni, nj ) )
+            t -= A.W[1 + d] * A.dst[row_start( N, nj ) + ni];
+      }
+      A.work[idx] = ( 1.0 - A.relax ) * A.dst[idx] + sc * t;
+   }
+}
+
+template < int RPT >
+__global__ __launch_bounds__( 1024 ) void p1_sor_face3d_sweep_kernel( const FaceSorArgs A )
+{
+   extern __shared__ double val[]; // [3][stride]
+   const int                N = A.N, R = N - 3, bw = A.backwards;
+   const int                stride = RPT * (int) blockDim.x + 2;
+   const double             sc     = A.relax / A.W[0];
+   const int                kappa  = bw ? 1 : 2;
+   // neighbour in the same row, neighbour of step tau-1, neighbour of step tau-2
+   const int    dL = bw ? 1 : 0, d1 = bw ? 5 : 4, d2 = bw ? 3 : 2;
+   const double bL = -sc * A.W[1 + dL], b1 = -sc * A.W[1 + d1], b2 = -sc * A.W[1 + d2];
+   const int    tauMin = 1 + kappa, tauMax = bw ? 2 * N - 6 : 2 * N - 5;
+
+   double q[RPT][kSweepDepth];
+   double left[RPT];
+   int    rr[RPT], jj[RPT], len[RPT];
+#pragma unroll
+   for ( int u = 0; u < RPT; ++u )
+   {
+      rr[u]   = (int) threadIdx.x + 1 + u * (int) blockDim.x; // ordinal of the row in sweep order
+      jj[u]   = bw ? R + 1 - rr[u] : rr[u];
+      len[u]  = N - 2 - jj[u];
+      left[u] = 0.0;
+#pragma unroll
+      for ( int k = 0; k < kSweepDepth; ++k )
+      {
+         const int s = tauMin + k - kappa * rr[u];
+         q[u][k]     = ( rr[u] <= R && s >= 1 && s <= len[u] ) ? A.work[row_start( N, jj[u] ) + ( bw ? len[u] + 1 - s : s )] : 0.0;
+      }
+   }
+   int p0 = tauMin % 3; // LDS ring slot of the current step
+   for ( int tau0 = tauMin; tau0 <= tauMax; tau0 += kSweepDepth )
+   {
+#pragma unroll
+      for ( int k = 0; k < kSweepDepth; ++k )
+      {
+         const int tau = tau0 + k;
+         const int pm1 = p0 == 0 ? 2 : p0 - 1, pm2 = pm1 == 0 ? 2 : pm1 - 1;
+#pragma unroll
+         for ( int u = 0; u < RPT; ++u )
+         {
+            const int s = tau - kappa * rr[u];
+            if ( rr[u] <= R && s >= 1 && s <= len[u] )
+            {
+               const int i = bw ? len[u] + 1 - s : s, j = jj[u];
+               if ( s == 1 )
+                  left[u] = 0.0;
+               const double n1 = face_interior( N, i + kFaceDirs[d1][0], j + kFaceDirs[d1][1] ) ? val[pm1 * stride + rr[u] - 1] : 0.0;
+               const double n2 = face_interior( N, i + kFaceDirs[d2][0], j + kFaceDirs[d2][1] ) ? val[pm2 * stride + rr[u] - 1] : 0.0;
+               const double v  = fma( bL, left[u], fma( b1, n1, fma( b2, n2, q[u][k] ) ) );
+               left[u]                       = v;
+               val[p0 * stride + rr[u]]      = v;
+               A.dst[row_start( N, j ) + i]  = v;
+            }
+            const int sn = s + kSweepDepth;
+            q[u][k]      = ( rr[u] <= R && sn >= 1 && sn <= len[u] ) ? A.work[row_start( N, jj[u] ) + ( bw ? len[u] + 1 - sn : sn )] : 0.0;
+         }
+         __syncthreads();
+         p0 = p0 == 2 ? 0 : p0 + 1;
+      }
+   }
+}
+
 bool is_perm( const int* v, int n, const int* ref )
 {
    for ( int a = 0; a < n; ++a )
@@ -397,6 +505,84 @@ HYTEG_HIP_API int hyteg_hip_p1_sor_shell_cells( int                             
    A.table = reinterpret_cast< const SorShellDesc* >( tables_dev );
    A.N = ( 1 << level ) + 1, A.relax = relax, A.backwards = backwards ? 1 : 0;
    return launch_sor_shell( A, ncells, any, backwards, as_stream( stream ) );
+}
+
+HYTEG_HIP_API size_t hyteg_hip_p1_sor_face3d_workspace( int level )
+{
+   const int N = ( 1 << level ) + 1;
+   return (size_t) tri( N ) * sizeof( double );
+}
+
+HYTEG_HIP_API int hyteg_hip_p1_sor_face3d( double*            dst_face,
+                                           const double*      rhs_face,
+                                           double*            work,
+                                           int                level,
+                                           int                ncells,
+                                           const int*         vmaps,
+                                           const double*      w,
+                                           double             relax,
+                                           int                backwards,
+                                           hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( dst_face && rhs_face && work && vmaps && w, "p1_sor_face3d: null pointer" );
+   HH_REQUIRE( level >= 1 && level <= HYTEG_HIP_MAX_LEVEL, "p1_sor_face3d: level out of range [1,11]" );
+   HH_REQUIRE( ncells == 1 || ncells == 2, "p1_sor_face3d: a macro-face has 1 or 2 neighbour cells" );
+   HH_REQUIRE( dst_face != rhs_face, "p1_sor_face3d: dst and rhs must not alias" );
+   static const int offs[15][3] = { { 0, 0, -1 }, { 1, 0, -1 }, { -1, 1, -1 }, { 0, 1, -1 }, { 0, -1, 0 }, { 1, -1, 0 }, { -1, 0, 0 }, { 0, 0, 0 },
+                                    { 1, 0, 0 },  { -1, 1, 0 }, { 0, 1, 0 },   { 0, -1, 1 }, { 1, -1, 1 }, { -1, 0, 1 }, { 0, 0, 1 } };
+   static const int dirs[6][2]   = { { -1, 0 }, { 1, 0 }, { 0, -1 }, { 0, 1 }, { 1, -1 }, { -1, 1 } }; // = kFaceDirs
+   FaceSorArgs A{};
+   A.dst = dst_face, A.rhs = rhs_face, A.work = work, A.N = ( 1 << level ) + 1, A.backwards = backwards ? 1 : 0, A.relax = relax;
+   for ( int k = 0; k < ncells; ++k )
+   {
+      const int v0 = vmaps[3 * k], v1 = vmaps[3 * k + 1], v2 = vmaps[3 * k + 2];
+      HH_REQUIRE( v0 >= 0 && v0 < 4 && v1 >= 0 && v1 < 4 && v2 >= 0 && v2 < 4 && v0 != v1 && v0 != v2 && v1 != v2, "p1_sor_face3d: bad vertex map" );
+      const int v3 = 6 - v0 - v1 - v2;
+      for ( int s = 0; s < 15; ++s )
+      {
+         // a cell offset in barycentric coordinates, read off in the face's frame (the vertex map is linear)
+         const int bary[4] = { -offs[s][0] - offs[s][1] - offs[s][2], offs[s][0], offs[s][1], offs[s][2] };
+         const int dfx = bary[v1], dfy = bary[v2], dfz = bary[v3];
+         const double ws = w[15 * k + s];
+         if ( dfz < 0 )
+            continue; // the leaf lies outside this cell: not part of its share
+         if ( dfz == 0 )
+         {
+            if ( dfx == 0 && dfy == 0 )
+            {
+               A.W[0] += ws;
+               continue;
+            }
+            int d = -1;
+            for ( int e = 0; e < 6; ++e )
+               if ( dirs[e][0] == dfx && dirs[e][1] == dfy )
+                  d = e;
+            HH_REQUIRE( d >= 0, "p1_sor_face3d: in-plane leaf off the face stencil" );
+            A.W[1 + d] += ws;
+            continue;
+         }
+         HH_REQUIRE( A.nghost < 32, "p1_sor_face3d: too many ghost leaves" );
+         A.gk[A.nghost] = k, A.gdx[A.nghost] = dfx, A.gdy[A.nghost] = dfy, A.gw[A.nghost] = ws;
+         ++A.nghost;
+      }
+   }
+   HH_REQUIRE( A.W[0] != 0.0, "p1_sor_face3d: zero centre weight" );
+   const int R = A.N - 3;
+   if ( R < 1 )
+      return HYTEG_HIP_OK; // no inner face DoFs below level 2
+   hipStream_t st = as_stream( stream );
+   hipLaunchKernelGGL( p1_sor_face3d_prep_kernel, dim3( R ), dim3( kPrepThreads ), 0, st, A );
+   const int    rpt     = R > 512 ? ( R > 1024 ? 4 : 2 ) : 1;
+   const int    threads = ( ( ( R + rpt - 1 ) / rpt + 63 ) / 64 ) * 64;
+   const size_t lds     = size_t( 3 ) * ( size_t( rpt ) * threads + 2 ) * sizeof( double );
+   if ( rpt == 4 )
+      hipLaunchKernelGGL( p1_sor_face3d_sweep_kernel< 4 >, dim3( 1 ), dim3( threads ), lds, st, A );
+   else if ( rpt == 2 )
+      hipLaunchKernelGGL( p1_sor_face3d_sweep_kernel< 2 >, dim3( 1 ), dim3( threads ), lds, st, A );
+   else
+      hipLaunchKernelGGL( p1_sor_face3d_sweep_kernel< 1 >, dim3( 1 ), dim3( threads ), lds, st, A );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
 }
 
 } // extern "C"

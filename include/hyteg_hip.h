@@ -632,6 +632,26 @@ HYTEG_HIP_API int hyteg_hip_p1_apply_face3d( double*            dst_face,
                                              const double*      w /* host, ncells*15 */,
                                              int                update,
                                              hyteg_hip_stream_t stream );
+/* sor_face3d replaces vertexdof::macroface::generated::sor_3D_macroface_P1 / _one_sided and their _backwards variants
+ *   (src/constant_stencil_operator/P1generatedKernels/sor_3D_macroface_P1*.cpp; call site P1ConstantOperator.cpp:432-571;
+ *   the loop they unroll: P1Operator::smooth_sor_face3D, P1Operator.hpp:1424-1503): in-place SOR / Gauss-Seidel sweep over
+ *   the inner DoFs of ONE macro-face in lexicographic (y, x) order (backwards: reversed), ghost layers read as they are.
+ *   dst_face: face array with ncells ghost layers; rhs_face: at least the tri(N) face DoFs; vmaps, w as for apply_face3d
+ *   (w[7] of every cell = its share of the centre weight).  work: hyteg_hip_p1_sor_face3d_workspace( level ) bytes of
+ *   device memory (the sweep is split into a parallel preparation pass and a wavefront pass; the values in between live
+ *   there).  The updates are made in the reference's order; the terms of one update are summed in a different order
+ *   (tests compare at 1e-12). */
+HYTEG_HIP_API size_t hyteg_hip_p1_sor_face3d_workspace( int level );
+HYTEG_HIP_API int hyteg_hip_p1_sor_face3d( double*            dst_face,
+                                           const double*      rhs_face,
+                                           double*            work,
+                                           int                level,
+                                           int                ncells,
+                                           const int*         vmaps /* host, ncells*3 */,
+                                           const double*      w /* host, ncells*15 */,
+                                           double             relax,
+                                           int                backwards,
+                                           hyteg_hip_stream_t stream );
 
 /* ---- f1: quadratic (P2) grid transfer on one macro-cell -----------------------------------------------------------
  * replaces P2toP2QuadraticProlongation::prolongateAdditively3D and P2toP2QuadraticRestriction::restrictAdditively3D

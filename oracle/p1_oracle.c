@@ -899,6 +899,59 @@ HO_API void ho_apply_face3d( double* dst, const double* src, int level, int ncel
       }
 }
 
+/* SOR / Gauss-Seidel sweep over the inner DoFs of ONE macro-face in HyTeG's own face layout
+ * [ tri(N) face DoFs | ghost layer of neighbour cell 0 | ghost layer of neighbour cell 1 ], in place.
+ * P1Operator::smooth_sor_face3D, src/hyteg/p1functionspace/P1Operator.hpp:1424-1503 (the loop the constant-stencil operator's
+ * generated kernels sor_3D_macroface_P1{,_one_sided}{,_backwards} unroll; call site P1ConstantOperator.cpp:432-571): for every
+ * inner face DoF in lexicographic (y, x) order -- backwards: the reverse order -- tmp = rhs - sum over the neighbour cells of
+ * that cell's off-centre stencil leaves (in-plane leaves from the face DoFs, leaves at distance 1 from the cell's ghost
+ * layer), dst = (1 - relax) dst + relax tmp / (sum of the cells' centre weights).  vmaps, w as in ho_apply_face3d. */
+HO_API void ho_sor_face3d( double* dst, const double* rhs, int level, int ncells, const int* vmaps, const double* w, double relax, int backwards )
+{
+   const int64_t N = ho_width( level ), n = N - 1;
+   double        centre = 0.0;
+   for ( int k = 0; k < ncells; ++k )
+      centre += w[15 * k + 7];
+   const double  inv   = 1.0 / centre;
+   const int64_t count = ( N - 3 ) * ( N - 2 ) / 2; /* inner face DoFs: y = 1..N-3, x = 1..N-2-y */
+   for ( int64_t q = 0; q < count; ++q )
+   {
+      /* the q-th inner DoF in (y, x) order, or in the reverse of that order */
+      int64_t r = backwards ? count - 1 - q : q, y = 1;
+      while ( r >= N - 2 - y )
+      {
+         r -= N - 2 - y;
+         ++y;
+      }
+      const int64_t x   = 1 + r;
+      double        tmp = rhs[ho_face_index_w( N, x, y )];
+      for ( int k = 0; k < ncells; ++k )
+      {
+         const int* v  = vmaps + 3 * k;
+         const int  v3 = 6 - v[0] - v[1] - v[2];
+         int64_t    c[3];
+         face_to_cell_coords( n, v, x, y, 0, c );
+         for ( int s = 0; s < 15; ++s )
+         {
+            if ( s == 7 )
+               continue;
+            const int64_t lx = c[0] + OFFS[s][0], ly = c[1] + OFFS[s][1], lz = c[2] + OFFS[s][2];
+            if ( !inside( N, lx, ly, lz ) )
+               continue;
+            int64_t       bary[4] = { n - lx - ly - lz, lx, ly, lz };
+            const int64_t fx = bary[v[1]], fy = bary[v[2]], fz = bary[v3];
+            if ( fz > 1 )
+               continue;
+            const int64_t idx = fz == 0 ? ho_face_index_w( N, fx, fy ) :
+                                          ho_face_size_w( N ) + k * ho_face_size_w( N - 1 ) + ho_face_index_w( N - 1, fx, fy );
+            tmp -= w[15 * k + s] * dst[idx];
+         }
+      }
+      const int64_t i = ho_face_index_w( N, x, y );
+      dst[i]          = ( 1.0 - relax ) * dst[i] + relax * tmp * inv;
+   }
+}
+
 /* ---- SOR / Gauss-Seidel on the macro-vertices, -edges and -faces around one cell, cell-centric restatement ----
  * vertexdof::macrovertex::smooth_sor (src/hyteg/p1functionspace/VertexDoFMacroVertex.hpp:231-251),
  * P1Operator::smooth_sor_edge (src/hyteg/p1functionspace/P1Operator.hpp:1352-1421) and

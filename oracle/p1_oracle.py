@@ -78,6 +78,7 @@ def _bind(lib):
         "ho_copy_face_to_cell": (None, [_P, _P, i, i, i, i]),
         "ho_copy_cell_to_face": (None, [_P, _P, i, i, i, i, i]),
         "ho_apply_face3d": (None, [_P, _P, i, i, C.POINTER(C.c_int), _P, i]),
+        "ho_sor_face3d": (None, [_P, _P, i, i, C.POINTER(C.c_int), _P, C.c_double, i]),
         "ho_edge_array_size": (ll, [i]),
         "ho_edge_index": (ll, [i, ll, ll, ll, i]),
         "ho_p2_micro_cell_dofs": (None, [i, i, ll, ll, ll, C.POINTER(ll)]),
@@ -360,6 +361,13 @@ def copy_face_to_cell(cell, face, level, v):
 def copy_cell_to_face(face, cell, level, v, neighbor):
     lib().ho_copy_cell_to_face(_p(face), _p(cell), level, *map(int, v), int(neighbor))
     return face
+
+
+def sor_face3d(dst, rhs, level, vmaps, ws, relax, backwards=False):
+    """P1Operator::smooth_sor_face3D on one macro-face in HyTeG's face layout, in place (P1Operator.hpp:1424-1503)."""
+    vm = np.ascontiguousarray(np.array(vmaps, dtype=np.int32).reshape(-1))
+    w = np.ascontiguousarray(np.array(ws, dtype=np.float64).reshape(-1))
+    lib().ho_sor_face3d(_p(dst), _p(rhs), level, len(vmaps), vm.ctypes.data_as(C.POINTER(C.c_int)), _p(w), float(relax), int(bool(backwards)))
 
 
 def apply_face3d(dst, src, level, vmaps, ws, update=REPLACE):

@@ -76,3 +76,33 @@ def test_apply_face3d(env, level, ncells):
             # only the inner face DoFs are written
             nf = po.face_size_w(po.width(level))
             assert np.array_equal(got[nf:], dst0[nf:])
+
+
+@pytest.mark.parametrize("level", [2, 3, 5, 7])
+@pytest.mark.parametrize("ncells", [1, 2])
+def test_sor_face3d(env, level, ncells):
+    """sor_3D_macroface_P1{,_one_sided}{,_backwards} in HyTeG's face layout against the literal restatement of
+    P1Operator::smooth_sor_face3D (P1Operator.hpp:1424-1503): the updates in the same order, the sums reassociated."""
+    torch, capi, po = env
+    rng = np.random.default_rng(11 * level + ncells)
+    tets = [SKEW_TET, OCT_TET]
+    nface = po.face_array_size(level, 2)
+    u0, rhs_h = rng.random(nface), rng.random(nface)
+    rhs = _dev(torch, rhs_h)
+    work = torch.zeros(capi.p1_sor_face3d_workspace(level) // 8, dtype=torch.float64, device="cuda")
+    for vs in ([(0, 1, 2), (2, 0, 3)], [(3, 1, 0), (1, 2, 3)], [(1, 3, 2), (0, 2, 1)]):
+        vmaps = vs[:ncells]
+        ws = []
+        for k, v in enumerate(vmaps):
+            slot = 6 + {(0, 1, 2): 0, (0, 1, 3): 1, (0, 2, 3): 2, (1, 2, 3): 3}[tuple(sorted(v))]
+            ws.append(po.assemble_cell_slot_stencils(tets[k], level)[slot])
+        for relax, backwards in ((1.0, False), (1.0, True), (0.7, False), (1.3, True)):
+            u = _dev(torch, u0)
+            capi.p1_sor_face3d(u.data_ptr(), rhs.data_ptr(), work.data_ptr(), level, vmaps, ws, relax, backwards)
+            torch.cuda.synchronize()
+            ref = u0.copy()
+            po.sor_face3d(ref, rhs_h, level, vmaps, ws, relax, backwards)
+            got = u.cpu().numpy()
+            nf = po.face_size_w(po.width(level))
+            assert np.array_equal(got[nf:], u0[nf:])  # ghost layers untouched
+            assert np.linalg.norm(got - ref) <= 1e-12 * np.linalg.norm(ref)

@@ -122,3 +122,46 @@ def test_face_apply_equals_the_sum_of_the_cells_shares_and_annihilates_linears(f
                     assert out[k] == 0.0
                 k += 1
     st.close()
+
+
+@pytest.mark.parametrize("ncells", [1, 2])
+@pytest.mark.parametrize("backwards", [False, True])
+def test_sor_face3d_is_gauss_seidel_for_the_face_apply(ncells, backwards):
+    """ho_sor_face3d restates P1Operator::smooth_sor_face3D (P1Operator.hpp:1424-1503).  Pins: (i) one update leaves the
+    face equation of the LAST updated DoF satisfied exactly (relax = 1): (apply_face3d(u) - rhs) vanishes there; (ii) swept to
+    convergence, apply_face3d(u) = rhs at every inner face DoF while ghost layers and face boundary keep their values;
+    (iii) relax = 0 changes nothing."""
+    level = 3
+    n = 1 << level
+    rng = np.random.default_rng(5 + ncells)
+    vmaps = [(0, 1, 2), (2, 0, 3)][:ncells]
+    tets = [SKEW_TET, [[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]]]
+    ws = []
+    for k, v in enumerate(vmaps):
+        slot = 6 + {(0, 1, 2): 0, (0, 1, 3): 1, (0, 2, 3): 2, (1, 2, 3): 3}[tuple(sorted(v))]
+        ws.append(po.assemble_cell_slot_stencils(tets[k], level)[slot])
+    size = po.face_array_size(level, 2)
+    u0, rhs = rng.random(size), rng.random(size)
+    nf = po.face_size_w(po.width(level))
+    inner = np.zeros(size, dtype=bool)
+    k, order = 0, []
+    for y in range(n + 1):
+        for x in range(n + 1 - y):
+            if x >= 1 and y >= 1 and x + y <= n - 1:
+                inner[k] = True
+                order.append(k)
+            k += 1
+    u = u0.copy()
+    po.sor_face3d(u, rhs, level, vmaps, ws, 0.0, backwards)
+    assert np.array_equal(u, u0)
+    po.sor_face3d(u, rhs, level, vmaps, ws, 1.0, backwards)
+    assert np.array_equal(u[~inner], u0[~inner])
+    res = np.zeros(size)
+    po.apply_face3d(res, u, level, vmaps, ws)
+    last = order[0] if backwards else order[-1]
+    assert abs(res[last] - rhs[last]) < 1e-13 * abs(rhs[last])
+    for _ in range(400):
+        po.sor_face3d(u, rhs, level, vmaps, ws, 1.0, backwards)
+    po.apply_face3d(res, u, level, vmaps, ws)
+    assert np.abs(res[inner] - rhs[inner]).max() < 1e-11
+    assert np.array_equal(u[~inner], u0[~inner])
