@@ -694,6 +694,46 @@ HYTEG_HOST_API int hyteg_host_p2operator_apply( hh_p2operator_t op, hh_p2functio
 {
    return guarded( [&] { static_cast< P2OperatorH* >( op )->p->apply( F2( src ), F2( dst ), (uint_t) level, DoFType( flag ), UpdateType( update ) ); } );
 }
+/* P2 Jacobi smoother and geometric multigrid (P2ElementwiseOperator::smooth_jac, WeightedJacobiSmoother,
+ * GeometricMultigridSolver with P2toP2Quadratic{Restriction,Prolongation}, CG on the coarsest level) */
+HYTEG_HOST_API int hyteg_host_p2operator_compute_inverse_diagonal( hh_p2operator_t op )
+{
+   return guarded( [&] { static_cast< P2OperatorH* >( op )->p->computeInverseDiagonalOperatorValues(); } );
+}
+HYTEG_HOST_API int hyteg_host_p2operator_inverse_diagonal_copy( hh_p2operator_t op, hh_p2function_t dst, int level )
+{
+   return guarded( [&] { F2( dst ).assign( { 1.0 }, { *static_cast< P2OperatorH* >( op )->p->getInverseDiagonalValues() }, (uint_t) level, All ); } );
+}
+HYTEG_HOST_API int hyteg_host_p2operator_smooth_jac( hh_p2operator_t op, hh_p2function_t dst, hh_p2function_t rhs, hh_p2function_t src, double relax,
+                                                     int level, int flag )
+{
+   return guarded( [&] { static_cast< P2OperatorH* >( op )->p->smooth_jac( F2( dst ), F2( rhs ), F2( src ), relax, (uint_t) level, DoFType( flag ) ); } );
+}
+struct P2SolverH
+{
+   std::shared_ptr< Solver< P2ElementwiseLaplaceOperator > > p;
+};
+HYTEG_HOST_API int hyteg_host_p2_gmg_create( hh_storage_t s, int minL, int maxL, double relax, int pre, int post, int wcycle, int cgMaxIter, double cgTol,
+                                             hh_p2solver_t* out )
+{
+   return guarded( [&] {
+      using Op     = P2ElementwiseLaplaceOperator;
+      auto storage = static_cast< StorageH* >( s )->p;
+      auto smoother = std::make_shared< WeightedJacobiSmoother< Op > >( storage, (uint_t) minL, (uint_t) maxL, relax );
+      auto coarse   = std::make_shared< CGSolver< Op > >( storage, (uint_t) minL, (uint_t) minL, (uint_t) cgMaxIter, cgTol, cgTol );
+      *out          = new P2SolverH{ std::make_shared< GeometricMultigridSolver< Op, P2toP2QuadraticRestriction, P2toP2QuadraticProlongation > >(
+          storage, smoother, coarse, std::make_shared< P2toP2QuadraticRestriction >(), std::make_shared< P2toP2QuadraticProlongation >(),
+          (uint_t) minL, (uint_t) maxL, (uint_t) pre, (uint_t) post, 0, wcycle ? CycleType::WCYCLE : CycleType::VCYCLE ) };
+   } );
+}
+HYTEG_HOST_API int hyteg_host_p2_solver_solve( hh_p2solver_t solver, hh_p2operator_t op, hh_p2function_t x, hh_p2function_t b, int level )
+{
+   return guarded( [&] { static_cast< P2SolverH* >( solver )->p->solve( *static_cast< P2OperatorH* >( op )->p, F2( x ), F2( b ), (uint_t) level ); } );
+}
+HYTEG_HOST_API int hyteg_host_p2_solver_destroy( hh_p2solver_t solver )
+{
+   return guarded( [&] { delete static_cast< P2SolverH* >( solver ); } );
+}
 HYTEG_HOST_API int hyteg_host_p2_cg_solve( hh_storage_t s, hh_p2operator_t op, hh_p2function_t x, hh_p2function_t b, int level, int maxIter,
                                            double tol, int* iterations )
 {

@@ -129,6 +129,14 @@ class P2Function
    {
       vectorOp( 1, scalars, functions, level, flag );
    }
+   // P2Function::multElementwise (P2Function.cpp: vertex- and edge-DoF parts separately)
+   void multElementwise( const std::vector< std::reference_wrapper< const P2Function< ValueType > > >& functions,
+                         uint_t                                                                    level,
+                         DoFType                                                                   flag = All ) const
+   {
+      vectorOp( 2, std::vector< ValueType >( functions.size(), ValueType( 1 ) ), functions, level, flag );
+   }
+   uint64_t uid() const { return uid_; }
    // a shared DoF is counted by its lowest-numbered neighbour cell only
    ValueType dotLocal( const P2Function< ValueType >& rhs, uint_t level, DoFType flag = All ) const
    {
@@ -200,14 +208,16 @@ class P2Function
                   DoFType                                                                   flag ) const
    {
       if ( functions.empty() || functions.size() > HYTEG_HIP_MAX_SRCS || scalars.size() != functions.size() )
-         throw std::runtime_error( "P2Function::assign/add: bad number of functions or scalars" );
+         throw std::runtime_error( "P2Function::assign/add/multElementwise: bad number of functions or scalars" );
       std::vector< std::reference_wrapper< const P1Function< ValueType > > > vs;
       for ( uint_t k = 0; k < functions.size(); ++k )
          vs.push_back( functions[k].get().vertexDoFFunction_ );
       if ( op == 0 )
          vertexDoFFunction_.assign( scalars, vs, level, flag );
-      else
+      else if ( op == 1 )
          vertexDoFFunction_.add( scalars, vs, level, flag );
+      else
+         vertexDoFFunction_.multElementwise( vs, level, flag );
       forCells( [&]( uint_t c, const MacroCell& cell ) {
          const double* es[HYTEG_HIP_MAX_SRCS];
          for ( uint_t k = 0; k < functions.size(); ++k )
@@ -223,6 +233,7 @@ class P2Function
    uint_t                                                 minLevel_, maxLevel_;
    P1Function< ValueType >                                vertexDoFFunction_;
    std::vector< std::vector< double* > >                  edge_; // [local cell][level - minLevel]
+   uint64_t                                               uid_ = nextUid();
 };
 
 } // namespace hyteg

@@ -112,6 +112,76 @@ class P2ElementwiseOperator
             hostMatrices_[l].push_back( h );
          }
    }
+   uint64_t uid() const { return uid_; }
+
+   // P2ElementwiseOperator::computeInverseDiagonalOperatorValues (P2ElementwiseOperator.hpp:110, computeDiagonalOperatorValues .cpp:420-520:
+   // every micro-cell adds the diagonal of its element matrix to its ten DoFs, shared DoFs are summed over the macro-cells, then the
+   // entries are inverted).  Here: the apply kernel with element matrices whose off-diagonal entries are zeroed, applied to the
+   // function 1 -- every DoF receives exactly the sum of the elMat[k][k] of its adjacent micro-cells, through the same kernels and
+   // the same additive exchange as apply() -- and a reciprocal on the host (set-up time, once per operator).
+   void computeInverseDiagonalOperatorValues()
+   {
+      inverseDiagonalValues_.reset( new P2Function< double >( "inverse diagonal entries", storage_, minLevel_, maxLevel_ ) );
+      P2Function< double > ones( "p2_diag_ones", storage_, minLevel_, maxLevel_ );
+      for ( uint_t l = minLevel_; l <= maxLevel_; ++l )
+      {
+         ones.interpolate( 1.0, l, All );
+         std::vector< const double* > diagTables;
+         for ( uint_t c = 0; c < storage_->getNumberOfLocalCells(); ++c )
+         {
+            std::vector< double > h( 600, 0.0 );
+            const auto&           full = hostMatrices_.at( l ).at( c );
+            for ( int t = 0; t < 6; ++t )
+               for ( int k = 0; k < 10; ++k )
+                  h[100 * t + 11 * k] = full[100 * t + 11 * k];
+            std::vector< double > table( hyteg_hip_p2_operator_table_size() );
+            hipCheck( hyteg_hip_p2_build_operator_table( h.data(), table.data() ), "P2ElementwiseOperator: diagonal table" );
+            diagTables.push_back( storage_->uploadTable( table ) );
+         }
+         const P2Function< double >& d = *inverseDiagonalValues_;
+         launchWith( diagTables, 1.0, ones, d, l, All, HYTEG_HIP_MASK_ALL, HYTEG_HIP_REPLACE );
+         if ( storage_->getCells().size() > 1 )
+         {
+            d.getVertexDoFFunction().sumSharedCopies( l, All );
+            d.sumSharedEdgeCopies( l, All );
+         }
+         const size_t          nv = (size_t) layout::cellSize( (int) l ), ne = std::max< size_t >( 1, d.getNumberOfEdgeDoFs( l ) );
+         std::vector< double > hv( nv ), he( ne );
+         for ( uint_t c = 0; c < storage_->getNumberOfLocalCells(); ++c )
+         {
+            d.getVertexDoFFunction().copyCellToHost( c, l, hv.data() );
+            d.copyEdgeToHost( c, l, he.data() );
+            hipCheck( hyteg_hip_stream_synchronize( storage_->stream() ), "P2ElementwiseOperator: inverse diagonal" );
+            for ( auto& v : hv )
+               v = v != 0.0 ? 1.0 / v : 0.0;
+            for ( auto& v : he )
+               v = v != 0.0 ? 1.0 / v : 0.0;
+            d.getVertexDoFFunction().copyCellFromHost( c, l, hv.data() );
+            d.copyEdgeFromHost( c, l, he.data() );
+         }
+      }
+   }
+   std::shared_ptr< P2Function< double > > getInverseDiagonalValues() const
+   {
+      if ( !inverseDiagonalValues_ )
+         throw std::runtime_error( "Inverse diagonal values have not been assembled, call computeInverseDiagonalOperatorValues() "
+                                   "to set up this function." );
+      return inverseDiagonalValues_;
+   }
+
+   // P2ElementwiseOperator::smooth_jac (P2ElementwiseOperator.cpp:344-374), statement by statement:
+   //   dst = A src;  dst = rhs - dst;  dst = D^-1 dst;  dst = src + relax dst
+   void smooth_jac( const P2Function< double >& dst, const P2Function< double >& rhs, const P2Function< double >& src, double relax,
+                    uint_t level, DoFType flag ) const
+   {
+      if ( &dst == &src )
+         throw std::runtime_error( "P2ElementwiseOperator::smooth_jac: src and dst must differ" );
+      apply( src, dst, level, flag );
+      dst.assign( { 1.0, -1.0 }, { rhs, dst }, level, flag );
+      dst.multElementwise( { *getInverseDiagonalValues(), dst }, level, flag );
+      dst.assign( { 1.0, relax }, { src, dst }, level, flag );
+   }
+
    std::shared_ptr< PrimitiveStorage > getStorage() const { return storage_; }
    const std::vector< double >&        getElementMatrices( uint_t level, uint_t localCell = 0 ) const { return hostMatrices_.at( level ).at( localCell ); }
 
@@ -153,13 +223,18 @@ class P2ElementwiseOperator
    void launch( double alpha, const P2Function< double >& src, const P2Function< double >& dst, uint_t level, DoFType flag, unsigned keep,
                 int update ) const
    {
+      launchWith( elementMatrices_.at( level ), alpha, src, dst, level, flag, keep, update );
+   }
+   void launchWith( const std::vector< const double* >& tables, double alpha, const P2Function< double >& src, const P2Function< double >& dst,
+                    uint_t level, DoFType flag, unsigned keep, int update ) const
+   {
       for ( uint_t c = 0; c < storage_->getNumberOfLocalCells(); ++c )
       {
          const MacroCell& cell = storage_->getLocalCell( c );
          hipCheck( hyteg_hip_p2_elementwise_apply_cell( dst.getVertexDoFFunction().getCellPointer( c, level ), dst.getEdgeCellPointer( c, level ),
                                                         src.getVertexDoFFunction().getCellPointer( c, level ), src.getEdgeCellPointer( c, level ),
-                                                        (int) level, elementMatrices_.at( level ).at( c ), alpha, update,
-                                                        storage_->maskFor( cell, flag ) & keep, storage_->stream() ),
+                                                        (int) level, tables.at( c ), alpha, update, storage_->maskFor( cell, flag ) & keep,
+                                                        storage_->stream() ),
                    "P2ElementwiseOperator::gemv" );
       }
    }
@@ -167,6 +242,8 @@ class P2ElementwiseOperator
    uint_t                                                       minLevel_, maxLevel_;
    std::map< uint_t, std::vector< const double* > >             elementMatrices_;
    std::map< uint_t, std::vector< std::vector< double > > >     hostMatrices_;
+   std::shared_ptr< P2Function< double > >                      inverseDiagonalValues_;
+   uint64_t                                                     uid_ = nextUid();
 };
 using P2ElementwiseLaplaceOperator = P2ElementwiseOperator< forms::P2LaplaceForm >; // P2ElementwiseOperator.hpp:454
 

@@ -5,6 +5,7 @@
 #include "p1operator.hpp"
 #include "p2operator.hpp"
 #include "gridtransfer.hpp"
+#include "p2gridtransfer.hpp"
 
 namespace hyteg {
 
@@ -32,12 +33,13 @@ template < class OperatorType >
 class WeightedJacobiSmoother : public Solver< OperatorType >
 {
  public:
+   using FunctionType = typename OperatorType::srcType; // P1Function or P2Function
    WeightedJacobiSmoother( const std::shared_ptr< PrimitiveStorage >& storage, uint_t minLevel, uint_t maxLevel, double relax )
    : relax_( relax )
    , tmp_( "weighted_jacobi_tmp", storage, minLevel, maxLevel )
    , flag_( Inner | NeumannBoundary )
    {}
-   void solve( const OperatorType& A, const P1Function< double >& x, const P1Function< double >& b, uint_t level ) override
+   void solve( const OperatorType& A, const FunctionType& x, const FunctionType& b, uint_t level ) override
    {
       tmp_.assign( { 1.0 }, { x }, level, All );
       A.smooth_jac( x, b, tmp_, relax_, level, flag_ );
@@ -45,7 +47,7 @@ class WeightedJacobiSmoother : public Solver< OperatorType >
    // n steps with ONE copy instead of n: after tmp = x (all points) a Jacobi step may just as well write into tmp
    // reading x, since a step only writes the points `flag_` selects and all other entries of the two functions agree.
    // Every step computes exactly what solve() computes (same kernel, same operands): results are bit-identical.
-   void solveSteps( const OperatorType& A, const P1Function< double >& x, const P1Function< double >& b, uint_t level, uint_t steps ) override
+   void solveSteps( const OperatorType& A, const FunctionType& x, const FunctionType& b, uint_t level, uint_t steps ) override
    {
       if ( steps == 0 )
          return;
@@ -62,9 +64,9 @@ class WeightedJacobiSmoother : public Solver< OperatorType >
    }
 
  private:
-   double               relax_;
-   P1Function< double > tmp_;
-   DoFType              flag_;
+   double       relax_;
+   FunctionType tmp_;
+   DoFType      flag_;
 };
 
 // Mixed-precision weighted Jacobi: the "fp32 smoother" of BASELINE config 5.  The reference instantiates its generated apply

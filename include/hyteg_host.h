@@ -183,6 +183,20 @@ HYTEG_HOST_API int hyteg_host_p2operator_destroy( hh_p2operator_t op );
 /* the six 10 x 10 element matrices (FEniCS ordering) of a local cell at `level` */
 HYTEG_HOST_API int hyteg_host_p2operator_element_matrices( hh_p2operator_t op, int local_cell, int level, double* out600 );
 HYTEG_HOST_API int hyteg_host_p2operator_apply( hh_p2operator_t op, hh_p2function_t src, hh_p2function_t dst, int level, int flag, int update );
+/* P2 Jacobi smoother and multigrid.  compute_inverse_diagonal: P2ElementwiseOperator::computeInverseDiagonalOperatorValues
+ * (P2ElementwiseOperator.hpp:110, .cpp:420-520); smooth_jac: .cpp:344-374 (dst != src);  gmg: GeometricMultigridSolver
+ * (src/hyteg/solvers/GeometricMultigridSolver.hpp) over WeightedJacobiSmoother, P2toP2QuadraticRestriction / Prolongation and a CG
+ * coarse-grid solver -- the composition of tests/hyteg/P2/P2GMG3DConvergenceTest.cpp with the Jacobi smoother in place of its
+ * Gauss-Seidel one (the edge-DoF Gauss-Seidel kernels are not built). */
+typedef void* hh_p2solver_t;
+HYTEG_HOST_API int hyteg_host_p2operator_compute_inverse_diagonal( hh_p2operator_t op );
+HYTEG_HOST_API int hyteg_host_p2operator_inverse_diagonal_copy( hh_p2operator_t op, hh_p2function_t dst, int level );
+HYTEG_HOST_API int hyteg_host_p2operator_smooth_jac( hh_p2operator_t op, hh_p2function_t dst, hh_p2function_t rhs, hh_p2function_t src, double relax,
+                                                     int level, int flag );
+HYTEG_HOST_API int hyteg_host_p2_gmg_create( hh_storage_t s, int min_level, int max_level, double relax, int pre, int post, int wcycle,
+                                             int cg_max_iter, double cg_tol, hh_p2solver_t* out );
+HYTEG_HOST_API int hyteg_host_p2_solver_solve( hh_p2solver_t solver, hh_p2operator_t op, hh_p2function_t x, hh_p2function_t b, int level );
+HYTEG_HOST_API int hyteg_host_p2_solver_destroy( hh_p2solver_t solver );
 /* CGSolver< P2ElementwiseLaplaceOperator > on one level, flags Inner | NeumannBoundary as in the reference's CGSolver */
 HYTEG_HOST_API int hyteg_host_p2_cg_solve( hh_storage_t s, hh_p2operator_t op, hh_p2function_t x, hh_p2function_t b, int level, int max_iter,
                                            double tol, int* iterations );

@@ -1,0 +1,129 @@
+"""P2 weighted-Jacobi smoother and geometric multigrid through the host layer: the inverse diagonal against the
+oracle's element matrices, smooth_jac against its definition (P2ElementwiseOperator.cpp:344-374), and the multigrid cycle of
+tests/hyteg/P2/P2GMG3DConvergenceTest.cpp with the Jacobi smoother in place of its Gauss-Seidel one: a harmonic quadratic is in
+the P2 space, so the discrete solution IS the function and the cycles must recover it from its Dirichlet data."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parent.parent
+MESHES = ROOT / "hyteg_amd" / "data" / "meshes"
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    import hostutil as hu
+    from hyteg_amd import host
+    from oracle import p1_oracle as po
+
+    assert torch.cuda.is_available()
+    return torch, host, po, hu
+
+
+def _upload(po, hu, st, f, level, fn):
+    for c in range(st.n_local_cells):
+        gid, co, nnc = st.local_cell(c)
+        f.upload(level, fn(hu.cell_points(co, level)), fn(po.edge_midpoints(co, level)), c)
+
+
+def _harmonic(p):
+    return p[:, 0] ** 2 - 0.5 * p[:, 1] ** 2 - 0.5 * p[:, 2] ** 2 + p[:, 0] * p[:, 1] + 2.0 * p[:, 2] - 1.0
+
+
+def test_p2_inverse_diagonal_matches_the_element_matrices(env):
+    """every DoF's diagonal entry is the sum of elMat[k][k] over its adjacent micro-cells: read it off the oracle's literal
+    scatter loop applied to unit vectors (level 2, one tetrahedron: 35 vertex + 130 edge DoFs)"""
+    torch, host, po, hu = env
+    level = 2
+    st = host.Storage.from_gmsh(MESHES / "tet_1el.msh")
+    A = host.P2ElementwiseLaplaceOperator(st, level, level)
+    A.compute_inverse_diagonal()
+    d = host.P2Function(st, "d", level, level)
+    A.inverse_diagonal_into(d, level)
+    gv, ge = d.download(level, 0)
+    gid, co, nnc = st.local_cell(0)
+    em = po.p2_cell_element_matrices(np.asarray(co).reshape(12), level)
+    nv, ne = po.cell_size(level), po.edge_array_size(level)
+    for kind, n, got in (("v", nv, gv), ("e", ne, ge)):
+        for i in range(n):
+            sv, se = np.zeros(nv), np.zeros(ne)
+            (sv if kind == "v" else se)[i] = 1.0
+            ov, oe = po.p2_elementwise_apply_cell(np.zeros(nv), np.zeros(ne), sv, se, level, em, 1.0, 0, 0x7FFF)
+            diag = (ov if kind == "v" else oe)[i]
+            assert diag > 0.0 and abs(got[i] * diag - 1.0) < 1e-13, (kind, i)
+    for o in (d, A):
+        o.close()
+    st.close()
+
+
+def test_p2_smooth_jac_is_its_definition(env):
+    """dst = src + relax D^-1 ( rhs - A src ) on the selected DoFs, untouched elsewhere"""
+    torch, host, po, hu = env
+    level = 3
+    st = host.Storage.from_gmsh(MESHES / "cube_6el.msh")
+    A = host.P2ElementwiseLaplaceOperator(st, level, level)
+    A.compute_inverse_diagonal()
+    x, b, y, r, d = (host.P2Function(st, n, level, level) for n in ("x", "b", "y", "r", "d"))
+    _upload(po, hu, st, x, level, lambda p: np.sin(2.0 * p[:, 0]) + p[:, 1] * p[:, 2])
+    _upload(po, hu, st, b, level, lambda p: np.cos(p[:, 0] + p[:, 1]) - p[:, 2])
+    _upload(po, hu, st, y, level, lambda p: 7.0 + 0.0 * p[:, 0])
+    A.inverse_diagonal_into(d, level)
+    A.smooth_jac(y, b, x, 0.6, level, host.Inner)
+    r.interpolate(0.0, level)
+    A.apply(x, r, level, host.Inner)
+    inner_v, inner_e = po.slot_of_points(level) == 14, po.edge_classes(level) == 14
+    for c in range(st.n_local_cells):
+        (xv, xe), (bv, be), (yv, ye), (rv, re_), (dv, de) = (f.download(level, c) for f in (x, b, y, r, d))
+        # Inner selects the DoFs that are not on the domain boundary: inside every macro-cell certainly
+        wv, we = xv + 0.6 * dv * (bv - rv), xe + 0.6 * de * (be - re_)
+        assert np.abs(yv[inner_v] - wv[inner_v]).max() <= 1e-13 * np.abs(wv).max()
+        assert np.abs(ye[inner_e] - we[inner_e]).max() <= 1e-13 * np.abs(we).max()
+    # Dirichlet DoFs keep their value: a corner of the cube
+    gid, co, nnc = st.local_cell(0)
+    yv, _ = y.download(level, 0)
+    assert yv[0] == 7.0
+    for o in (x, b, y, r, d, A):
+        o.close()
+    st.close()
+
+
+@pytest.mark.parametrize("mesh,min_level,max_level", [("tet_1el", 1, 4), ("cube_6el", 0, 3)])
+def test_p2_gmg_recovers_a_harmonic_quadratic(env, mesh, min_level, max_level):
+    torch, host, po, hu = env
+    st = host.Storage.from_gmsh(MESHES / f"{mesh}.msh")
+    A = host.P2ElementwiseLaplaceOperator(st, min_level, max_level)
+    A.compute_inverse_diagonal()
+    x, b, r, ex, err = (host.P2Function(st, n, min_level, max_level) for n in ("x", "b", "r", "ex", "err"))
+    L = max_level
+    _upload(po, hu, st, ex, L, _harmonic)
+    x.interpolate(0.0, L)
+    x.assign([1.0], [ex], L, host.DirichletBoundary)
+    b.interpolate(0.0, L)
+    gmg = host.P2Solver(st, min_level, max_level, relax=2.0 / 3.0, pre=3, post=3)
+
+    def residual():
+        r.interpolate(0.0, L)
+        A.apply(x, r, L, host.Inner)
+        r.assign([1.0, -1.0], [b, r], L, host.Inner)
+        return np.sqrt(r.dot(r, L, host.Inner))
+
+    def error():
+        err.assign([1.0, -1.0], [x, ex], L)
+        return np.sqrt(err.dot(err, L, host.All))
+
+    res = [residual()]
+    for _ in range(14):
+        gmg.solve(A, x, b, L)
+        res.append(residual())
+    rates = [res[k + 1] / res[k] for k in range(3, 9) if res[k] > 1e-12 * res[0]]
+    assert res[-1] < 1e-7 * res[0], res  # measured: ~0.2 per cycle on the single tetrahedron, levels 1-4
+    assert rates and max(rates) < 0.5, rates  # h-independent contraction of the V(3,3) Jacobi cycle with quadratic transfer
+    assert error() < 1e-7 * np.sqrt(ex.dot(ex, L, host.All))
+    for o in (x, b, r, ex, err, A, gmg):
+        o.close()
+    st.close()
