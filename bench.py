@@ -280,6 +280,7 @@ def main():
                                   + ("ncclSend/ncclRecv groups issued by the C++ host layer on a communication stream (RCCL over xGMI), "
                                      "event-ordered, overlapped with the interior kernel" if ctx.transport == "rccl" else
                                      "torch.distributed all_to_all hooks (rehearsal transport)")
+                                  + (f" [{ctx.transport_note}]" if ctx.transport_note else "")
                                   if world > 1 else None),
                 "device": capi.device_name(),
             },

@@ -32,8 +32,16 @@ class DistributedContext:
         self.device = torch.device(device)
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
-        if transport == "auto":
-            transport = "rccl" if (dist.get_backend() == "nccl" and self.device.type == "cuda") else "hooks"
+        auto = transport == "auto"
+        self.transport_note = ""
+        if auto:
+            transport = "hooks"
+            if dist.get_backend() == "nccl" and self.device.type == "cuda":
+                # every rank must be able to load librccl BEFORE the collective communicator set-up is entered
+                if self._all_ranks(capi.comm_available()):
+                    transport = "rccl"
+                else:
+                    self.transport_note = "librccl could not be loaded on every rank: exchange through torch.distributed hooks"
         self.transport = transport
         self.buffers = {}
         self._views = {}
@@ -44,8 +52,18 @@ class DistributedContext:
             # created (collectively) on this rank's current device
             ids = [capi.comm_unique_id() if self.rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
-            storage.use_rccl(ids[0])
-            return
+            err = None
+            try:
+                storage.use_rccl(ids[0])
+            except Exception as e:  # noqa: BLE001 -- reported below, on every rank
+                err = e
+            if self._all_ranks(err is None):
+                return
+            if not auto:
+                raise RuntimeError(f"RCCL transport could not be set up on every rank (this rank: {err!r})")
+            # "auto": all ranks switch together (set_hooks below replaces the transport of the ranks that did succeed)
+            self.transport = transport = "hooks"
+            self.transport_note = f"RCCL communicator set-up failed on some rank (this rank: {err!r}): exchange through torch.distributed hooks"
         if transport != "hooks":
             raise ValueError(f"unknown transport {transport!r}")
         # the hooks run on the stream the host layer launches its pack / reduce kernels on
@@ -81,6 +99,12 @@ class DistributedContext:
         self._stage = dist.get_backend() == "gloo" and self.device.type == "cuda"
         self._scalar = torch.zeros(8, dtype=torch.float64, device="cpu" if self._stage else self.device)
         storage.set_hooks(self.exchange_begin, self.exchange_end, self.allreduce_sum)
+
+    def _all_ranks(self, ok: bool) -> bool:
+        """logical AND over the ranks of a per-rank success flag"""
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag.item()))
 
     def send_tensor(self, level, key):
         return self.buffers[(level, key)][0]
