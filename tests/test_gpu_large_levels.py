@@ -286,3 +286,47 @@ def test_gauss_seidel_level_11_leaves_a_linear_function_alone(env):
     capi.p1_sor_cell(u.data_ptr(), rhs.data_ptr(), level, w, 1.0, True)
     torch.cuda.synchronize()
     assert float((u - u0).abs().max()) < 1e-8  # values up to 1e4, 2 x 15-term sums per point
+
+
+def test_grid_transfer_level_9_to_10_on_constants_and_a_linear(env):
+    """fine level 10 (1.44 GB per array) is the largest level of the brick prolongation and of 32-bit buffer offsets: prolongation
+    of 1 is 1 everywhere; prolongation of a linear function in the index coordinates reproduces it (P1 interpolation is exact
+    for linears: VertexDoFLinearProlongation3DTest.cpp:107-137), checked at every fine point on the device; restriction of 1
+    with all neighbour counts 1 gives 8 at inner coarse points."""
+    torch, capi, po = env
+    lc, lf = 9, 10
+    nc, nf = capi.cell_size(lc), capi.cell_size(lf)
+    free, _ = torch.cuda.mem_get_info()
+    if free < 4.5 * nf * 8:
+        pytest.skip(f"needs {4.5 * nf * 8 / 2**30:.0f} GiB of device memory")
+
+    def linear(level):
+        # value 3x - 2y + 5z + 1 in units of the level's mesh width: built slice by slice, row by row on the device
+        N = (1 << level) + 1
+        h = 1.0 / (N - 1)
+        parts = []
+        for z in range(N):
+            W = N - z
+            ys = torch.repeat_interleave(torch.arange(W, device="cuda"), torch.arange(W, 0, -1, device="cuda"))
+            starts = torch.cumsum(torch.arange(W, 0, -1, device="cuda"), 0) - torch.arange(W, 0, -1, device="cuda")
+            xs = torch.arange(ys.numel(), device="cuda") - starts[ys]
+            parts.append((3.0 * xs - 2.0 * ys + 5.0 * z).to(torch.float64) * h + 1.0)
+        return torch.cat(parts)
+
+    ones = [1.0] * 14
+    coarse = torch.ones(nc, dtype=torch.float64, device="cuda")
+    fine = torch.full((nf,), -1.0, dtype=torch.float64, device="cuda")
+    capi.p1_prolongate_cell(coarse.data_ptr(), fine.data_ptr(), lc, ones, capi.REPLACE)
+    torch.cuda.synchronize()
+    assert float(fine.min()) == 1.0 and float(fine.max()) == 1.0
+    coarse = linear(lc)
+    assert coarse.numel() == nc
+    capi.p1_prolongate_cell(coarse.data_ptr(), fine.data_ptr(), lc, ones, capi.REPLACE)
+    torch.cuda.synchronize()
+    want = linear(lf)
+    assert float((fine - want).abs().max()) <= 1e-13 * float(want.abs().max())
+    del want
+    fine.fill_(1.0)
+    capi.p1_restrict_cell(coarse.data_ptr(), fine.data_ptr(), lc, ones)
+    torch.cuda.synchronize()
+    assert float(coarse[capi.cell_index(lc, 3, 4, 5)]) == 8.0 and float(coarse.max()) == 8.0
