@@ -279,30 +279,52 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_k
    const T invc  = (T) ( 1.0 / A.st.w[7] );
    const T relax = (T) A.relax;
 
-   auto step = [&]( auto sc ) {
-      constexpr int s = decltype( sc )::value; // output slice z0 + s, centre q = s+1
+   // ADD / JACOBI read a second (and third) array at the output points.  Those loads run PFD slices ahead of their use as
+   // well, like the source slices (round 1 issued them at the top of the step that consumes them: the wave then waited a
+   // whole memory round trip at its first store of every slice -- 16.9 us for the fused Jacobi against 9.7 us for the apply,
+   // i.e. 7 us for 23 MB more).
+   T          EX0[LZ][NY], EX1[LZ][NY];
+   const bool hasInv = MODE == APPLY_JACOBI && A.invdiag != nullptr;
+   auto       load_extra = [&]( auto sc ) {
+      constexpr int s = decltype( sc )::value;
       constexpr int q = s + 1;
-      if constexpr ( q + 1 + PFD <= LZ + 1 )
-         load_slice( std::integral_constant< int, q + 1 + PFD >{}, baseq[q + 1 + PFD], Wqs[q + 1 + PFD] );
-
-      const int W  = Wqs[q];
-      int       io = baseq[q] + ( W - ym ); // (xb, y0, z)
-      // ADD / JACOBI read a second (and third) array at the output points: issue those loads now, ahead of the
-      // slice's arithmetic, instead of one dependent round trip per row right before the store
-      T ex0[NY], ex1[NY];
       if constexpr ( MODE != APPLY_REPLACE )
       {
-         int ie = io;
+         const int W  = Wqs[q];
+         int       ie = baseq[q] + ( W - ym ); // (xb, y0, z)
 #pragma unroll
          for ( int j = 0; j < NY; ++j )
          {
             const int last8 = ( W - ( t.y0 + j ) - 1 - t.xb ) * SZ;
             const int vo    = min( lane_off, last8 );
-            ex0[j]          = MODE == APPLY_ADD ? zm_load2< T, EX_AUX >( rd, vo, ie * SZ ) : zm_load2< T, EX_AUX >( rr, vo, ie * SZ );
-            ex1[j]          = ( MODE == APPLY_JACOBI && A.invdiag ) ? zm_load2< T >( ri, vo, ie * SZ ) : invc;
+            EX0[s][j]       = MODE == APPLY_ADD ? zm_load2< T, EX_AUX >( rd, vo, ie * SZ ) : zm_load2< T, EX_AUX >( rr, vo, ie * SZ );
+            if constexpr ( MODE == APPLY_JACOBI )
+            {
+               T v = invc; // scalar inverse diagonal unless a function was given (wave-uniform branch)
+               if ( hasInv )
+                  v = zm_load2< T >( ri, vo, ie * SZ );
+               EX1[s][j] = v;
+            }
             ie += W - ( t.y0 + j );
          }
       }
+   };
+   if constexpr ( MODE != APPLY_REPLACE )
+   {
+      [&]< int... Is >( std::integer_sequence< int, Is... > ) { ( load_extra( std::integral_constant< int, Is >{} ), ... ); }
+      ( std::make_integer_sequence < int, ( PFD < LZ ? PFD : LZ ) > {} );
+   }
+
+   auto step = [&]( auto sc ) {
+      constexpr int s = decltype( sc )::value; // output slice z0 + s, centre q = s+1
+      constexpr int q = s + 1;
+      if constexpr ( q + 1 + PFD <= LZ + 1 )
+         load_slice( std::integral_constant< int, q + 1 + PFD >{}, baseq[q + 1 + PFD], Wqs[q + 1 + PFD] );
+      if constexpr ( s + PFD < LZ )
+         load_extra( std::integral_constant< int, s + PFD >{} );
+
+      const int W  = Wqs[q];
+      int       io = baseq[q] + ( W - ym ); // (xb, y0, z)
       if constexpr ( s == 0 )
          ZM_TRACE( 3 );
 #pragma unroll
@@ -335,9 +357,9 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_k
          if ( MODE == APPLY_REPLACE )
             out = acc;
          else if ( MODE == APPLY_ADD )
-            out = acc + ex0[j];
+            out = acc + EX0[s][j];
          else
-            out = a0 + relax * ( ex1[j] * ( ex0[j] - acc ) );
+            out = a0 + relax * ( EX1[s][j] * ( EX0[s][j] - acc ) );
          // outputs are lanes 1 .. min( 62, R - 2 - xb ) of slices that exist: one unsigned compare of (lane - 1)
          const int      cnt = s < t.nz ? min( 62, R - 2 - t.xb ) : 0; // wave-uniform
          const unsigned lm1 = (unsigned) ( lane - 1 );
