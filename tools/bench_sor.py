@@ -23,7 +23,8 @@ def main():
     sh = stream.cuda_stream
     st = host.Storage.from_gmsh(ROOT / "hyteg_amd/data/meshes/tet_1el.msh")
     st.set_stream(sh)
-    algs = [("blocks", capi.SOR_BLOCKS)] + ([("dataflow", capi.SOR_DATAFLOW)] if args.all else [])
+    # "default": what the entry point picks by level (one-workgroup LDS kernel up to level 4, blocks above)
+    algs = [("default", capi.SOR_AUTO)] + ([("blocks", capi.SOR_BLOCKS), ("dataflow", capi.SOR_DATAFLOW)] if args.all else [])
     for L in args.levels:
         n = capi.cell_size(L)
         op = host.P1ConstantOperator(st, 2, L)
