@@ -253,6 +253,108 @@ class P1ConstantOperator
          sweepShell( 0xFu << 10 ); // macro-vertices
       }
    }
+   // Several functions swept by the SAME launches (no counterpart in the reference, which sweeps one function at a time): the
+   // Gauss-Seidel phases are chains of small dependent kernels whose duration does not depend on how many cells a launch
+   // covers, and the batched kernels take any list of cell arrays -- so the three velocity components of the Stokes smoother
+   // (StokesVelocityBlockBlockDiagonalPreconditioner) share one chain instead of running three.  The batch is ordered
+   // [function][cell]; every function sees exactly the kernels, tables and order of smooth_sor: results are bit-identical.
+   // Falls back to one smooth_sor per function where the batched path does not apply (large levels, different boundary
+   // conditions).
+   void smooth_sor_many( const std::vector< std::reference_wrapper< const P1Function< double > > >& dsts,
+                         const std::vector< std::reference_wrapper< const P1Function< double > > >& rhss, double relax, uint_t level,
+                         DoFType flagIn, bool backwards = false ) const
+   {
+      const uint_t nf = dsts.size();
+      if ( nf == 0 || rhss.size() != nf )
+         throw std::runtime_error( "smooth_sor_many: need as many right-hand sides as functions" );
+      const DoFType flag = dsts[0].get().effectiveFlag( flagIn );
+      bool          together = nf > 1 && storage_->useBatch( level ) && storage_->useBatchSor( level );
+      for ( uint_t k = 0; k < nf; ++k )
+         together = together && dsts[k].get().effectiveFlag( flagIn ) == flag && &dsts[k].get() != &rhss[k].get();
+      if ( !together )
+      {
+         for ( uint_t k = 0; k < nf; ++k )
+            smooth_sor( dsts[k].get(), rhss[k].get(), relax, level, flagIn, backwards );
+         return;
+      }
+      ScopedTimer timerOp( storage_->getTimingTree(), "Operator P1Function to P1Function" ), timerSor( storage_->getTimingTree(), backwards ? "SOR backwards" : "SOR" );
+      const int nc    = (int) storage_->getNumberOfLocalCells();
+      const int total = nc * (int) nf;
+      // chunks of the concatenated [function][cell] list
+      auto forChunks = [&]( auto&& fn ) {
+         for ( int first = 0; first < total; first += HYTEG_HIP_MAX_BATCH )
+            fn( first, std::min( HYTEG_HIP_MAX_BATCH, total - first ) );
+      };
+      auto pointers = [&]( const std::vector< std::reference_wrapper< const P1Function< double > > >& fs, int first, int count ) {
+         std::vector< double* > p;
+         for ( int e = first; e < first + count; ++e )
+            p.push_back( fs[(uint_t) ( e / nc )].get().getCellPointer( (uint_t) ( e % nc ), level ) );
+         return p;
+      };
+      auto repeatMasks = [&]( const std::vector< unsigned >& once ) {
+         std::vector< unsigned > m;
+         for ( uint_t k = 0; k < nf; ++k )
+            m.insert( m.end(), once.begin(), once.end() );
+         return m;
+      };
+      bool anyShell = false;
+      forCells( [&]( uint_t, const MacroCell& cell ) { anyShell = anyShell || ( storage_->maskFor( cell, flag ) & HYTEG_HIP_MASK_SHELL ); } );
+      auto sweepCells = [&]() {
+         const auto    masks = repeatMasks( storage_->masksFor( flag ) );
+         const double* table = repeatedTable( stencilTablesRep_, stencilTableHost( level ), level, nf );
+         forChunks( [&]( int first, int count ) {
+            const auto u = pointers( dsts, first, count ), r = pointers( rhss, first, count );
+            hipCheck( hyteg_hip_p1_sor_cells( count, u.data(), r.data(), (int) level, table + (size_t) first * 225, relax, backwards ? 1 : 0,
+                                              masks.data() + first, storage_->stream() ),
+                      "smooth_sor_many: cells" );
+         } );
+      };
+      if ( !anyShell && storage_->numRanks() == 1 )
+      {
+         sweepCells();
+         return;
+      }
+      std::vector< std::reference_wrapper< const P1Function< double > > > rests;
+      for ( uint_t k = 0; k < nf; ++k )
+      {
+         auto& slot = sorRestMany_[std::make_pair( level, k )];
+         if ( !slot )
+            slot.reset( new P1Function< double >( "sor_rest_many", storage_, level, level ) );
+         rests.push_back( std::cref( *slot ) );
+      }
+      auto sweepShell = [&]( unsigned bits ) {
+         const auto    masks = repeatMasks( storage_->masksFor( flag, false, bits & HYTEG_HIP_MASK_SHELL ) );
+         const double* rt    = repeatedTable( restTablesRep_, restTableHost( level ), level, nf );
+         forChunks( [&]( int first, int count ) {
+            const auto r = pointers( rests, first, count ), u = pointers( dsts, first, count );
+            hipCheck( hyteg_hip_p1_apply_cells( count, r.data(), u.data(), (int) level, rt + (size_t) first * 225, masks.data() + first,
+                                                HYTEG_HIP_REPLACE, storage_->stream() ),
+                      "smooth_sor_many: rest" );
+         } );
+         for ( uint_t k = 0; k < nf; ++k )
+            rests[k].get().sumSharedCopies( level, flag );
+         const hyteg_hip_sor_shell_tables* st = repeatedShellTable( level, nf );
+         forChunks( [&]( int first, int count ) {
+            const auto u = pointers( dsts, first, count ), r = pointers( rhss, first, count ), q = pointers( rests, first, count );
+            hipCheck( hyteg_hip_p1_sor_shell_cells( count, u.data(), r.data(), q.data(), (int) level, st + first, relax, masks.data() + first,
+                                                    backwards ? 1 : 0, storage_->stream() ),
+                      "smooth_sor_many: shell" );
+         } );
+      };
+      if ( !backwards )
+      {
+         sweepShell( HYTEG_HIP_MASK_SHELL );
+         sweepCells();
+      }
+      else
+      {
+         sweepCells();
+         sweepShell( 0xFu << 6 );  // macro-faces
+         sweepShell( 0x3Fu );      // macro-edges
+         sweepShell( 0xFu << 10 ); // macro-vertices
+      }
+   }
+
    void smooth_gs( const P1Function< double >& dst, const P1Function< double >& rhs, uint_t level, DoFType flag ) const
    {
       smooth_sor( dst, rhs, 1.0, level, flag, false );
@@ -395,6 +497,70 @@ class P1ConstantOperator
    }
 
  private:
+   // the per-cell tables of the batched kernels repeated nf times (smooth_sor_many: the batch is [function][cell])
+   const double* repeatedTable( std::map< std::pair< uint_t, uint_t >, const double* >& cache, const std::vector< double >& once, uint_t level,
+                                uint_t nf ) const
+   {
+      auto key = std::make_pair( level, nf );
+      auto it  = cache.find( key );
+      if ( it != cache.end() )
+         return it->second;
+      std::vector< double > h;
+      for ( uint_t k = 0; k < nf; ++k )
+         h.insert( h.end(), once.begin(), once.end() );
+      return cache[key] = storage_->uploadTable( h );
+   }
+   std::vector< double > stencilTableHost( uint_t level ) const
+   {
+      std::vector< double > h;
+      for ( int id : storage_->getLocalCellIDs() )
+      {
+         const auto& S = getCellStencils( id, level );
+         h.insert( h.end(), &S.slots[0][0], &S.slots[0][0] + 14 * 15 );
+         h.insert( h.end(), S.inner, S.inner + 15 );
+      }
+      return h;
+   }
+   std::vector< double > restTableHost( uint_t level ) const
+   {
+      std::vector< double > h;
+      for ( int id : storage_->getLocalCellIDs() )
+      {
+         const auto& T = sorTables_.at( level ).at( id );
+         h.insert( h.end(), &T.rest[0][0], &T.rest[0][0] + 14 * 15 );
+         h.insert( h.end(), 15, 0.0 );
+      }
+      return h;
+   }
+   std::vector< hyteg_hip_sor_shell_tables > shellTableHost( uint_t level ) const
+   {
+      std::vector< hyteg_hip_sor_shell_tables > h;
+      for ( int id : storage_->getLocalCellIDs() )
+      {
+         const auto&                T = sorTables_.at( level ).at( id );
+         hyteg_hip_sor_shell_tables r{};
+         std::memcpy( r.edge_verts, T.edgeVerts, sizeof( r.edge_verts ) );
+         std::memcpy( r.face_verts, T.faceVerts, sizeof( r.face_verts ) );
+         std::memcpy( r.edge_w, T.edgeW, sizeof( r.edge_w ) );
+         std::memcpy( r.face_w, T.faceW, sizeof( r.face_w ) );
+         std::memcpy( r.vertex_w, T.vertexW, sizeof( r.vertex_w ) );
+         h.push_back( r );
+      }
+      return h;
+   }
+   const hyteg_hip_sor_shell_tables* repeatedShellTable( uint_t level, uint_t nf ) const
+   {
+      auto key = std::make_pair( level, nf );
+      auto it  = shellTablesRep_.find( key );
+      if ( it != shellTablesRep_.end() )
+         return it->second;
+      const auto                                once = shellTableHost( level );
+      std::vector< hyteg_hip_sor_shell_tables > h;
+      for ( uint_t k = 0; k < nf; ++k )
+         h.insert( h.end(), once.begin(), once.end() );
+      return shellTablesRep_[key] =
+                 static_cast< const hyteg_hip_sor_shell_tables* >( storage_->uploadBytes( h.data(), h.size() * sizeof( h[0] ) ) );
+   }
    // device tables [local cell][15 point classes][15 weights] for the batched kernels: classes 0..13 the cell's shares, 14 inner
    const double* stencilTable( uint_t level ) const
    {
@@ -520,6 +686,9 @@ class P1ConstantOperator
    std::map< uint_t, std::vector< stencil::CellStencils > >   stencils_;
    std::map< uint_t, std::vector< stencil::CellSorTables > >  sorTables_;
    mutable std::map< uint_t, std::unique_ptr< P1Function< double > > > sorRest_;
+   mutable std::map< std::pair< uint_t, uint_t >, std::unique_ptr< P1Function< double > > > sorRestMany_; // (level, k)
+   mutable std::map< std::pair< uint_t, uint_t >, const double* >                         stencilTablesRep_, restTablesRep_;
+   mutable std::map< std::pair< uint_t, uint_t >, const hyteg_hip_sor_shell_tables* >     shellTablesRep_;
    mutable std::map< uint_t, const double* >                  stencilTables_, restTables_;
    mutable std::map< uint_t, const hyteg_hip_sor_shell_tables* > shellTables_;
    std::shared_ptr< P1Function< double > >                    inverseDiagonalValues_;

@@ -26,6 +26,14 @@ class Solver
       for ( uint_t i = 0; i < steps; ++i )
          solve( A, x, b, level );
    }
+   // one solve() for each of several independent (x, b) pairs of the same operator (the velocity components of a block-diagonal
+   // preconditioner); a solver may override it with something equivalent that shares launches between the pairs
+   virtual void solveMany( const OperatorType& A, const std::vector< std::reference_wrapper< const FunctionType > >& xs,
+                           const std::vector< std::reference_wrapper< const FunctionType > >& bs, uint_t level )
+   {
+      for ( size_t k = 0; k < xs.size(); ++k )
+         solve( A, xs[k].get(), bs[k].get(), level );
+   }
 };
 
 // WeightedJacobiSmoother.hpp:46-62
@@ -164,6 +172,11 @@ class SORSmoother : public Solver< OperatorType >
    void solve( const OperatorType& A, const P1Function< double >& x, const P1Function< double >& b, uint_t level ) override
    {
       A.smooth_sor( x, b, relax_, level, flag_ );
+   }
+   void solveMany( const OperatorType& A, const std::vector< std::reference_wrapper< const P1Function< double > > >& xs,
+                   const std::vector< std::reference_wrapper< const P1Function< double > > >& bs, uint_t level ) override
+   {
+      A.smooth_sor_many( xs, bs, relax_, level, flag_ );
    }
 
  private:

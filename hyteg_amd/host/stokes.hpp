@@ -321,8 +321,14 @@ class StokesVelocityBlockBlockDiagonalPreconditioner : public Solver< OperatorTy
    {}
    void solve( const OperatorType& A, const FunctionType& x, const FunctionType& b, uint_t level ) override
    {
+      // the components are independent: one solveMany instead of a loop, so that a smoother can sweep them with shared launches
+      std::vector< std::reference_wrapper< const P1Function< double > > > xs, bs;
       for ( uint_t k = 0; k < x.uvw().getDimension(); ++k )
-         scalar_->solve( A.getA(), x.uvw()[k], b.uvw()[k], level );
+      {
+         xs.push_back( std::cref( x.uvw()[k] ) );
+         bs.push_back( std::cref( b.uvw()[k] ) );
+      }
+      scalar_->solveMany( A.getA(), xs, bs, level );
    }
 
  private:

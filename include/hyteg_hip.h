@@ -362,7 +362,7 @@ HYTEG_HIP_API int hyteg_hip_p1_sor_shell_cell( double*            dst,
  * where a cell is too small to fill the GPU.  `dst`, `src`, ... are HOST arrays of `ncells` device pointers, `masks` a host
  * array of `ncells` point masks (bits 0..13 macro-primitive slots, bit 14 inner points); tables ending in `_dev` are device
  * memory.  Levels 0..11. */
-#define HYTEG_HIP_MAX_BATCH 64
+#define HYTEG_HIP_MAX_BATCH 80
 /* op 0 assign, 1 add, 2 multElementwise, 3 set to scalars[0]; srcs = [nsrc][ncells] */
 HYTEG_HIP_API int hyteg_hip_p1_vector_cells( int                  op,
                                              int                  ncells,

@@ -131,7 +131,7 @@ def test_batched_calls_reject_bad_arguments(env):
     torch, capi, host, po = env
     a = _dev(torch, np.zeros(po.cell_size(2)))
     with pytest.raises(capi.HytegHipError):
-        capi.p1_vector_cells(0, [a.data_ptr()] * 65, [[a.data_ptr()] * 65], [1.0], 2, [0x7FFF] * 65)
+        capi.p1_vector_cells(0, [a.data_ptr()] * 81, [[a.data_ptr()] * 81], [1.0], 2, [0x7FFF] * 81)  # > HYTEG_HIP_MAX_BATCH
     with pytest.raises(capi.HytegHipError):
         capi.p1_apply_cells([a.data_ptr()], [a.data_ptr()], 2, a.data_ptr(), [0x7FFF])  # dst aliases src
 
