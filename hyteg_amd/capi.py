@@ -89,8 +89,10 @@ SIGNATURES = {
     "hyteg_hip_p2_prolongate_cell": (_i, [_vp, _vp, _vp, _vp, _i, _i, C.c_uint, _vp]),
     "hyteg_hip_p2_restrict_cell": (_i, [_vp, _vp, _vp, _vp, _i, _dp, C.c_uint, _vp]),
     "hyteg_hip_p2_edge_vector_cell_masked": (_i, [_i, _vp, _i, C.POINTER(_vp), _dp, _i, C.c_uint, _vp]),
+    "hyteg_hip_p2_edge_vector_cell_kinds": (_i, [_i, _vp, _i, C.POINTER(_vp), _dp, _i, C.c_uint, C.c_uint, _vp]),
     "hyteg_hip_p2_edge_dot_cell_masked": (_i, [_vp, _vp, _i, C.c_uint, _vp, _vp, _vp]),
     "hyteg_hip_p2_elementwise_apply_cell": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _d, _i, C.c_uint, _vp]),
+    "hyteg_hip_p2_elementwise_apply_cell_kinds": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _d, _i, C.c_uint, C.c_uint, _vp]),
     "hyteg_hip_p1_vector_cells_dev": (_i, [_i, _i, C.POINTER(_vp), _i, C.POINTER(_vp), C.POINTER(_vp), _i, C.POINTER(C.c_uint), _vp]),
     "hyteg_hip_cg_scalars": (_i, [_vp, _i, _d, _d, _vp]),
     "hyteg_hip_p1_cg_small_max_entries": (_i, []),
@@ -420,9 +422,10 @@ def p2_edge_dot_cell_masked(a, b, level, mask, result_dev, workspace_dev, stream
     check(lib().hyteg_hip_p2_edge_dot_cell_masked(a, b, level, mask, result_dev, workspace_dev, stream), "p2_edge_dot_cell_masked")
 
 
-def p2_elementwise_apply_cell(dst_v, dst_e, src_v, src_e, level, optable_dev, alpha=1.0, update=REPLACE, mask=0x7FFF, stream=0):
-    check(lib().hyteg_hip_p2_elementwise_apply_cell(dst_v, dst_e, src_v, src_e, level, optable_dev, float(alpha), update, mask, stream),
-          "p2_elementwise_apply_cell")
+def p2_elementwise_apply_cell(dst_v, dst_e, src_v, src_e, level, optable_dev, alpha=1.0, update=REPLACE, mask=0x7FFF, stream=0, kinds=0xFF):
+    """kinds: destination kinds to compute (bit 0 vertex DoFs, 1..7 edge DoFs X, Y, Z, XY, XZ, YZ, XYZ)"""
+    check(lib().hyteg_hip_p2_elementwise_apply_cell_kinds(dst_v, dst_e, src_v, src_e, level, optable_dev, float(alpha), update, mask, kinds,
+                                                          stream), "p2_elementwise_apply_cell")
 
 
 def p1_sor_cells(u, rhs, level, stencils_dev, relax, masks, backwards=False, stream=0):

@@ -136,6 +136,7 @@ struct P2Args
    double        alpha;
    int           N, update;
    unsigned      mask;
+   unsigned      kinds; // destination kinds to compute: bit 0 vertex DoFs, 1..7 edge DoFs X, Y, Z, XY, XZ, YZ, XYZ
    P2Tables      T;
 };
 
@@ -194,7 +195,7 @@ __global__ __launch_bounds__( kThreads ) void p2_elementwise_kernel( const P2Arg
    const int c = blockIdx.y; // destination kind
    const int N = A.N, n = N - 1;
    const int W = c == 0 ? N : ( c == 7 ? n - 1 : n );
-   if ( W <= 0 )
+   if ( W <= 0 || !( ( A.kinds >> c ) & 1u ) )
       return;
    // G lanes per DoF share its (at most 24) adjacent micro-cells, 24 / G each.  One thread per DoF walks 24 dependent memory
    // round trips: pure latency (39 us at level 5, 47 us at level 7); 32 lanes per DoF repeat the decode 32 times
@@ -344,12 +345,14 @@ struct EdgeVecArgs
    int64_t       size;
    int           N, nsrc, op; // 0 assign, 1 add, 2 mult, 3 set constant c[0]
    unsigned      mask;
+   unsigned      kinds; // bit k (1..7): edge DoFs of orientation k - 1 take part
 };
 __global__ __launch_bounds__( kThreads ) void p2_edge_vector_kernel( const EdgeVecArgs A )
 {
    const int64_t i = (int64_t) blockIdx.x * kThreads + threadIdx.x;
    int           x, y, z, o;
-   if ( i >= A.size || !edge_entry( A.N - 1, i, x, y, z, o ) || !( ( A.mask >> edge_class( A.N, x, y, z, o ) ) & 1u ) )
+   if ( i >= A.size || !edge_entry( A.N - 1, i, x, y, z, o ) || !( ( A.kinds >> ( o + 1 ) ) & 1u ) ||
+        !( ( A.mask >> edge_class( A.N, x, y, z, o ) ) & 1u ) )
       return;
    double tmp;
    if ( A.op == 3 )
@@ -543,6 +546,7 @@ struct P2FastArgs
    const double* table; // device: [600 element matrices | stencil weights of kind 0 | kind 1 | ... ]
    double        alpha;
    int           N, update;
+   unsigned      kinds; // destination kinds to compute (bit per kind), as in P2Args
 };
 
 // Row bases: every stencil entry of destination kind C reads source kind K at (x + dx, y + dy, z + dz) with compile-time
@@ -682,6 +686,8 @@ __device__ inline void p2_inner_body( const P2FastArgs& A )
 // all eight destination kinds in one launch (blockIdx.y = kind): one ramp-up instead of eight, kinds overlap
 __global__ __launch_bounds__( kThreads ) void p2_inner_kernel( const P2FastArgs A )
 {
+   if ( !( ( A.kinds >> blockIdx.y ) & 1u ) )
+      return;
    switch ( blockIdx.y )
    {
    case 0:
@@ -853,7 +859,9 @@ __device__ inline void p2_rows_body( const P2RowsArgs& A, int block )
    }
    ( std::make_integer_sequence< int, kSrc.n >{} );
 
-   [&]< int... C >( std::integer_sequence< int, C... > ) { ( p2_rows_kind< C, UPDATE >( A, U, i0, lane, x, y, z, tl.cnt, rdV, rdE ), ... ); }
+   [&]< int... C >( std::integer_sequence< int, C... > ) {
+      ( ( ( A.F.kinds >> C ) & 1u ? p2_rows_kind< C, UPDATE >( A, U, i0, lane, x, y, z, tl.cnt, rdV, rdE ) : (void) 0 ), ... );
+   }
    ( std::make_integer_sequence< int, 8 >{} );
 }
 template < int UPDATE >
@@ -940,6 +948,8 @@ __device__ inline void p2_boundary_body( const P2ClassArgs& B, int bx )
 }
 __device__ inline void p2_boundary_dispatch( const P2ClassArgs& B, int kind, int bx )
 {
+   if ( !( ( B.F.kinds >> kind ) & 1u ) )
+      return;
    switch ( kind )
    {
    case 0: p2_boundary_body< 0 >( B, bx ); break;
@@ -1094,14 +1104,27 @@ HYTEG_HIP_API int hyteg_hip_p2_edge_vector_cell_masked( int                  op,
                                                         unsigned             mask,
                                                         hyteg_hip_stream_t   stream )
 {
+   return hyteg_hip_p2_edge_vector_cell_kinds( op, dst, nsrc, srcs, scalars, level, mask, 0xFEu, stream );
+}
+
+HYTEG_HIP_API int hyteg_hip_p2_edge_vector_cell_kinds( int                  op,
+                                                       double*              dst,
+                                                       int                  nsrc,
+                                                       const double* const* srcs,
+                                                       const double*        scalars,
+                                                       int                  level,
+                                                       unsigned             mask,
+                                                       unsigned             kind_mask,
+                                                       hyteg_hip_stream_t   stream )
+{
    HH_REQUIRE( dst && op >= 0 && op <= 3, "p2_edge_vector_cell_masked: null dst or bad op" );
    HH_REQUIRE( level >= 0 && level <= HYTEG_HIP_P2_MAX_LEVEL, "p2_edge_vector_cell_masked: level out of range [0,9]" );
    HH_REQUIRE( op == 3 ? scalars != nullptr : ( nsrc >= 1 && nsrc <= HYTEG_HIP_MAX_SRCS && srcs ), "p2_edge_vector_cell_masked: bad sources" );
    HH_REQUIRE( op == 2 || scalars, "p2_edge_vector_cell_masked: null scalars" );
-   if ( ( mask & HYTEG_HIP_MASK_ALL ) == 0 )
+   if ( ( mask & HYTEG_HIP_MASK_ALL ) == 0 || ( kind_mask & 0xFEu ) == 0 )
       return HYTEG_HIP_OK;
    EdgeVecArgs A{};
-   A.dst = dst, A.N = ( 1 << level ) + 1, A.nsrc = nsrc, A.op = op, A.mask = mask & HYTEG_HIP_MASK_ALL;
+   A.dst = dst, A.N = ( 1 << level ) + 1, A.nsrc = nsrc, A.op = op, A.mask = mask & HYTEG_HIP_MASK_ALL, A.kinds = kind_mask & 0xFEu;
    A.size = (int64_t) hyteg_hip_p2_edge_array_size( level );
    if ( op == 3 )
       A.c[0] = scalars[0];
@@ -1160,12 +1183,29 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell( double*            dst_ve
                                                        unsigned           mask,
                                                        hyteg_hip_stream_t stream )
 {
+   return hyteg_hip_p2_elementwise_apply_cell_kinds( dst_vertex, dst_edge, src_vertex, src_edge, level, optable_dev, alpha, update, mask, 0xFFu,
+                                                     stream );
+}
+
+HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell_kinds( double*            dst_vertex,
+                                                             double*            dst_edge,
+                                                             const double*      src_vertex,
+                                                             const double*      src_edge,
+                                                             int                level,
+                                                             const double*      optable_dev,
+                                                             double             alpha,
+                                                             int                update,
+                                                             unsigned           mask,
+                                                             unsigned           kind_mask,
+                                                             hyteg_hip_stream_t stream )
+{
    HH_REQUIRE( dst_vertex && dst_edge && src_vertex && src_edge && optable_dev, "p2_elementwise_apply_cell: null pointer" );
    HH_REQUIRE( level >= 0 && level <= HYTEG_HIP_P2_MAX_LEVEL, "p2_elementwise_apply_cell: level out of range [0,9]" );
    HH_REQUIRE( dst_vertex != src_vertex && dst_edge != src_edge, "p2_elementwise_apply_cell: src and dst must not alias" );
    HH_REQUIRE( update == HYTEG_HIP_REPLACE || update == HYTEG_HIP_ADD, "p2_elementwise_apply_cell: bad update type" );
    mask &= HYTEG_HIP_MASK_ALL;
-   if ( mask == 0 )
+   kind_mask &= 0xFFu;
+   if ( mask == 0 || kind_mask == 0 )
       return HYTEG_HIP_OK;
    hipStream_t       s = as_stream( stream );
    static const bool perThread = [] {
@@ -1174,7 +1214,7 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell( double*            dst_ve
    }();
    P2FastArgs F;
    F.dstV = dst_vertex, F.dstE = dst_edge, F.srcV = src_vertex, F.srcE = src_edge, F.table = optable_dev, F.alpha = alpha;
-   F.N = ( 1 << level ) + 1, F.update = update;
+   F.N = ( 1 << level ) + 1, F.update = update, F.kinds = kind_mask;
    const int  faces = 4 * tri( F.N );
    const int  nbx   = ( faces + kThreads - 1 ) / kThreads;
    const bool rows  = ( mask & HYTEG_HIP_MASK_INNER ) && level >= 3 && !perThread;
@@ -1225,7 +1265,7 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell( double*            dst_ve
       // levels 0 and 1: a DoF can be next to several macro-faces at once; micro-cell by micro-cell gather in the reference's order
       P2Args A;
       A.dstV = dst_vertex, A.dstE = dst_edge, A.srcV = src_vertex, A.srcE = src_edge, A.elmat = optable_dev, A.alpha = alpha;
-      A.N = ( 1 << level ) + 1, A.update = update, A.mask = mask & HYTEG_HIP_MASK_SHELL, A.T = tables();
+      A.N = ( 1 << level ) + 1, A.update = update, A.mask = mask & HYTEG_HIP_MASK_SHELL, A.kinds = kind_mask, A.T = tables();
       const int     faces = 4 * tri( A.N ); // candidates of the widest kind
       constexpr int G     = 8;
       hipLaunchKernelGGL( p2_elementwise_kernel< G >, dim3( (unsigned) ( ( faces + kThreads / G - 1 ) / ( kThreads / G ) ), 8 ), dim3( kThreads ), 0,

@@ -107,7 +107,8 @@ SIGNATURES = {
     "hyteg_host_p2operator_compute_inverse_diagonal": (_i, [_vp]),
     "hyteg_host_p2operator_inverse_diagonal_copy": (_i, [_vp, _vp, _i]),
     "hyteg_host_p2operator_smooth_jac": (_i, [_vp, _vp, _vp, _vp, _d, _i, _i]),
-    "hyteg_host_p2_gmg_create": (_i, [_vp, _i, _i, _d, _i, _i, _i, _i, _d, C.POINTER(_vp)]),
+    "hyteg_host_p2operator_smooth_sor": (_i, [_vp, _vp, _vp, _d, _i, _i, _i]),
+    "hyteg_host_p2_gmg_create": (_i, [_vp, _i, _i, _i, _d, _i, _i, _i, _i, _d, C.POINTER(_vp)]),
     "hyteg_host_p2_solver_solve": (_i, [_vp, _vp, _vp, _vp, _i]),
     "hyteg_host_p2_solver_destroy": (_i, [_vp]),
 }
@@ -642,6 +643,9 @@ class P2ElementwiseLaplaceOperator:
     def smooth_jac(self, dst: "P2Function", rhs: "P2Function", src: "P2Function", relax, level, flag=Inner | NeumannBoundary):
         _ck(lib().hyteg_host_p2operator_smooth_jac(self.h, dst.h, rhs.h, src.h, float(relax), level, flag), "P2 smooth_jac")
 
+    def smooth_sor(self, dst: "P2Function", rhs: "P2Function", relax, level, flag=Inner | NeumannBoundary, backwards=False):
+        _ck(lib().hyteg_host_p2operator_smooth_sor(self.h, dst.h, rhs.h, float(relax), level, flag, int(bool(backwards))), "P2 smooth_sor")
+
     def cg_solve(self, x: P2Function, b: P2Function, level, max_iter=1000, tol=1e-14):
         it = _i()
         _ck(lib().hyteg_host_p2_cg_solve(self.storage.h, self.h, x.h, b.h, level, max_iter, float(tol), C.byref(it)), "P2 CG")
@@ -657,11 +661,13 @@ class P2Solver:
     """GeometricMultigridSolver< P2ElementwiseLaplaceOperator, P2toP2QuadraticRestriction, P2toP2QuadraticProlongation > with a
     weighted-Jacobi smoother and CG on the coarsest level"""
 
-    def __init__(self, storage: Storage, min_level, max_level, relax=2.0 / 3.0, pre=3, post=3, wcycle=False, cg_max_iter=1000, cg_tol=1e-14):
+    def __init__(self, storage: Storage, min_level, max_level, relax=2.0 / 3.0, pre=3, post=3, wcycle=False, cg_max_iter=1000, cg_tol=1e-14,
+                 smoother=JACOBI):
         self.storage = storage
         h = _vp()
-        _ck(lib().hyteg_host_p2_gmg_create(storage.h, min_level, max_level, float(relax), pre, post, int(bool(wcycle)), cg_max_iter, float(cg_tol),
-                                           C.byref(h)), "P2 gmg")
+        kind = {JACOBI: 0, GAUSS_SEIDEL: 1, SOR: 2}[smoother]
+        _ck(lib().hyteg_host_p2_gmg_create(storage.h, min_level, max_level, kind, float(relax), pre, post, int(bool(wcycle)), cg_max_iter,
+                                           float(cg_tol), C.byref(h)), "P2 gmg")
         self.h = h
 
     def solve(self, op, x: "P2Function", b: "P2Function", level):

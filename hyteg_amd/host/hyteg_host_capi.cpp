@@ -709,17 +709,30 @@ HYTEG_HOST_API int hyteg_host_p2operator_smooth_jac( hh_p2operator_t op, hh_p2fu
 {
    return guarded( [&] { static_cast< P2OperatorH* >( op )->p->smooth_jac( F2( dst ), F2( rhs ), F2( src ), relax, (uint_t) level, DoFType( flag ) ); } );
 }
+HYTEG_HOST_API int hyteg_host_p2operator_smooth_sor( hh_p2operator_t op, hh_p2function_t dst, hh_p2function_t rhs, double relax, int level, int flag,
+                                                     int backwards )
+{
+   return guarded( [&] {
+      static_cast< P2OperatorH* >( op )->p->smooth_sor( F2( dst ), F2( rhs ), relax, (uint_t) level, DoFType( flag ), backwards != 0 );
+   } );
+}
 struct P2SolverH
 {
    std::shared_ptr< Solver< P2ElementwiseLaplaceOperator > > p;
 };
-HYTEG_HOST_API int hyteg_host_p2_gmg_create( hh_storage_t s, int minL, int maxL, double relax, int pre, int post, int wcycle, int cgMaxIter, double cgTol,
-                                             hh_p2solver_t* out )
+HYTEG_HOST_API int hyteg_host_p2_gmg_create( hh_storage_t s, int minL, int maxL, int smootherKind, double relax, int pre, int post, int wcycle,
+                                             int cgMaxIter, double cgTol, hh_p2solver_t* out )
 {
    return guarded( [&] {
       using Op     = P2ElementwiseLaplaceOperator;
       auto storage = static_cast< StorageH* >( s )->p;
-      auto smoother = std::make_shared< WeightedJacobiSmoother< Op > >( storage, (uint_t) minL, (uint_t) maxL, relax );
+      std::shared_ptr< Solver< Op > > smoother;
+      if ( smootherKind == 0 )
+         smoother = std::make_shared< WeightedJacobiSmoother< Op > >( storage, (uint_t) minL, (uint_t) maxL, relax );
+      else if ( smootherKind == 1 )
+         smoother = std::make_shared< GaussSeidelSmoother< Op > >();
+      else
+         smoother = std::make_shared< SORSmoother< Op > >( relax );
       auto coarse   = std::make_shared< CGSolver< Op > >( storage, (uint_t) minL, (uint_t) minL, (uint_t) cgMaxIter, cgTol, cgTol );
       *out          = new P2SolverH{ std::make_shared< GeometricMultigridSolver< Op, P2toP2QuadraticRestriction, P2toP2QuadraticProlongation > >(
           storage, smoother, coarse, std::make_shared< P2toP2QuadraticRestriction >(), std::make_shared< P2toP2QuadraticProlongation >(),

@@ -137,6 +137,24 @@ class P2Function
       vectorOp( 2, std::vector< ValueType >( functions.size(), ValueType( 1 ) ), functions, level, flag );
    }
    uint64_t uid() const { return uid_; }
+   // assign / add / multElementwise restricted to DoF kinds (bit 0: vertex DoFs, 1..7: edge DoFs X, Y, Z, XY, XZ, YZ, XYZ): the
+   // per-type sweeps of the P2 Gauss-Seidel smoother
+   // `keep`: further restriction to point classes (HYTEG_HIP_MASK_INNER: inside the macro-cells, HYTEG_HIP_MASK_SHELL: on shared primitives)
+   void assignKinds( const std::vector< ValueType >& scalars, const std::vector< std::reference_wrapper< const P2Function< ValueType > > >& functions,
+                     uint_t level, DoFType flag, unsigned kinds, unsigned keep = HYTEG_HIP_MASK_ALL ) const
+   {
+      vectorOp( 0, scalars, functions, level, flag, kinds, keep );
+   }
+   void addKinds( const std::vector< ValueType >& scalars, const std::vector< std::reference_wrapper< const P2Function< ValueType > > >& functions,
+                  uint_t level, DoFType flag, unsigned kinds, unsigned keep = HYTEG_HIP_MASK_ALL ) const
+   {
+      vectorOp( 1, scalars, functions, level, flag, kinds, keep );
+   }
+   void multElementwiseKinds( const std::vector< std::reference_wrapper< const P2Function< ValueType > > >& functions, uint_t level, DoFType flag,
+                              unsigned kinds, unsigned keep = HYTEG_HIP_MASK_ALL ) const
+   {
+      vectorOp( 2, std::vector< ValueType >( functions.size(), ValueType( 1 ) ), functions, level, flag, kinds, keep );
+   }
    // a shared DoF is counted by its lowest-numbered neighbour cell only
    ValueType dotLocal( const P2Function< ValueType >& rhs, uint_t level, DoFType flag = All ) const
    {
@@ -205,25 +223,32 @@ class P2Function
                   const std::vector< ValueType >&                                           scalars,
                   const std::vector< std::reference_wrapper< const P2Function< ValueType > > >& functions,
                   uint_t                                                                    level,
-                  DoFType                                                                   flag ) const
+                  DoFType                                                                   flag,
+                  unsigned                                                                  kinds = 0xFFu,
+                  unsigned                                                                  keep  = HYTEG_HIP_MASK_ALL ) const
    {
       if ( functions.empty() || functions.size() > HYTEG_HIP_MAX_SRCS || scalars.size() != functions.size() )
          throw std::runtime_error( "P2Function::assign/add/multElementwise: bad number of functions or scalars" );
       std::vector< std::reference_wrapper< const P1Function< ValueType > > > vs;
       for ( uint_t k = 0; k < functions.size(); ++k )
          vs.push_back( functions[k].get().vertexDoFFunction_ );
-      if ( op == 0 )
-         vertexDoFFunction_.assign( scalars, vs, level, flag );
-      else if ( op == 1 )
-         vertexDoFFunction_.add( scalars, vs, level, flag );
-      else
-         vertexDoFFunction_.multElementwise( vs, level, flag );
+      if ( kinds & 1u )
+      {
+         if ( op == 0 )
+            vertexDoFFunction_.assign( scalars, vs, level, flag );
+         else if ( op == 1 )
+            vertexDoFFunction_.add( scalars, vs, level, flag );
+         else
+            vertexDoFFunction_.multElementwise( vs, level, flag );
+      }
+      if ( ( kinds & 0xFEu ) == 0 )
+         return;
       forCells( [&]( uint_t c, const MacroCell& cell ) {
          const double* es[HYTEG_HIP_MAX_SRCS];
          for ( uint_t k = 0; k < functions.size(); ++k )
             es[k] = functions[k].get().getEdgeCellPointer( c, level );
-         hipCheck( hyteg_hip_p2_edge_vector_cell_masked( op, getEdgeCellPointer( c, level ), (int) functions.size(), es, scalars.data(), (int) level,
-                                                         storage_->maskFor( cell, flag ), storage_->stream() ),
+         hipCheck( hyteg_hip_p2_edge_vector_cell_kinds( op, getEdgeCellPointer( c, level ), (int) functions.size(), es, scalars.data(), (int) level,
+                                                        storage_->maskFor( cell, flag ) & keep, kinds, storage_->stream() ),
                    "P2Function vector op" );
       } );
    }

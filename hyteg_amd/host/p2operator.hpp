@@ -4,6 +4,7 @@
 
 #include "p2function.hpp"
 #include "forms.hpp"
+#include "p1operator.hpp"
 
 namespace hyteg {
 
@@ -70,6 +71,23 @@ struct P2LaplaceForm
                }
             elMat[10 * i + j] = s;
          }
+   }
+};
+} // namespace forms
+
+namespace forms {
+// the vertex-vertex block of a P2 form as a P1-style form (first row of the element matrix, vertex columns): the
+// vertex-to-vertex sub-operator of P2ConstantOperator (P2ConstantOperator.hpp: vertexToVertex), whose Gauss-Seidel sweep is the
+// P1 one
+template < class P2Form >
+struct P2VertexToVertexForm
+{
+   static void integrateRow0( const std::array< Point3D, 4 >& c, double row[4] )
+   {
+      double h[100];
+      P2Form::integrateAll( c, h );
+      for ( int j = 0; j < 4; ++j )
+         row[j] = h[j];
    }
 };
 } // namespace forms
@@ -169,6 +187,101 @@ class P2ElementwiseOperator
       return inverseDiagonalValues_;
    }
 
+   // apply restricted to destination kinds (bit 0: vertex DoFs, 1..7: edge DoFs X .. XYZ) and point classes (`keep`); the other
+   // entries of dst are not meaningful afterwards (use a temporary)
+   void applyKinds( const P2Function< double >& src, const P2Function< double >& dst, uint_t level, DoFType flag, unsigned kinds,
+                    unsigned keep = HYTEG_HIP_MASK_ALL ) const
+   {
+      if ( &src == &dst )
+         throw std::runtime_error( "P2ElementwiseOperator::applyKinds: src and dst must differ" );
+      launchWith( elementMatrices_.at( level ), 1.0, src, dst, level, flag, keep, HYTEG_HIP_REPLACE, kinds );
+      if ( storage_->getCells().size() > 1 && ( keep & HYTEG_HIP_MASK_SHELL ) )
+      {
+         if ( kinds & 1u )
+            dst.getVertexDoFFunction().sumSharedCopies( level, flag );
+         if ( kinds & 0xFEu )
+            dst.sumSharedEdgeCopies( level, flag );
+      }
+   }
+
+   // P2ConstantOperator::smooth_sor / smooth_gs (src/constant_stencil_operator/P2ConstantOperator.cpp:113-153, macro-cell part
+   // :913-1200).  On a macro-cell the reference sweeps the vertex DoFs in lexicographic order
+   // (sor_3D_macrocell_P2_update_vertexdofs[_backwards]: vertex-to-vertex and edge-to-vertex stencils, edge DoFs as they are) and
+   // then the edge DoFs type by type, X, Y, Z, XY, XZ, YZ, XYZ (sor_3D_macrocell_P2_update_edgedofs_by_type_*; backwards: the
+   // reverse, edge types first) -- no element holds two edges of one type, so the DoFs of a type do not couple and a type's
+   // sweep is order-free.  Here:
+   //   * vertex DoFs:  rhs' = rhs_v - ( A u )_v + ( A_vv u_v )_v  moves the edge contributions to the right-hand side; then the
+   //     P1 sweep of the vertex-to-vertex operator (P1ConstantOperator< P2VertexToVertexForm >::smooth_sor: exact lexicographic
+   //     order inside the cells, the reference's vertex / edge / face order on shared primitives);
+   //   * edge DoFs INSIDE the macro-cells, type T:  e_T += relax D^-1 ( rhs - A u )_T  with the apply restricted to that type --
+   //     this IS the reference's macro-cell sweep;
+   //   * edge DoFs on primitives shared between macro-cells (before the cell sweeps, as in the reference, which treats
+   //     macro-edges and -faces before the cells): the edge type of such a DoF differs from neighbour cell to neighbour cell
+   //     (every cell has its own local frame), so the colour of a shared DoF is its type in the lowest-numbered neighbour cell:
+   //     per colour every cell applies the operator on its shell (all types), the shares are summed, every cell updates its
+   //     shell DoFs of that type, and the copies are then overwritten with the owner's -- each shared DoF is updated exactly
+   //     once per sweep.  DoFs of one colour with different owner cells can couple: there the sweep is a Jacobi step between
+   //     them.  A Gauss-Seidel ordering of the same splitting, not the reference's iterates on multi-cell meshes.
+   void smooth_sor( const P2Function< double >& dst, const P2Function< double >& rhs, double relax, uint_t level, DoFType flag,
+                    bool backwards = false ) const
+   {
+      if ( &dst == &rhs )
+         throw std::runtime_error( "P2ElementwiseOperator::smooth_sor: dst and rhs must differ" );
+      if ( !v2v_ )
+      {
+         v2v_.reset( new P1ConstantOperator< forms::P2VertexToVertexForm< P2Form > >( storage_, minLevel_, maxLevel_ ) );
+         sorTmp_.reset( new P2Function< double >( "p2_sor_tmp", storage_, minLevel_, maxLevel_ ) );
+         sorTmpV_.reset( new P1Function< double >( "p2_sor_tmp_v", storage_, minLevel_, maxLevel_ ) );
+      }
+      const P2Function< double >& t  = *sorTmp_;
+      const P1Function< double >& tv = t.getVertexDoFFunction();
+      const P1Function< double >& sv = *sorTmpV_;
+      const P1Function< double >& uv = dst.getVertexDoFFunction();
+      const bool                  shared = storage_->getCells().size() > 1;
+      auto vertexSweep = [&]() {
+         applyKinds( dst, t, level, flag, 1u );
+         v2v_->apply( uv, sv, level, flag );
+         tv.assign( { 1.0, -1.0, 1.0 }, { rhs.getVertexDoFFunction(), tv, sv }, level, flag );
+         v2v_->smooth_sor( uv, tv, relax, level, flag, backwards );
+      };
+      auto update = [&]( unsigned k, unsigned keep ) {
+         t.assignKinds( { 1.0, -1.0 }, { rhs, t }, level, flag, k, keep );
+         t.multElementwiseKinds( { *getInverseDiagonalValues(), t }, level, flag, k, keep );
+         dst.addKinds( { relax }, { t }, level, flag, k, keep );
+      };
+      auto sharedEdgeSweep = [&]( int type ) {
+         applyKinds( dst, t, level, flag, 0xFEu, HYTEG_HIP_MASK_SHELL ); // every cell's share of every shared edge DoF, summed
+         update( 1u << type, HYTEG_HIP_MASK_SHELL );
+         dst.syncSharedEdgeCopies( level, flag ); // the lowest-numbered neighbour cell's copy (and its frame) decides
+      };
+      auto cellEdgeSweep = [&]( int type ) {
+         applyKinds( dst, t, level, flag, 1u << type, HYTEG_HIP_MASK_INNER );
+         update( 1u << type, HYTEG_HIP_MASK_INNER );
+      };
+      if ( !backwards )
+      {
+         vertexSweep();
+         if ( shared )
+            for ( int type = 1; type <= 7; ++type )
+               sharedEdgeSweep( type );
+         for ( int type = 1; type <= 7; ++type )
+            cellEdgeSweep( type );
+      }
+      else
+      {
+         for ( int type = 7; type >= 1; --type )
+            cellEdgeSweep( type );
+         if ( shared )
+            for ( int type = 7; type >= 1; --type )
+               sharedEdgeSweep( type );
+         vertexSweep();
+      }
+   }
+   void smooth_gs( const P2Function< double >& dst, const P2Function< double >& rhs, uint_t level, DoFType flag ) const
+   {
+      smooth_sor( dst, rhs, 1.0, level, flag );
+   }
+
    // P2ElementwiseOperator::smooth_jac (P2ElementwiseOperator.cpp:344-374), statement by statement:
    //   dst = A src;  dst = rhs - dst;  dst = D^-1 dst;  dst = src + relax dst
    void smooth_jac( const P2Function< double >& dst, const P2Function< double >& rhs, const P2Function< double >& src, double relax,
@@ -226,15 +339,16 @@ class P2ElementwiseOperator
       launchWith( elementMatrices_.at( level ), alpha, src, dst, level, flag, keep, update );
    }
    void launchWith( const std::vector< const double* >& tables, double alpha, const P2Function< double >& src, const P2Function< double >& dst,
-                    uint_t level, DoFType flag, unsigned keep, int update ) const
+                    uint_t level, DoFType flag, unsigned keep, int update, unsigned kinds = 0xFFu ) const
    {
       for ( uint_t c = 0; c < storage_->getNumberOfLocalCells(); ++c )
       {
          const MacroCell& cell = storage_->getLocalCell( c );
-         hipCheck( hyteg_hip_p2_elementwise_apply_cell( dst.getVertexDoFFunction().getCellPointer( c, level ), dst.getEdgeCellPointer( c, level ),
-                                                        src.getVertexDoFFunction().getCellPointer( c, level ), src.getEdgeCellPointer( c, level ),
-                                                        (int) level, tables.at( c ), alpha, update, storage_->maskFor( cell, flag ) & keep,
-                                                        storage_->stream() ),
+         hipCheck( hyteg_hip_p2_elementwise_apply_cell_kinds( dst.getVertexDoFFunction().getCellPointer( c, level ),
+                                                              dst.getEdgeCellPointer( c, level ),
+                                                              src.getVertexDoFFunction().getCellPointer( c, level ),
+                                                              src.getEdgeCellPointer( c, level ), (int) level, tables.at( c ), alpha, update,
+                                                              storage_->maskFor( cell, flag ) & keep, kinds, storage_->stream() ),
                    "P2ElementwiseOperator::gemv" );
       }
    }
@@ -243,6 +357,9 @@ class P2ElementwiseOperator
    std::map< uint_t, std::vector< const double* > >             elementMatrices_;
    std::map< uint_t, std::vector< std::vector< double > > >     hostMatrices_;
    std::shared_ptr< P2Function< double > >                      inverseDiagonalValues_;
+   mutable std::unique_ptr< P1ConstantOperator< forms::P2VertexToVertexForm< P2Form > > > v2v_; // smooth_sor
+   mutable std::unique_ptr< P2Function< double > >                                        sorTmp_;
+   mutable std::unique_ptr< P1Function< double > >                                        sorTmpV_;
    uint64_t                                                     uid_ = nextUid();
 };
 using P2ElementwiseLaplaceOperator = P2ElementwiseOperator< forms::P2LaplaceForm >; // P2ElementwiseOperator.hpp:454

@@ -165,18 +165,22 @@ template < class OperatorType >
 class SORSmoother : public Solver< OperatorType >
 {
  public:
+   using FunctionType = typename OperatorType::srcType; // P1Function or P2Function
    explicit SORSmoother( double relax )
    : relax_( relax )
    , flag_( Inner | NeumannBoundary )
    {}
-   void solve( const OperatorType& A, const P1Function< double >& x, const P1Function< double >& b, uint_t level ) override
+   void solve( const OperatorType& A, const FunctionType& x, const FunctionType& b, uint_t level ) override
    {
       A.smooth_sor( x, b, relax_, level, flag_ );
    }
-   void solveMany( const OperatorType& A, const std::vector< std::reference_wrapper< const P1Function< double > > >& xs,
-                   const std::vector< std::reference_wrapper< const P1Function< double > > >& bs, uint_t level ) override
+   void solveMany( const OperatorType& A, const std::vector< std::reference_wrapper< const FunctionType > >& xs,
+                   const std::vector< std::reference_wrapper< const FunctionType > >& bs, uint_t level ) override
    {
-      A.smooth_sor_many( xs, bs, relax_, level, flag_ );
+      if constexpr ( std::is_same< FunctionType, P1Function< double > >::value )
+         A.smooth_sor_many( xs, bs, relax_, level, flag_ );
+      else
+         Solver< OperatorType >::solveMany( A, xs, bs, level );
    }
 
  private:

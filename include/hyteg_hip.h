@@ -557,6 +557,17 @@ HYTEG_HIP_API int hyteg_hip_p2_edge_vector_cell_masked( int                  op,
                                                         int                  level,
                                                         unsigned             mask,
                                                         hyteg_hip_stream_t   stream );
+/* the same restricted further to the edge-DoF orientations in kind_mask (bit 1..7 = X, Y, Z, XY, XZ, YZ, XYZ): the sweeps
+ * "by type" of the P2 Gauss-Seidel smoother (sor_3D_macrocell_P2_update_edgedofs_by_type_*, P2ConstantOperator.cpp:913-1200) */
+HYTEG_HIP_API int hyteg_hip_p2_edge_vector_cell_kinds( int                  op,
+                                                       double*              dst,
+                                                       int                  nsrc,
+                                                       const double* const* srcs,
+                                                       const double*        scalars,
+                                                       int                  level,
+                                                       unsigned             mask,
+                                                       unsigned             kind_mask,
+                                                       hyteg_hip_stream_t   stream );
 HYTEG_HIP_API int hyteg_hip_p2_edge_dot_cell_masked( const double*      a,
                                                      const double*      b,
                                                      int                level,
@@ -573,6 +584,19 @@ HYTEG_HIP_API int    hyteg_hip_p2_elementwise_apply_cell( double*            dst
                                                           double             alpha,
                                                           int                update,
                                                           unsigned           mask,
+                                                          hyteg_hip_stream_t stream );
+/* ... only the destination kinds in kind_mask (bit 0: vertex DoFs, 1..7: edge DoFs X, Y, Z, XY, XZ, YZ, XYZ) are computed and
+ * written; the others are left alone */
+HYTEG_HIP_API int    hyteg_hip_p2_elementwise_apply_cell_kinds( double*            dst_vertex,
+                                                          double*            dst_edge,
+                                                          const double*      src_vertex,
+                                                          const double*      src_edge,
+                                                          int                level,
+                                                          const double*      optable_dev,
+                                                          double             alpha,
+                                                          int                update,
+                                                          unsigned           mask,
+                                                          unsigned           kind_mask,
                                                           hyteg_hip_stream_t stream );
 
 /* a10: additive exchange of shared points (the reduce-into-owner of VertexDoFAdditivePackInfo.hpp:676-745,

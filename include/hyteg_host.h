@@ -193,7 +193,13 @@ HYTEG_HOST_API int hyteg_host_p2operator_compute_inverse_diagonal( hh_p2operator
 HYTEG_HOST_API int hyteg_host_p2operator_inverse_diagonal_copy( hh_p2operator_t op, hh_p2function_t dst, int level );
 HYTEG_HOST_API int hyteg_host_p2operator_smooth_jac( hh_p2operator_t op, hh_p2function_t dst, hh_p2function_t rhs, hh_p2function_t src, double relax,
                                                      int level, int flag );
-HYTEG_HOST_API int hyteg_host_p2_gmg_create( hh_storage_t s, int min_level, int max_level, double relax, int pre, int post, int wcycle,
+/* smooth_sor: P2ConstantOperator::smooth_sor (P2ConstantOperator.cpp:113-153; macro-cell part :913-1200: vertex DoFs in
+ * lexicographic order, then the edge DoFs type by type; backwards: reversed).  Exactly the reference's sweep inside a macro-cell;
+ * on DoFs shared between macro-cells a different Gauss-Seidel ordering of the same splitting.  Needs
+ * compute_inverse_diagonal.  gmg smoother: 0 weighted Jacobi( relax ), 1 Gauss-Seidel, 2 SOR( relax ). */
+HYTEG_HOST_API int hyteg_host_p2operator_smooth_sor( hh_p2operator_t op, hh_p2function_t dst, hh_p2function_t rhs, double relax, int level, int flag,
+                                                     int backwards );
+HYTEG_HOST_API int hyteg_host_p2_gmg_create( hh_storage_t s, int min_level, int max_level, int smoother, double relax, int pre, int post, int wcycle,
                                              int cg_max_iter, double cg_tol, hh_p2solver_t* out );
 HYTEG_HOST_API int hyteg_host_p2_solver_solve( hh_p2solver_t solver, hh_p2operator_t op, hh_p2function_t x, hh_p2function_t b, int level );
 HYTEG_HOST_API int hyteg_host_p2_solver_destroy( hh_p2solver_t solver );

@@ -127,3 +127,69 @@ def test_p2_gmg_recovers_a_harmonic_quadratic(env, mesh, min_level, max_level):
     for o in (x, b, r, ex, err, A, gmg):
         o.close()
     st.close()
+
+
+@pytest.mark.parametrize("level", [2, 3])
+def test_p2_smooth_sor_on_one_macro_cell_is_the_reference_sweep(env, level):
+    """vertex DoFs in lexicographic order, then the edge DoFs type by type (backwards: reversed), every update with the current
+    values of all other DoFs: oracle/p2_sor_oracle.py restates sor_3D_macrocell_P2_update_{vertexdofs,edgedofs_by_type}*"""
+    torch, host, po, hu = env
+    from oracle import p2_sor_oracle as ps
+
+    st = host.Storage.from_gmsh(MESHES / "tet_1el.msh")
+    A = host.P2ElementwiseLaplaceOperator(st, level, level)
+    A.compute_inverse_diagonal()
+    u, b = host.P2Function(st, "u", level, level), host.P2Function(st, "b", level, level)
+    gid, co, nnc = st.local_cell(0)
+    M = ps.assemble_cell_matrix(np.asarray(co).reshape(12), level)
+    rng = np.random.default_rng(level)
+    nv, ne = po.cell_size(level), po.edge_array_size(level)
+    uv0, ue0, bv, be = rng.standard_normal(nv), rng.standard_normal(ne), rng.standard_normal(nv), rng.standard_normal(ne)
+    b.upload(level, bv, be, 0)
+    for relax, backwards in ((1.0, False), (1.0, True), (0.8, False), (1.2, True)):
+        u.upload(level, uv0, ue0, 0)
+        A.smooth_sor(u, b, relax, level, host.Inner, backwards)
+        gv, ge = u.download(level, 0)
+        wv, we = ps.sor_cell(M, uv0, ue0, bv, be, level, relax, backwards)
+        scale = max(np.abs(wv).max(), np.abs(we).max())
+        assert np.abs(gv - wv).max() <= 1e-12 * scale and np.abs(ge - we).max() <= 1e-12 * scale, (relax, backwards)
+    for o in (u, b, A):
+        o.close()
+    st.close()
+
+
+def test_p2_gmg_3d_convergence_test_of_the_reference(env):
+    """tests/hyteg/convergence/P2GMG3DConvergenceTest.cpp: regular_octahedron_8el, levels 0-3, V(2,2) with the Gauss-Seidel
+    smoother, CG on level 0, u = sin(x) sinh(y) z on the boundary, random inner start: the ratio of the squared discrete L2
+    residuals of consecutive cycles stays below 3e-2 (:128).  Our sweep orders the DoFs shared between macro-cells differently
+    from the reference, so this pins the criterion, not the iterates."""
+    torch, host, po, hu = env
+    min_level, max_level = 0, 3
+    st = host.Storage.from_gmsh(MESHES / "regular_octahedron_8el.msh")
+    A = host.P2ConstantLaplaceOperator(st, min_level, max_level)
+    A.compute_inverse_diagonal()
+    u, f, r, ex = (host.P2Function(st, n, min_level, max_level) for n in ("u", "f", "r", "ex"))
+    L = max_level
+    rng = np.random.default_rng(0)
+    _upload(po, hu, st, ex, L, lambda p: np.sin(p[:, 0]) * np.sinh(p[:, 1]) * p[:, 2])
+    # random inner start: the same random value on every copy of a shared DoF does not matter for the criterion, the Dirichlet
+    # data does
+    _upload(po, hu, st, u, L, lambda p: np.sin(37.0 * p[:, 0] + 11.0 * p[:, 1]) * np.cos(23.0 * p[:, 2]) * 0.5 + 0.5)
+    u.assign([1.0], [ex], L, host.DirichletBoundary)
+    f.interpolate(0.0, L)
+    gmg = host.P2Solver(st, min_level, max_level, pre=2, post=2, smoother=host.GAUSS_SEIDEL)
+
+    def res2():
+        r.interpolate(0.0, L)
+        A.apply(u, r, L, host.Inner)
+        return r.dot(r, L, host.Inner)
+
+    last = res2()
+    for cycle in range(4):
+        gmg.solve(A, u, f, L)
+        now = res2()
+        assert now / last < 3.0e-2, (cycle, now / last)
+        last = now
+    for o in (u, f, r, ex, A, gmg):
+        o.close()
+    st.close()
