@@ -780,6 +780,26 @@ struct SrcIndex
    static constexpr SrcIndexOf< C > value = build_src_index< C >();
 };
 
+// which destination kinds use source i (bit per kind): a kind-restricted apply (the per-type sweeps of the P2 Gauss-Seidel
+// smoother) loads only the sources of the kinds it computes
+struct SrcUsers
+{
+   unsigned m[160];
+};
+constexpr SrcUsers build_src_users()
+{
+   SrcUsers          R{};
+   const KindStencil S8[8] = { KindStencilOf< 0 >::value, KindStencilOf< 1 >::value, KindStencilOf< 2 >::value, KindStencilOf< 3 >::value,
+                               KindStencilOf< 4 >::value, KindStencilOf< 5 >::value, KindStencilOf< 6 >::value, KindStencilOf< 7 >::value };
+   for ( int i = 0; i < kSrc.n; ++i )
+      for ( int c = 0; c < 8; ++c )
+         for ( int q = 0; q < S8[c].n; ++q )
+            if ( kSrc.kind[i] == S8[c].kind[q] && kSrc.dx[i] == S8[c].dx[q] && kSrc.dy[i] == S8[c].dy[q] && kSrc.dz[i] == S8[c].dz[q] )
+               R.m[i] |= 1u << c;
+   return R;
+}
+constexpr SrcUsers kSrcUsers = build_src_users();
+
 struct P2RowsArgs
 {
    P2FastArgs  F;
@@ -830,7 +850,9 @@ __device__ inline void p2_rows_kind( const P2RowsArgs& A, const double ( &U )[kS
    __builtin_amdgcn_raw_buffer_store_b64( p2_v2i{ __double2loint( acc ), __double2hiint( acc ) }, rd, voff, 0, 0 );
 }
 
-template < int UPDATE >
+// RESTRICTED: only some destination kinds are computed (A.F.kinds) and only their sources are loaded; the unrestricted form
+// keeps its loads free of branches (with one wave-uniform branch per load the full apply was 16 % slower)
+template < int UPDATE, bool RESTRICTED = false >
 __device__ inline void p2_rows_body( const P2RowsArgs& A, int block )
 {
    const int t = __builtin_amdgcn_readfirstlane( block * kRowsWaves + ( (int) threadIdx.x >> 6 ) );
@@ -851,23 +873,28 @@ __device__ inline void p2_rows_body( const P2RowsArgs& A, int block )
    [&]< int... I >( std::integer_sequence< int, I... > ) {
       ( ( [&] {
            constexpr int K = kSrc.kind[I], DX = kSrc.dx[I], DY = kSrc.dy[I], DZ = kSrc.dz[I];
-           const int     voff = p2_rows_base< K, DY, DZ >( i0, N, y, z ) + lane8 + ( DX + 1 ) * 8;
-           const p2_v2i  v    = __builtin_amdgcn_raw_buffer_load_b64( K == 0 ? rsV : rsE, voff, 0, 0 );
-           U[I]               = __hiloint2double( v.y, v.x );
+           double        u = 0.0;
+           if ( !RESTRICTED || ( kSrcUsers.m[I] & A.F.kinds ) ) // wave-uniform: sources of kinds that are not computed are not loaded
+           {
+              const int    voff = p2_rows_base< K, DY, DZ >( i0, N, y, z ) + lane8 + ( DX + 1 ) * 8;
+              const p2_v2i v    = __builtin_amdgcn_raw_buffer_load_b64( K == 0 ? rsV : rsE, voff, 0, 0 );
+              u                 = __hiloint2double( v.y, v.x );
+           }
+           U[I] = u;
         }() ),
         ... );
    }
    ( std::make_integer_sequence< int, kSrc.n >{} );
 
    [&]< int... C >( std::integer_sequence< int, C... > ) {
-      ( ( ( A.F.kinds >> C ) & 1u ? p2_rows_kind< C, UPDATE >( A, U, i0, lane, x, y, z, tl.cnt, rdV, rdE ) : (void) 0 ), ... );
+      ( ( ( !RESTRICTED || ( ( A.F.kinds >> C ) & 1u ) ) ? p2_rows_kind< C, UPDATE >( A, U, i0, lane, x, y, z, tl.cnt, rdV, rdE ) : (void) 0 ), ... );
    }
    ( std::make_integer_sequence< int, 8 >{} );
 }
-template < int UPDATE >
+template < int UPDATE, bool RESTRICTED >
 __global__ __launch_bounds__( 64 * kRowsWaves, 2 ) void p2_rows_kernel( const P2RowsArgs A )
 {
-   p2_rows_body< UPDATE >( A, (int) blockIdx.x );
+   p2_rows_body< UPDATE, RESTRICTED >( A, (int) blockIdx.x );
 }
 
 // Boundary DoFs in stencil form (levels >= 2): which adjacent micro-cells exist depends only on the macro-primitive the DoF
@@ -1233,12 +1260,26 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell_kinds( double*            
       const unsigned rowBlocks = (unsigned) ( ( tt.count + kRowsWaves - 1 ) / kRowsWaves );
       const unsigned shell     = mask & HYTEG_HIP_MASK_SHELL;
       const int      nb        = shell ? nbx : 0;
-      if ( nb == 0 )
+      if ( kind_mask != 0xFFu )
+      {
+         // some kinds only: the boundary DoFs (their kernel skips the other kinds) in their own launch, the rows restricted
+         if ( nb )
+         {
+            P2ClassArgs B;
+            B.F = F, B.mask = shell;
+            hipLaunchKernelGGL( p2_boundary_kernel, dim3( (unsigned) nbx, 8 ), dim3( kThreads ), 0, s, B );
+         }
+         if ( update == HYTEG_HIP_ADD )
+            hipLaunchKernelGGL( ( p2_rows_kernel< HYTEG_HIP_ADD, true > ), dim3( rowBlocks ), dim3( kThreads ), 0, s, R );
+         else
+            hipLaunchKernelGGL( ( p2_rows_kernel< HYTEG_HIP_REPLACE, true > ), dim3( rowBlocks ), dim3( kThreads ), 0, s, R );
+      }
+      else if ( nb == 0 )
       {
          if ( update == HYTEG_HIP_ADD )
-            hipLaunchKernelGGL( p2_rows_kernel< HYTEG_HIP_ADD >, dim3( rowBlocks ), dim3( kThreads ), 0, s, R );
+            hipLaunchKernelGGL( ( p2_rows_kernel< HYTEG_HIP_ADD, false > ), dim3( rowBlocks ), dim3( kThreads ), 0, s, R );
          else
-            hipLaunchKernelGGL( p2_rows_kernel< HYTEG_HIP_REPLACE >, dim3( rowBlocks ), dim3( kThreads ), 0, s, R );
+            hipLaunchKernelGGL( ( p2_rows_kernel< HYTEG_HIP_REPLACE, false > ), dim3( rowBlocks ), dim3( kThreads ), 0, s, R );
       }
       else if ( update == HYTEG_HIP_ADD )
          hipLaunchKernelGGL( p2_apply_fused_kernel< HYTEG_HIP_ADD >, dim3( 8 * nb + rowBlocks ), dim3( kThreads ), 0, s, R, shell, nb );

@@ -46,6 +46,36 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / args.reps
             print(f"level {L} P2 apply, {name:14s} {us:8.2f} us   ({nv + ne} DoFs, {16 * (nv + ne) / us * 1e-3:7.1f} GB/s algorithmic if all)", flush=True)
+        # one destination kind at a time (the per-type sweeps of the Gauss-Seidel smoother) and a whole sweep through the host layer
+        for kinds, name in ((0x01, "vertex DoFs only"), (0x02, "X edges only"), (0x80, "XYZ edges only")):
+            def fk(k):
+                capi.p2_elementwise_apply_cell(DV[k % nb].data_ptr(), DE[k % nb].data_ptr(), SV[k % nb].data_ptr(), SE[k % nb].data_ptr(),
+                                               L, em.data_ptr(), 1.0, 0, 0x4000, sh, kinds)
+            for k in range(3):
+                fk(k)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for k in range(args.reps):
+                fk(k)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            print(f"level {L} P2 apply, inner, {name:17s} {e0.elapsed_time(e1) * 1e3 / args.reps:8.2f} us", flush=True)
+        op.compute_inverse_diagonal()
+        x, b = host.P2Function(st, "x", L, L), host.P2Function(st, "b", L, L)
+        x.interpolate(1.0, L, host.Inner)
+        b.interpolate(0.0, L)
+        for k in range(2):
+            op.smooth_sor(x, b, 1.0, L, host.Inner)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for k in range(5):
+            op.smooth_sor(x, b, 1.0, L, host.Inner)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        print(f"level {L} P2 Gauss-Seidel sweep (host layer, one macro-cell) {e0.elapsed_time(e1) * 1e3 / 5:9.1f} us", flush=True)
+        x.close(), b.close()
 
 
 if __name__ == "__main__":
