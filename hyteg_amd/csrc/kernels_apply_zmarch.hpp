@@ -198,22 +198,22 @@ __device__ inline BrickTask zm_decode_task( const ZMarchArgs& A, int task )
 // re-reads it).  gfx950 "aux" bits: 1 = sc0, 2 = nt, 16 = sc1.
 // PFD: how many slices ahead of the one being computed the loads run.
 // T: value type of the arrays and of the arithmetic (double or float; the weights travel as doubles and are converted).
-template < int MODE, int NY, int LZ, int EX_AUX = 0, bool DEC = false, int PFD = 1, typename T = double >
-__global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_kernel( const ZMarchArgs A )
+template < int MODE, int NY, int LZ, int EX_AUX, bool DEC, int PFD, typename T >
+__device__ inline void zmarch_body( const ZMarchArgs& A, const BrickTask* tasks, int ntasks, int xcd_chunk )
 {
    constexpr int SZ = (int) sizeof( T );
    ZM_TRACE( 0 );
    int b = blockIdx.x;
-   if ( A.xcd_chunk > 0 )
-      b = ( blockIdx.x & 7 ) * A.xcd_chunk + ( blockIdx.x >> 3 );
+   if ( xcd_chunk > 0 )
+      b = ( blockIdx.x & 7 ) * xcd_chunk + ( blockIdx.x >> 3 );
    const int task = __builtin_amdgcn_readfirstlane( b * kZMarchWavesPerBlock + ( threadIdx.x >> 6 ) );
-   if ( task >= A.ntasks )
+   if ( task >= ntasks )
       return;
    BrickTask t;
    if constexpr ( DEC )
       t = zm_decode_task< NY, LZ >( A, task );
    else
-      t = A.tasks[task];
+      t = tasks[task];
    const int lane = threadIdx.x & 63;
    ZM_TRACE( 1 );
 
@@ -372,6 +372,23 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_k
    [&]< int... Is >( std::integer_sequence< int, Is... > ) { ( step( std::integral_constant< int, Is >{} ), ... ); }
    ( std::make_integer_sequence< int, LZ >{} );
    ZM_TRACE( 4 );
+}
+
+template < int MODE, int NY, int LZ, int EX_AUX = 0, bool DEC = false, int PFD = 1, typename T = double >
+__global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_kernel( const ZMarchArgs A )
+{
+   zmarch_body< MODE, NY, LZ, EX_AUX, DEC, PFD, T >( A, A.tasks, A.ntasks, A.xcd_chunk );
+}
+
+// The same kernel with the three values a wave needs before it can fetch its brick -- table pointer, task count, XCD chunk --
+// as leading scalar arguments: built with -mllvm -amdgpu-kernarg-preload-count=4 the command processor places them in SGPRs
+// at wave launch, so the task load does not wait for a kernel-argument load first (one scalar round trip less in the start-up
+// chain of DESIGN 3.1).  The rest of the arguments stay in the struct.
+template < int MODE, int NY, int LZ, int EX_AUX = 0, bool DEC = false, int PFD = 1, typename T = double >
+__global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_preload_kernel( const BrickTask* tasks, int ntasks, int xcd_chunk,
+                                                                                              const ZMarchArgs A )
+{
+   zmarch_body< MODE, NY, LZ, EX_AUX, DEC, PFD, T >( A, tasks, ntasks, xcd_chunk );
 }
 
 // host: bricks of NY rows x 62 outputs x LZ slices, ordered z-chunk, y-chunk, x-chunk (memory order); zs (optional)

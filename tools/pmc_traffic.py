@@ -34,14 +34,15 @@ def mean_counter(prefix, kernel_substr, counter):
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
 
-fetch, nf = mean_counter("bench", "p1_apply_zmarch_kernel", "FETCH_SIZE")
-write, nw = mean_counter("bench", "p1_apply_zmarch_kernel", "WRITE_SIZE")
+KERNEL = "p1_apply_zmarch_"  # p1_apply_zmarch_kernel or p1_apply_zmarch_preload_kernel (first arguments preloaded into SGPRs)
+fetch, nf = mean_counter("bench", KERNEL, "FETCH_SIZE")
+write, nw = mean_counter("bench", KERNEL, "WRITE_SIZE")
 cfetch, _ = mean_counter("calib", "calib_copy_kernel<false>", "FETCH_SIZE")
 cwrite, _ = mean_counter("calib", "calib_copy_kernel<false>", "WRITE_SIZE")
 kname = None
 for f in newest_per_pass("bench"):
     for r in csv.DictReader(open(f)):
-        if "p1_apply_zmarch_kernel" in r["Kernel_Name"]:
+        if KERNEL in r["Kernel_Name"]:
             kname = r["Kernel_Name"].split("(")[0]
             break
     if kname:
@@ -55,12 +56,12 @@ def capi_kernel_name(rocprof_name):
     (and bench.py's roofline.kernel) uses: 'p1_apply_zmarch_kernel<MODE=0,NY=4,LZ=8,EX_AUX=0,DEC=0,PFD=2>'"""
     import re
 
-    m = re.search(r"p1_apply_zmarch_kernel<([^>]*)>", rocprof_name)
+    m = re.search(r"(p1_apply_zmarch_(?:preload_)?kernel)<([^>]*)>", rocprof_name)
     if not m:
         return None
-    a = [x.strip() for x in m.group(1).split(",")]
+    a = [x.strip() for x in m.group(2).split(",")]
     dec = {"false": "0", "true": "1"}.get(a[4], a[4])
-    name = f"p1_apply_zmarch_kernel<MODE={a[0]},NY={a[1]},LZ={a[2]},EX_AUX={a[3]},DEC={dec},PFD={a[5]}>"
+    name = f"{m.group(1)}<MODE={a[0]},NY={a[1]},LZ={a[2]},EX_AUX={a[3]},DEC={dec},PFD={a[5]}>"
     return name if len(a) < 7 or a[6] == "double" else name[:-1] + f",T={a[6]}>"
 
 
