@@ -192,39 +192,89 @@ def main():
         # -> interior stencil kernel (overlaps the exchange) -> reduction of the shares
         laplace.apply(srcs[k % nbuf], dsts[k % nbuf], level, host.Inner, host.Replace)
 
-    # untimed: every ring pair is touched (twice) whatever --warmup says, so that no first access (page tables, TLB) of a
-    # buffer falls into the timed region; then the W warm-up steps of the contract
-    pre_warm = 2 * nbuf
-    for k in range(pre_warm):
-        step(k)
-    for k in range(args.warmup):
-        step(k)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for k in range(args.steps):
-        step(k)
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels are launched on
+    def all_ranks(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag.item()))
 
-    # the same K steps once more, every step between its own pair of events (reported beside the region mean: an upper bound,
-    # the events themselves cost ~2.4 us each between two kernels)
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    evs[0].record(stream)
-    for k in range(args.steps):
-        step(k)
-        evs[k + 1].record(stream)
-    torch.cuda.synchronize()
-    per_step_us = sorted(evs[k].elapsed_time(evs[k + 1]) * 1e3 for k in range(args.steps))
+    def results(pairs):
+        """apply on the given ring pairs -> the destination arrays of this rank's cells (bytes are compared)"""
+        out = []
+        for k in pairs:
+            step(k)
+            out += [dsts[k % nbuf].download_cell(c, level) for c in range(storage.n_local_cells)]
+        return out
+
+    # N > 1: the exchange goes peer to peer (pack kernels store into the neighbour GPUs' IPC-mapped arenas, comm_p2p.hip)
+    # if -- and only if -- that reproduces, bit for bit on every rank, what the RCCL send/recv transport underneath delivers,
+    # before and after the timed region; otherwise the run is (re)done on RCCL.  HYTEG_BENCH_P2P=0 skips the attempt.
+    p2p = {"tried": False}
+    check_pairs = [0, 1, 0, 1 % nbuf, 0]  # both slot parities, repeated
+    if world > 1 and os.environ.get("HYTEG_BENCH_P2P", "1") != "0":
+        reference = results(check_pairs)
+        p2p["tried"] = True
+        if ctx.enable_p2p():
+            ok, err = True, ""
+            try:
+                got = results(check_pairs)
+                storage.check_transport()
+                ok = all(np.array_equal(a, b) for a, b in zip(got, reference))
+            except Exception as e:  # noqa: BLE001 -- agreed on below
+                ok, err = False, repr(e)
+            if not all_ranks(ok):
+                ctx.disable_p2p(f"peer-to-peer exchange did not reproduce the RCCL results before the timed region {err}: run on "
+                                f"{ctx.inner_transport}")
+        p2p["used_before"] = ctx.transport == "p2p"
+
+    def measure():
+        # untimed: every ring pair is touched (twice) whatever --warmup says, so that no first access (page tables, TLB) of a
+        # buffer falls into the timed region; then the W warm-up steps of the contract
+        for k in range(pre_warm):
+            step(k)
+        for k in range(args.warmup):
+            step(k)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for k in range(args.steps):
+            step(k)
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels are launched on
+
+        # the same K steps once more, every step between its own pair of events (reported beside the region mean: an upper
+        # bound, the events themselves cost ~2.4 us each between two kernels)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        evs[0].record(stream)
+        for k in range(args.steps):
+            step(k)
+            evs[k + 1].record(stream)
+        torch.cuda.synchronize()
+        per_step_us = sorted(evs[k].elapsed_time(evs[k + 1]) * 1e3 for k in range(args.steps))
+        return elapsed, dev_ms, per_step_us
+
+    pre_warm = 2 * nbuf
+    elapsed, dev_ms, per_step_us = measure()
+    if world > 1 and ctx.transport == "p2p":
+        ok, err = True, ""
+        try:
+            got = results(check_pairs)
+            storage.check_transport()
+            ok = all(np.array_equal(a, b) for a, b in zip(got, reference))
+        except Exception as e:  # noqa: BLE001
+            ok, err = False, repr(e)
+        if not all_ranks(ok):
+            ctx.disable_p2p(f"peer-to-peer exchange failed its check after the timed region {err}: measured again on {ctx.inner_transport}")
+            elapsed, dev_ms, per_step_us = measure()
+    p2p["verified"] = world > 1 and ctx.transport == "p2p"
     median_us = per_step_us[len(per_step_us) // 2]
 
     if dist is not None:
@@ -279,6 +329,10 @@ def main():
                 "halo_exchange": (f"transport '{ctx.transport}': "
                                   + ("ncclSend/ncclRecv groups issued by the C++ host layer on a communication stream (RCCL over xGMI), "
                                      "event-ordered, overlapped with the interior kernel" if ctx.transport == "rccl" else
+                                     f"pack kernel stores into the neighbour GPUs' IPC-mapped {ctx.p2p_arena['kind']} arenas over xGMI, "
+                                     "one-wave wait kernel before the reduce kernel, no library call per exchange; results equal to the "
+                                     f"'{ctx.inner_transport}' transport's bit for bit on every rank before and after the timed region"
+                                     if ctx.transport == "p2p" else
                                      "torch.distributed all_to_all hooks (rehearsal transport)")
                                   + (f" [{ctx.transport_note}]" if ctx.transport_note else "")
                                   if world > 1 else None),

@@ -39,6 +39,12 @@ SIGNATURES = {
     "hyteg_hip_comm_destroy": (_i, [_vp]),
     "hyteg_hip_comm_exchange": (_i, [_vp, _i, C.POINTER(_i), _vp, C.POINTER(_i), _vp, C.POINTER(_i), _vp]),
     "hyteg_hip_comm_allreduce_sum": (_i, [_vp, _vp, _i, _vp]),
+    "hyteg_hip_p2p_arena_create": (_i, [C.c_size_t, C.POINTER(_vp), C.c_char_p, C.POINTER(_i)]),
+    "hyteg_hip_p2p_arena_destroy": (_i, [_vp]),
+    "hyteg_hip_p2p_arena_open": (_i, [C.c_char_p, C.POINTER(_vp)]),
+    "hyteg_hip_p2p_arena_close": (_i, [_vp]),
+    "hyteg_hip_p2p_pack": (_i, [_vp, _i, _vp, _vp, _vp, _i, C.c_ulonglong, _vp, _vp]),
+    "hyteg_hip_p2p_wait": (_i, [_vp, _i, _i, C.c_ulonglong, _vp, C.c_uint, _vp]),
     "hyteg_hip_graph_begin_capture": (_i, [_vp]),
     "hyteg_hip_graph_end_capture": (_i, [_vp, C.POINTER(_vp)]),
     "hyteg_hip_graph_abort_capture": (_i, [_vp]),

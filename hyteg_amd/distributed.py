@@ -14,6 +14,12 @@ Two transports sit behind the shared-point exchange of the C++ host layer (hyteg
            Backend "gloo" moves them through host memory: this is how the CPU tests and the two-ranks-on-one-GPU tests
            run the multi-rank logic without one GPU per rank.
 
+  "p2p"    on top of either of the two (enable_p2p, or transport="p2p"): the pack kernel stores straight into receive slots
+           inside the neighbour GPUs' IPC-mapped arenas and a one-wave kernel waits for their sequence numbers
+           (hyteg_amd/csrc/comm_p2p.hip) -- no library call per exchange.  torch.distributed carries the set-up only: the
+           64-byte arena handles and, per plan, where every peer expects this rank's values.  The all-reduce of dot
+           products and plans of levels that were not connected stay with the transport underneath.
+
 A plan is identified by (level, key) with key = cls + 2 * dof_kind (boundary class 0 / 1; vertex DoFs / edge DoFs of P2
 functions)."""
 from __future__ import annotations
@@ -32,8 +38,12 @@ class DistributedContext:
         self.device = torch.device(device)
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
+        want_p2p = transport == "p2p"
+        if want_p2p:
+            transport = "auto"
         auto = transport == "auto"
         self.transport_note = ""
+        self._levels, self._dof_kinds = tuple(levels), tuple(dof_kinds)
         if auto:
             transport = "hooks"
             if dist.get_backend() == "nccl" and self.device.type == "cuda":
@@ -58,6 +68,8 @@ class DistributedContext:
             except Exception as e:  # noqa: BLE001 -- reported below, on every rank
                 err = e
             if self._all_ranks(err is None):
+                if want_p2p:
+                    self.enable_p2p()
                 return
             if not auto:
                 raise RuntimeError(f"RCCL transport could not be set up on every rank (this rank: {err!r})")
@@ -99,6 +111,71 @@ class DistributedContext:
         self._stage = dist.get_backend() == "gloo" and self.device.type == "cuda"
         self._scalar = torch.zeros(8, dtype=torch.float64, device="cpu" if self._stage else self.device)
         storage.set_hooks(self.exchange_begin, self.exchange_end, self.allreduce_sum)
+        if want_p2p:
+            self.enable_p2p()
+
+    # ---- peer-to-peer transport on top of the one set up above ----
+    def enable_p2p(self, levels=None, dof_kinds=None) -> bool:
+        """Collective.  Connects the plans of `levels` x `dof_kinds` (default: those given to the constructor) peer to
+        peer.  Returns False -- on every rank, with the storage back on the transport underneath and the reason in
+        transport_note -- if any step fails on any rank (no IPC between the ranks' devices, arena allocation, ...)."""
+        if self.device.type != "cuda":
+            raise RuntimeError("the peer-to-peer transport needs device memory")
+        levels = self._levels if levels is None else tuple(levels)
+        dof_kinds = self._dof_kinds if dof_kinds is None else tuple(dof_kinds)
+        st = self.storage
+        keys = [(lv, cls + 2 * dk) for lv in levels for dk in dof_kinds for cls in (0, 1)]
+        plans = {k: st.plan(*k) for k in keys}
+        align = 256
+        need = 4096 + sum(2 * -(-max(8, 8 * int(p["total_recv"])) // align) * align + -(-max(1, 64 * len(p["peers"])) // align) * align
+                          for p in plans.values())
+
+        def step(fn):
+            err, out = None, None
+            try:
+                out = fn()
+            except Exception as e:  # noqa: BLE001 -- agreed on below, on every rank
+                err = e
+            return out, err
+
+        (res, err) = step(lambda: st.use_p2p(need))
+        if self._all_ranks(err is None):
+            handle, kind = res
+            handles = [None] * self.world
+            dist.all_gather_object(handles, handle)
+            _, err = step(lambda: st.p2p_open(handles))
+        if self._all_ranks(err is None):
+            def lay():
+                mine = {}
+                for k, p in plans.items():
+                    o = st.p2p_layout(k[0], k[1], len(p["peers"]))
+                    mine[k] = {int(peer): [int(x) for x in o[j]] for j, peer in enumerate(p["peers"])}
+                return mine
+            mine, err = step(lay)
+        if self._all_ranks(err is None):
+            everyone = [None] * self.world
+            dist.all_gather_object(everyone, mine)
+
+            def connect():
+                for k, p in plans.items():
+                    st.p2p_connect(k[0], k[1], [everyone[int(peer)][k][self.rank] for peer in p["peers"]])
+            _, err = step(connect)
+        if self._all_ranks(err is None):
+            self.inner_transport = self.transport
+            self.transport = "p2p"
+            self.p2p_arena = {"bytes": need, "kind": ("uncached", "fine-grained", "default")[kind]}
+            return True
+        st.drop_p2p()
+        self.transport_note = f"peer-to-peer transport not available on every rank (this rank: {err!r}): staying on {self.transport}"
+        return False
+
+    def disable_p2p(self, note: str = "") -> None:
+        """back to the transport underneath (collective by convention: every rank must take the same decision)"""
+        if self.transport == "p2p":
+            self.storage.drop_p2p()
+            self.transport = self.inner_transport
+            if note:
+                self.transport_note = note
 
     def _all_ranks(self, ok: bool) -> bool:
         """logical AND over the ranks of a per-rank success flag"""

@@ -33,6 +33,12 @@ SIGNATURES = {
     "hyteg_host_storage_set_batch_max_level": (_i, [_vp, _i]),
     "hyteg_host_storage_set_hooks": (_i, [_vp, EXCHANGE_CB, EXCHANGE_CB, ALLREDUCE_CB, _vp]),
     "hyteg_host_storage_use_rccl": (_i, [_vp, C.c_char_p]),
+    "hyteg_host_storage_use_p2p": (_i, [_vp, C.c_size_t, C.c_char_p, C.POINTER(C.c_int)]),
+    "hyteg_host_storage_p2p_open": (_i, [_vp, C.c_char_p]),
+    "hyteg_host_storage_p2p_layout": (_i, [_vp, _i, _i, C.POINTER(C.c_longlong)]),
+    "hyteg_host_storage_p2p_connect": (_i, [_vp, _i, _i, C.POINTER(C.c_longlong)]),
+    "hyteg_host_storage_drop_p2p": (_i, [_vp]),
+    "hyteg_host_storage_check_transport": (_i, [_vp]),
     "hyteg_host_storage_transport_name": (_i, [_vp, C.c_char_p, _i]),
     "hyteg_host_storage_allreduce_sum": (_i, [_vp, _dp, _i]),
     "hyteg_host_storage_enable_timing": (_i, [_vp, _i, _i]),
@@ -237,6 +243,37 @@ class Storage:
         if len(unique_id) != 128:
             raise ValueError("use_rccl: the unique id has 128 bytes")
         _ck(lib().hyteg_host_storage_use_rccl(self.h, bytes(unique_id)), "storage_use_rccl")
+
+    # ---- peer-to-peer transport on top of the current one (see include/hyteg_host.h for the set-up sequence) ----
+    def use_p2p(self, arena_bytes: int):
+        """-> (this rank's arena handle: 64 bytes, arena kind 0 uncached / 1 fine-grained / 2 default)"""
+        buf = C.create_string_buffer(64)
+        kind = C.c_int(0)
+        _ck(lib().hyteg_host_storage_use_p2p(self.h, int(arena_bytes), buf, C.byref(kind)), "storage_use_p2p")
+        return buf.raw, kind.value
+
+    def p2p_open(self, handles):
+        """handles: the 64-byte handles of all ranks, rank by rank"""
+        blob = b"".join(bytes(h) for h in handles)
+        _ck(lib().hyteg_host_storage_p2p_open(self.h, blob), "storage_p2p_open")
+
+    def p2p_layout(self, level: int, key: int, npeers: int):
+        """-> int64 array [npeers, 3]: byte offsets (slot 0, slot 1, flag) in this rank's arena of every peer's segment"""
+        o = np.zeros((max(npeers, 1), 3), dtype=np.int64)
+        _ck(lib().hyteg_host_storage_p2p_layout(self.h, level, key, o.ctypes.data_as(C.POINTER(C.c_longlong))), "storage_p2p_layout")
+        return o[:npeers]
+
+    def p2p_connect(self, level: int, key: int, offsets):
+        o = np.ascontiguousarray(offsets, dtype=np.int64).reshape(-1, 3)
+        o = o if len(o) else np.zeros((1, 3), dtype=np.int64)
+        _ck(lib().hyteg_host_storage_p2p_connect(self.h, level, key, o.ctypes.data_as(C.POINTER(C.c_longlong))), "storage_p2p_connect")
+
+    def drop_p2p(self):
+        _ck(lib().hyteg_host_storage_drop_p2p(self.h), "storage_drop_p2p")
+
+    def check_transport(self):
+        """synchronises; raises if a device-side wait of the transport has timed out since the last check"""
+        _ck(lib().hyteg_host_storage_check_transport(self.h), "storage_check_transport")
 
     def allreduce_sum(self, values):
         """sum over all ranks of a sequence of floats (through the storage's transport)"""

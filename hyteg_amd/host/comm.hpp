@@ -51,6 +51,15 @@ class Transport
    // a point-to-point transport is only called by ranks that have peers.
    virtual bool collective() const = 0;
    virtual const char* name() const = 0;
+   // A transport that delivers the packed values itself (straight into the peers' receive slots) enqueues the pack here and
+   // returns true; otherwise the storage gathers them into plan.sendBuffer.  Called right before exchangeBegin.
+   // bases / entries: the arguments of hyteg_hip_gather_entries for this plan.
+   virtual bool pack( const ExchangePlan&, int /*level*/, int /*key*/, double* const* /*bases*/, hyteg_hip_stream_t ) { return false; }
+   // where the reduce kernel finds the received segments (concatenated per peer) of the exchange that exchangeEnd has just
+   // completed; valid until the next exchangeBegin of the plan
+   virtual double* recvBase( const ExchangePlan& plan, int /*level*/, int /*key*/ ) { return plan.recvBuffer; }
+   // raises if a device-side wait of this transport has timed out since the last call (synchronises the stream)
+   virtual void check( hyteg_hip_stream_t ) {}
 };
 
 // callbacks set by the embedding application (hyteg_amd/host.py: torch.distributed over gloo for the CPU tests); a
@@ -178,6 +187,233 @@ class RcclTransport : public Transport
    hyteg_hip_stream_t                           commStream_ = nullptr;
    double*                                      scalars_    = nullptr;
    std::map< std::pair< int, int >, Events >    events_;
+};
+
+// Peer to peer over xGMI without a library call per exchange (C-ABI hyteg_hip_p2p_*, comm_p2p.hip): the pack kernel stores
+// into receive slots inside the peers' IPC-mapped arenas and publishes a sequence number, a one-wave kernel in front of the
+// reduce kernel waits for the peers' numbers.  Set-up (once, through whatever channel the application has -- DistributedContext
+// uses torch.distributed): exchange of the arena handles, then per plan every rank lays out the receive side in its own
+// arena (layoutPlan) and learns where its peers expect its values (connectPlan).  Plans that were not connected, and the
+// all-reduce of dot products, go through the transport this one wraps (RCCL in production, hooks in the gloo tests).
+class P2PTransport : public Transport
+{
+ public:
+   static constexpr int    kFlagStride = 8;   // flag words of a plan are 64 bytes apart
+   static constexpr size_t kAlign      = 256; // of every piece of the arena
+
+   P2PTransport( int nranks, int rank, size_t arenaBytes, std::shared_ptr< Transport > inner )
+   : nranks_( nranks )
+   , rank_( rank )
+   , arenaBytes_( arenaBytes )
+   , inner_( std::move( inner ) )
+   , mapped_( (size_t) nranks, nullptr )
+   {
+      if ( !inner_ )
+         throw std::runtime_error( "P2PTransport: needs an inner transport (set-up of unconnected plans, all-reduce)" );
+      handle_.resize( HYTEG_HIP_P2P_HANDLE_BYTES );
+      hipCheck( hyteg_hip_p2p_arena_create( arenaBytes, &arena_, handle_.data(), &arenaKind_ ), "P2PTransport: arena" );
+      void* p = nullptr;
+      hipCheck( hyteg_hip_malloc( &p, sizeof( unsigned ) ), "P2PTransport: malloc" );
+      dStatus_ = static_cast< unsigned* >( p );
+      const unsigned zero = 0;
+      hipCheck( hyteg_hip_upload( dStatus_, &zero, sizeof( zero ), nullptr ), "P2PTransport: upload" );
+      hipCheck( hyteg_hip_stream_synchronize( nullptr ), "P2PTransport: sync" );
+      if ( const char* e = std::getenv( "HYTEG_HIP_P2P_TIMEOUT_MS" ) )
+         timeoutMs_ = (unsigned) std::atoi( e );
+   }
+   ~P2PTransport() override
+   {
+      if ( lastCompute_ )
+         hyteg_hip_stream_synchronize( lastCompute_ );
+      hyteg_hip_stream_synchronize( nullptr );
+      for ( auto& s : plans_ )
+      {
+         hyteg_hip_free( s.second.dPeers );
+         hyteg_hip_free( s.second.dCounter );
+      }
+      for ( void* m : mapped_ )
+         hyteg_hip_p2p_arena_close( m );
+      hyteg_hip_free( dStatus_ );
+      hyteg_hip_p2p_arena_destroy( arena_ );
+   }
+   const std::vector< unsigned char >& handle() const { return handle_; }
+   int                                 arenaKind() const { return arenaKind_; }
+   Transport&                          inner() const { return *inner_; }
+   std::shared_ptr< Transport >        innerShared() const { return inner_; }
+
+   // handles: nranks * HYTEG_HIP_P2P_HANDLE_BYTES bytes, rank by rank (the own entry is ignored)
+   void openPeers( const unsigned char* handles )
+   {
+      for ( int r = 0; r < nranks_; ++r )
+         if ( r != rank_ && !mapped_[(size_t) r] )
+            hipCheck( hyteg_hip_p2p_arena_open( handles + (size_t) r * HYTEG_HIP_P2P_HANDLE_BYTES, &mapped_[(size_t) r] ),
+                      "P2PTransport: open the arena of a peer" );
+      opened_ = true;
+   }
+   // Receive side of a plan inside this rank's arena.  Returns, per peer of the plan, the byte offsets { slot 0, slot 1,
+   // flag word } of that peer's segment: the application delivers triple k to rank plan.peers[k].
+   std::vector< long long > layoutPlan( const ExchangePlan& plan, int level, int key )
+   {
+      PlanState& S = plans_[{ level, key }];
+      if ( !S.laidOut )
+      {
+         const size_t bytes = (size_t) plan.totalRecv() * sizeof( double );
+         S.recvOff[0]       = take( bytes );
+         S.recvOff[1]       = take( bytes );
+         S.flagOff          = take( plan.peers.size() * kFlagStride * sizeof( unsigned long long ) );
+         S.laidOut          = true;
+      }
+      std::vector< long long > out;
+      size_t                   seg = 0;
+      for ( size_t k = 0; k < plan.peers.size(); ++k )
+      {
+         out.push_back( (long long) ( S.recvOff[0] + seg ) );
+         out.push_back( (long long) ( S.recvOff[1] + seg ) );
+         out.push_back( (long long) ( S.flagOff + k * kFlagStride * sizeof( unsigned long long ) ) );
+         seg += (size_t) plan.recvCount[k] * sizeof( double );
+      }
+      return out;
+   }
+   // offsets: per peer of the plan the triple that peer's layoutPlan returned for THIS rank (offsets into its arena)
+   void connectPlan( const ExchangePlan& plan, int level, int key, const long long* offsets )
+   {
+      if ( !opened_ )
+         throw std::runtime_error( "P2PTransport::connectPlan: openPeers has not been called" );
+      PlanState& S = plans_[{ level, key }];
+      if ( !S.laidOut )
+         throw std::runtime_error( "P2PTransport::connectPlan: layoutPlan comes first" );
+      std::vector< hyteg_hip_p2p_peer_t > peers( plan.peers.size() );
+      int                                 start = 0;
+      for ( size_t k = 0; k < plan.peers.size(); ++k )
+      {
+         const int q = plan.peers[k];
+         if ( q < 0 || q >= nranks_ || q == rank_ || !mapped_[(size_t) q] )
+            throw std::runtime_error( "P2PTransport::connectPlan: peer rank " + std::to_string( q ) + " has no mapped arena" );
+         char* base = static_cast< char* >( mapped_[(size_t) q] );
+         for ( int s = 0; s < 3; ++s )
+            if ( offsets[3 * k + s] < 0 || (size_t) offsets[3 * k + s] + ( s < 2 ? (size_t) plan.sendCount[k] * sizeof( double ) : 8 ) > arenaBytes_ )
+               throw std::runtime_error( "P2PTransport::connectPlan: offset outside the peer's arena" );
+         peers[k].slot[0] = reinterpret_cast< double* >( base + offsets[3 * k + 0] );
+         peers[k].slot[1] = reinterpret_cast< double* >( base + offsets[3 * k + 1] );
+         peers[k].flag    = reinterpret_cast< unsigned long long* >( base + offsets[3 * k + 2] );
+         peers[k].start   = start;
+         peers[k].count   = plan.sendCount[k];
+         start += plan.sendCount[k];
+      }
+      if ( !peers.empty() )
+      {
+         void* d = nullptr;
+         hipCheck( hyteg_hip_malloc( &d, peers.size() * sizeof( hyteg_hip_p2p_peer_t ) ), "P2PTransport: malloc" );
+         hipCheck( hyteg_hip_upload( d, peers.data(), peers.size() * sizeof( hyteg_hip_p2p_peer_t ), nullptr ), "P2PTransport: upload" );
+         S.dPeers = static_cast< hyteg_hip_p2p_peer_t* >( d );
+         hipCheck( hyteg_hip_malloc( &d, sizeof( unsigned ) ), "P2PTransport: malloc" );
+         const unsigned zero = 0;
+         hipCheck( hyteg_hip_upload( d, &zero, sizeof( zero ), nullptr ), "P2PTransport: upload" );
+         S.dCounter = static_cast< unsigned* >( d );
+         hipCheck( hyteg_hip_stream_synchronize( nullptr ), "P2PTransport: sync" );
+      }
+      S.connected = true;
+   }
+   bool connected( int level, int key ) const
+   {
+      auto it = plans_.find( { level, key } );
+      return it != plans_.end() && it->second.connected;
+   }
+
+   bool pack( const ExchangePlan& plan, int level, int key, double* const* bases, hyteg_hip_stream_t compute ) override
+   {
+      PlanState* S = find( level, key );
+      if ( !S )
+         return inner_->pack( plan, level, key, bases, compute );
+      if ( S->inFlight )
+         throw std::runtime_error( "P2PTransport: second exchange of a plan begun before the first one has ended" );
+      S->inFlight  = true;
+      lastCompute_ = compute;
+      ++S->seq;
+      hipCheck( hyteg_hip_p2p_pack( S->dPeers, (int) plan.peers.size(), bases, plan.dSendBuf, plan.dSendOff, plan.totalSend(), S->seq,
+                                    S->dCounter, compute ),
+                "P2PTransport: pack" );
+      return true;
+   }
+   void exchangeBegin( const ExchangePlan& plan, int level, int key, hyteg_hip_stream_t compute ) override
+   {
+      if ( !find( level, key ) )
+         inner_->exchangeBegin( plan, level, key, compute );
+   }
+   void exchangeEnd( const ExchangePlan& plan, int level, int key, hyteg_hip_stream_t compute ) override
+   {
+      PlanState* S = find( level, key );
+      if ( !S )
+         return inner_->exchangeEnd( plan, level, key, compute );
+      if ( plan.peers.empty() )
+         return;
+      if ( !S->inFlight )
+         throw std::runtime_error( "P2PTransport: exchangeEnd without exchangeBegin" );
+      S->inFlight = false;
+      hipCheck( hyteg_hip_p2p_wait( reinterpret_cast< const unsigned long long* >( static_cast< char* >( arena_ ) + S->flagOff ),
+                                    (int) plan.peers.size(), kFlagStride, S->seq, dStatus_, timeoutMs_, compute ),
+                "P2PTransport: wait" );
+   }
+   double* recvBase( const ExchangePlan& plan, int level, int key ) override
+   {
+      PlanState* S = find( level, key );
+      if ( !S )
+         return inner_->recvBase( plan, level, key );
+      return reinterpret_cast< double* >( static_cast< char* >( arena_ ) + S->recvOff[S->seq & 1ull] );
+   }
+   void check( hyteg_hip_stream_t compute ) override
+   {
+      unsigned st = 0;
+      hipCheck( hyteg_hip_download( &st, dStatus_, sizeof( st ), compute ), "P2PTransport: download" );
+      hipCheck( hyteg_hip_stream_synchronize( compute ), "P2PTransport: sync" );
+      if ( st )
+      {
+         const unsigned zero = 0;
+         hipCheck( hyteg_hip_upload( dStatus_, &zero, sizeof( zero ), compute ), "P2PTransport: upload" );
+         hipCheck( hyteg_hip_stream_synchronize( compute ), "P2PTransport: sync" );
+         throw std::runtime_error( "P2PTransport: a wait for the values of peer slot " + std::to_string( st - 1 ) +
+                                   " timed out -- the results since the last check are not valid" );
+      }
+      inner_->check( compute );
+   }
+   void        allreduceSum( double* values, int n ) override { inner_->allreduceSum( values, n ); }
+   bool        collective() const override { return inner_->collective(); }
+   const char* name() const override { return "p2p"; }
+
+ private:
+   struct PlanState
+   {
+      bool                  laidOut = false, connected = false, inFlight = false;
+      size_t                recvOff[2] = { 0, 0 }, flagOff = 0;
+      hyteg_hip_p2p_peer_t* dPeers   = nullptr;
+      unsigned*             dCounter = nullptr;
+      unsigned long long    seq      = 0;
+   };
+   PlanState* find( int level, int key )
+   {
+      auto it = plans_.find( { level, key } );
+      return it != plans_.end() && it->second.connected ? &it->second : nullptr;
+   }
+   size_t take( size_t bytes )
+   {
+      const size_t off = used_;
+      used_ += ( std::max< size_t >( bytes, 1 ) + kAlign - 1 ) / kAlign * kAlign;
+      if ( used_ > arenaBytes_ )
+         throw std::runtime_error( "P2PTransport: arena of " + std::to_string( arenaBytes_ ) + " bytes is too small" );
+      return off;
+   }
+   int                                          nranks_, rank_;
+   size_t                                       arenaBytes_, used_ = 0;
+   std::shared_ptr< Transport >                 inner_;
+   std::vector< void* >                         mapped_;
+   std::vector< unsigned char >                 handle_;
+   void*                                        arena_     = nullptr;
+   int                                          arenaKind_ = 0;
+   bool                                         opened_    = false;
+   unsigned*                                    dStatus_   = nullptr;
+   unsigned                                     timeoutMs_ = 0;
+   hyteg_hip_stream_t                           lastCompute_ = nullptr;
+   std::map< std::pair< int, int >, PlanState > plans_;
 };
 
 } // namespace hyteg

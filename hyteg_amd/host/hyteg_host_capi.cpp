@@ -149,6 +149,52 @@ HYTEG_HOST_API int hyteg_host_storage_use_rccl( hh_storage_t s, const unsigned c
       S( s ).useRccl( unique_id );
    } );
 }
+HYTEG_HOST_API int hyteg_host_storage_use_p2p( hh_storage_t s, size_t arena_bytes, unsigned char* handle, int* arena_kind )
+{
+   return guarded( [&] {
+      if ( !handle )
+         throw std::runtime_error( "storage_use_p2p: null handle buffer" );
+      P2PTransport& T = S( s ).useP2P( arena_bytes );
+      std::copy( T.handle().begin(), T.handle().end(), handle );
+      if ( arena_kind )
+         *arena_kind = T.arenaKind();
+   } );
+}
+HYTEG_HOST_API int hyteg_host_storage_p2p_open( hh_storage_t s, const unsigned char* handles )
+{
+   return guarded( [&] {
+      if ( !handles )
+         throw std::runtime_error( "storage_p2p_open: null handles" );
+      S( s ).p2p().openPeers( handles );
+   } );
+}
+HYTEG_HOST_API int hyteg_host_storage_p2p_layout( hh_storage_t s, int level, int key, long long* offsets )
+{
+   return guarded( [&] {
+      const auto& plan = S( s ).devicePlan( level, key & 1, key >> 1 );
+      const auto  o    = S( s ).p2p().layoutPlan( plan, level, key );
+      if ( !o.empty() && !offsets )
+         throw std::runtime_error( "storage_p2p_layout: null offsets" );
+      std::copy( o.begin(), o.end(), offsets );
+   } );
+}
+HYTEG_HOST_API int hyteg_host_storage_p2p_connect( hh_storage_t s, int level, int key, const long long* offsets )
+{
+   return guarded( [&] {
+      const auto& plan = S( s ).devicePlan( level, key & 1, key >> 1 );
+      if ( !plan.peers.empty() && !offsets )
+         throw std::runtime_error( "storage_p2p_connect: null offsets" );
+      S( s ).p2p().connectPlan( plan, level, key, offsets );
+   } );
+}
+HYTEG_HOST_API int hyteg_host_storage_drop_p2p( hh_storage_t s )
+{
+   return guarded( [&] { S( s ).dropP2P(); } );
+}
+HYTEG_HOST_API int hyteg_host_storage_check_transport( hh_storage_t s )
+{
+   return guarded( [&] { S( s ).checkTransport(); } );
+}
 HYTEG_HOST_API int hyteg_host_storage_allreduce_sum( hh_storage_t s, double* values, int n )
 {
    return guarded( [&] {

@@ -279,6 +279,35 @@ class PrimitiveStorage
    // RCCL over xGMI issued from this layer; uniqueId: HYTEG_HIP_COMM_ID_BYTES bytes created by rank 0
    // (hyteg_hip_comm_unique_id) and distributed by the application.  Collective over all ranks.
    void       useRccl( const unsigned char* uniqueId ) { transport_ = std::make_shared< RcclTransport >( nranks_, rank_, uniqueId ); }
+   // Peer-to-peer transport on top of the current one (which keeps the all-reduce and every plan that is not connected):
+   // see P2PTransport in comm.hpp for the set-up sequence.
+   P2PTransport& useP2P( size_t arenaBytes )
+   {
+      auto p     = std::make_shared< P2PTransport >( nranks_, rank_, arenaBytes, transport_ );
+      transport_ = p;
+      return *p;
+   }
+   P2PTransport& p2p() const
+   {
+      auto* p = dynamic_cast< P2PTransport* >( transport_.get() );
+      if ( !p )
+         throw std::runtime_error( "PrimitiveStorage: the transport is not the peer-to-peer one" );
+      return *p;
+   }
+   // back to the transport the peer-to-peer one wraps (used when its self-check fails on some rank)
+   void dropP2P()
+   {
+      if ( auto* p = dynamic_cast< P2PTransport* >( transport_.get() ) )
+      {
+         std::shared_ptr< Transport > inner = p->innerShared();
+         transport_                         = inner;
+      }
+   }
+   void       checkTransport() const
+   {
+      if ( transport_ )
+         transport_->check( stream_ );
+   }
    Transport* transport() const { return transport_.get(); }
    Transport& requireTransport( const char* what ) const
    {
@@ -311,10 +340,15 @@ class PrimitiveStorage
          if ( host.peers.empty() && !T.collective() )
             continue;
          const ExchangePlan& plan = devicePlan( level, cls, dofKind );
+         const int key = cls + 2 * dofKind;
          if ( !plan.peers.empty() )
-            hipCheck( hyteg_hip_gather_entries( plan.sendBuffer, basesTable( arrays, plan ), plan.dSendBuf, plan.dSendOff, plan.totalSend(), stream_ ),
-                      "exchange: pack" );
-         T.exchangeBegin( plan, level, cls + 2 * dofKind, stream_ );
+         {
+            double** bases = basesTable( arrays, plan, plan.recvBuffer );
+            if ( !T.pack( plan, level, key, bases, stream_ ) )
+               hipCheck( hyteg_hip_gather_entries( plan.sendBuffer, bases, plan.dSendBuf, plan.dSendOff, plan.totalSend(), stream_ ),
+                         "exchange: pack" );
+         }
+         T.exchangeBegin( plan, level, key, stream_ );
       }
    }
    void sharedExchangeEnd( const std::vector< double* >& arrays, int level, DoFType flag, int dofKind, bool additive ) const
@@ -324,12 +358,13 @@ class PrimitiveStorage
          if ( !testFlag( boundaryTypeOf( cls == 1 ), flag ) )
             continue;
          const ExchangePlan& host = exchangePlan( level, cls, dofKind );
+         const int           key  = cls + 2 * dofKind;
          if ( nranks_ > 1 && ( !host.peers.empty() || requireTransport( "exchange" ).collective() ) )
-            transport_->exchangeEnd( devicePlan( level, cls, dofKind ), level, cls + 2 * dofKind, stream_ );
+            transport_->exchangeEnd( devicePlan( level, cls, dofKind ), level, key, stream_ );
          if ( host.ngroups() == 0 )
             continue;
          const ExchangePlan& plan  = devicePlan( level, cls, dofKind );
-         double**            bases = basesTable( arrays, plan );
+         double**            bases = basesTable( arrays, plan, nranks_ > 1 && !plan.peers.empty() ? transport_->recvBase( plan, level, key ) : plan.recvBuffer );
          hipCheck( additive ? hyteg_hip_sum_shared( bases, plan.dGroupPtr, plan.dEntryBuf, plan.dEntryOff, plan.ngroups(),
                                                     (int) arrays.size(), stream_ )
                             : hyteg_hip_copy_shared( bases, plan.dGroupPtr, plan.dEntryBuf, plan.dEntryOff, plan.ngroups(),
@@ -338,10 +373,10 @@ class PrimitiveStorage
       }
    }
    // device table [ local cell arrays ..., receive segment of peer 0, peer 1, ... ] (cached by content)
-   double** basesTable( const std::vector< double* >& arrays, const ExchangePlan& plan ) const
+   double** basesTable( const std::vector< double* >& arrays, const ExchangePlan& plan, double* recvBase ) const
    {
       std::vector< double* > host( arrays );
-      double*                seg = plan.recvBuffer;
+      double*                seg = recvBase;
       for ( uint_t s = 0; s < plan.peers.size(); ++s )
       {
          host.push_back( seg );

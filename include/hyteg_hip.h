@@ -748,6 +748,48 @@ HYTEG_HIP_API int hyteg_hip_comm_exchange( hyteg_hip_comm_t   comm,
 /* in-place sum over all ranks of n doubles in device memory; stream-ordered */
 HYTEG_HIP_API int hyteg_hip_comm_allreduce_sum( hyteg_hip_comm_t comm, double* values, int n, hyteg_hip_stream_t stream );
 
+/* ---- the same exchange peer to peer: stores into IPC-mapped arenas of the neighbour GPUs (comm_p2p.hip) -----------
+ * Same reference semantics as hyteg_hip_comm_exchange (BufferedCommunication.cpp:181-470), no library call per exchange:
+ * every rank creates one arena (uncached device memory), hands its HYTEG_HIP_P2P_HANDLE_BYTES handle to the other ranks
+ * of the node (any channel; the handle is a plain byte string) and maps theirs.  Inside its arena a rank lays out, per
+ * exchange plan and peer, two receive slots (used alternately, by sequence parity) and one 8-byte flag word; it tells
+ * each peer where they are, and the peer describes them, as pointers into ITS mapping of that arena, in a
+ * hyteg_hip_p2p_peer_t.  hyteg_hip_p2p_pack gathers n values like hyteg_hip_gather_entries and stores value k into slot
+ * [seq & 1] of the peer whose segment [start, start + count) holds k, then writes seq to every peer's flag word;
+ * hyteg_hip_p2p_wait enqueues a kernel that returns once the npeers flag words at flags[p * stride] (this rank's own
+ * arena) have reached seq, or sets *status to 1 + p after timeout_ms (0: 20 s) -- it never spins unbounded.
+ * Sequence numbers start at 1 and grow by one per exchange of a plan on both sides. */
+#define HYTEG_HIP_P2P_HANDLE_BYTES 64 /* sizeof( hipIpcMemHandle_t ) */
+typedef struct
+{
+   double*             slot[2]; /* receive slots of this rank's segment in the peer's arena (mapped here) */
+   unsigned long long* flag;    /* this rank's flag word in the peer's arena (mapped here) */
+   int                 start;   /* first index of the peer's segment in the send enumeration */
+   int                 count;
+} hyteg_hip_p2p_peer_t;
+/* kind (optional) receives 0 uncached / 1 fine-grained / 2 default memory (env HYTEG_HIP_P2P_ARENA; default uncached) */
+HYTEG_HIP_API int hyteg_hip_p2p_arena_create( size_t bytes, void** base, unsigned char* handle, int* kind );
+HYTEG_HIP_API int hyteg_hip_p2p_arena_destroy( void* base );
+HYTEG_HIP_API int hyteg_hip_p2p_arena_open( const unsigned char* handle, void** mapped );
+HYTEG_HIP_API int hyteg_hip_p2p_arena_close( void* mapped );
+/* peers: device array of npeers descriptors; counter: device word, zero before the first call, owned by the plan */
+HYTEG_HIP_API int hyteg_hip_p2p_pack( const hyteg_hip_p2p_peer_t* peers,
+                                      int                         npeers,
+                                      double* const*              bases,
+                                      const int*                  entry_buf,
+                                      const int*                  entry_off,
+                                      int                         n,
+                                      unsigned long long          seq,
+                                      unsigned*                   counter,
+                                      hyteg_hip_stream_t          stream );
+HYTEG_HIP_API int hyteg_hip_p2p_wait( const unsigned long long* flags,
+                                      int                       npeers,
+                                      int                       stride,
+                                      unsigned long long        seq,
+                                      unsigned*                 status,
+                                      unsigned                  timeout_ms,
+                                      hyteg_hip_stream_t        stream );
+
 #ifdef __cplusplus
 }
 #endif

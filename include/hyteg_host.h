@@ -68,6 +68,19 @@ HYTEG_HOST_API int hyteg_host_storage_timing_reset( hh_storage_t s );
  *     the calling operation fail (the host layer never reduces a receive buffer whose transfer failed). */
 HYTEG_HOST_API int hyteg_host_storage_use_rccl( hh_storage_t s, const unsigned char* unique_id );
 HYTEG_HOST_API int hyteg_host_storage_transport_name( hh_storage_t s, char* buf, int buflen );
+/* (c) peer to peer on top of (a) or (b) (which keep the all-reduce and every plan that is not connected): the pack kernel
+ *     stores into receive slots inside the peers' IPC-mapped arenas, a one-wave kernel waits for their sequence numbers
+ *     (include/hyteg_hip.h, hyteg_hip_p2p_*) -- no library call per exchange.  Set-up, collective, any channel for the bytes:
+ *       use_p2p( arena_bytes ) -> this rank's HYTEG_HIP_P2P_HANDLE_BYTES handle;  p2p_open( handles of all ranks, rank by rank );
+ *       per plan: p2p_layout -> 3 byte offsets { slot 0, slot 1, flag } per peer of the plan, deliver triple k to rank
+ *       peers[k];  p2p_connect( the triples the peers laid out for this rank, in the order of peers[] ).
+ *     check_transport synchronises and fails if a device-side wait has timed out; drop_p2p returns to the wrapped transport. */
+HYTEG_HOST_API int hyteg_host_storage_use_p2p( hh_storage_t s, size_t arena_bytes, unsigned char* handle, int* arena_kind );
+HYTEG_HOST_API int hyteg_host_storage_p2p_open( hh_storage_t s, const unsigned char* handles );
+HYTEG_HOST_API int hyteg_host_storage_p2p_layout( hh_storage_t s, int level, int key, long long* offsets );
+HYTEG_HOST_API int hyteg_host_storage_p2p_connect( hh_storage_t s, int level, int key, const long long* offsets );
+HYTEG_HOST_API int hyteg_host_storage_drop_p2p( hh_storage_t s );
+HYTEG_HOST_API int hyteg_host_storage_check_transport( hh_storage_t s );
 /* in-place sum over all ranks of n doubles in host memory through the storage's transport (no-op on one rank):
  * walberla::mpi::allReduceInplace( ..., SUM ) of the reference's norms and dot products */
 HYTEG_HOST_API int hyteg_host_storage_allreduce_sum( hh_storage_t s, double* values, int n );

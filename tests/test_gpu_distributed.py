@@ -55,7 +55,7 @@ def _run(host, storage, level, ctx=None):
     return applied, dot, cycled, swept
 
 
-def _worker(rank, world, port, level, q):
+def _worker(rank, world, port, level, q, transport="auto"):
     sys.path.insert(0, str(ROOT))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
@@ -69,14 +69,26 @@ def _worker(rank, world, port, level, q):
     try:
         st = host.Storage.from_gmsh(MESH, rank, world)
         st.set_stream(torch.cuda.current_stream().cuda_stream)
-        ctx = DistributedContext(st, [2, 3, level] if level > 3 else [2, 3], torch.device("cuda", 0))
-        q.put((rank,) + _run(host, st, level, ctx))
+        ctx = DistributedContext(st, [2, 3, level] if level > 3 else [2, 3], torch.device("cuda", 0), transport=transport)
+        if transport == "p2p":
+            # no silent fallback in a test: the peer-to-peer set-up (IPC handles between the two processes) must have worked
+            assert ctx.transport == "p2p" and st.transport == "p2p", ctx.transport_note
+        out = _run(host, st, level, ctx)
+        st.check_transport()  # no device-side wait has timed out
+        q.put((rank,) + out)
         dist.barrier()
+    except BaseException as e:  # the parent fails at once instead of waiting for the queue
+        q.put(("error", rank, repr(e)))
+        raise
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_reproduce_the_single_rank_results():
+@pytest.mark.parametrize("world,transport", [(2, "auto"), (2, "p2p"), (4, "p2p")])
+def test_ranks_on_one_gpu_reproduce_the_single_rank_results(world, transport):
+    """transport "auto": gloo hooks staged through host memory.  "p2p": the pack kernels store into the other processes'
+    IPC-mapped arenas and wait kernels poll sequence numbers (comm_p2p.hip) -- no host synchronisation between the ranks'
+    kernels, so this also exercises the slot / sequence protocol under real asynchrony (dots still go through gloo)."""
     import torch
     import torch.multiprocessing as mp
 
@@ -84,7 +96,7 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_rank_results():
     from hyteg_amd import host
 
     assert torch.cuda.is_available()
-    level, world = 3, 2
+    level = 3
     st = host.Storage.from_gmsh(MESH)
     st.set_stream(torch.cuda.current_stream().cuda_stream)
     ref_applied, ref_dot, ref_cycled, ref_swept = _run(host, st, level)
@@ -92,10 +104,13 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_rank_results():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, level, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, level, q, transport)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=240) for _ in range(world)]
+    results = []
+    for _ in range(world):
+        results.append(q.get(timeout=240))
+        assert results[-1][0] != "error", results[-1]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
