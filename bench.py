@@ -162,6 +162,9 @@ def main():
     # one level-`level` macro-cell per GPU: meshes of 1, 2, 4, 8 tetrahedra from the reference's test data; the cells of
     # a rank-r process are those with (cell id % world) == r (HyTeG's round-robin default)
     mesh = ROOT / "hyteg_amd" / "data" / "meshes" / f"{MESH_FOR_WORLD[world]}.msh"
+    if world == 1 and os.environ.get("HYTEG_BENCH_MESH"):
+        # development only: several macro-cells on ONE rank (boundary shares and the local reduce without any exchange)
+        mesh = ROOT / "hyteg_amd" / "data" / "meshes" / f"{os.environ['HYTEG_BENCH_MESH']}.msh"
     storage = host.Storage.from_gmsh(mesh, rank, world)
     stream = torch.cuda.current_stream()
     storage.set_stream(stream.cuda_stream)

@@ -278,14 +278,49 @@ __global__ __launch_bounds__( kThreads ) void sum_partials_kernel( const double*
    }
 }
 
-template < bool SUM >
+// what a reduce kernel waits for when the values of other ranks arrive peer to peer (comm_p2p.hip): the flag words of this
+// rank's arena must have reached seq
+struct ArrivalWait
+{
+   const unsigned long long* flags;
+   int                       npeers, stride;
+   unsigned long long        seq;
+   unsigned*                 status;
+   unsigned long long        timeout_ticks;
+};
+
+template < bool SUM, bool WAIT = false >
 __global__ __launch_bounds__( kThreads ) void sum_shared_kernel( double* const* __restrict__ bases,
                                                                   const int* __restrict__ group_ptr,
                                                                   const int* __restrict__ entry_buf,
                                                                   const int* __restrict__ entry_off,
                                                                   int ngroups,
-                                                                  int n_writable )
+                                                                  int n_writable,
+                                                                  ArrivalWait W = ArrivalWait{} )
 {
+   if constexpr ( WAIT )
+   {
+      // every workgroup polls for itself (first wave, lane p takes peer p, p + 64, ...); bounded like hyteg_hip_p2p_wait
+      if ( threadIdx.x < 64 )
+      {
+         const unsigned long long t0 = wall_clock64();
+         for ( int p = threadIdx.x; p < W.npeers; p += 64 )
+         {
+            const unsigned long long* f = W.flags + (size_t) p * W.stride;
+            while ( __hip_atomic_load( f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM ) < W.seq )
+            {
+               if ( wall_clock64() - t0 > W.timeout_ticks )
+               {
+                  __hip_atomic_store( W.status, 1u + (unsigned) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+                  break;
+               }
+               __builtin_amdgcn_s_sleep( 8 );
+            }
+         }
+         __builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "" );
+      }
+      __syncthreads();
+   }
    const int g = blockIdx.x * kThreads + threadIdx.x;
    if ( g >= ngroups )
       return;
@@ -609,8 +644,8 @@ HYTEG_HIP_API int hyteg_hip_sum_shared( double* const*     bases,
    if ( ngroups <= 0 )
       return HYTEG_HIP_OK;
    HH_REQUIRE( bases && group_ptr && entry_buf && entry_off, "sum_shared: null pointer" );
-   hipLaunchKernelGGL( sum_shared_kernel< true >, dim3( ( ngroups + kThreads - 1 ) / kThreads ), dim3( kThreads ), 0,
-                       as_stream( stream ), bases, group_ptr, entry_buf, entry_off, ngroups, n_writable );
+   hipLaunchKernelGGL( ( sum_shared_kernel< true, false > ), dim3( ( ngroups + kThreads - 1 ) / kThreads ), dim3( kThreads ), 0,
+                       as_stream( stream ), bases, group_ptr, entry_buf, entry_off, ngroups, n_writable, ArrivalWait{} );
    HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;
 }
@@ -626,8 +661,39 @@ HYTEG_HIP_API int hyteg_hip_copy_shared( double* const*     bases,
    if ( ngroups <= 0 )
       return HYTEG_HIP_OK;
    HH_REQUIRE( bases && group_ptr && entry_buf && entry_off, "copy_shared: null pointer" );
-   hipLaunchKernelGGL( sum_shared_kernel< false >, dim3( ( ngroups + kThreads - 1 ) / kThreads ), dim3( kThreads ), 0,
-                       as_stream( stream ), bases, group_ptr, entry_buf, entry_off, ngroups, n_writable );
+   hipLaunchKernelGGL( ( sum_shared_kernel< false, false > ), dim3( ( ngroups + kThreads - 1 ) / kThreads ), dim3( kThreads ), 0,
+                       as_stream( stream ), bases, group_ptr, entry_buf, entry_off, ngroups, n_writable, ArrivalWait{} );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_reduce_shared_after_p2p( double* const*            bases,
+                                                     const int*                group_ptr,
+                                                     const int*                entry_buf,
+                                                     const int*                entry_off,
+                                                     int                       ngroups,
+                                                     int                       n_writable,
+                                                     int                       additive,
+                                                     const unsigned long long* flags,
+                                                     int                       npeers,
+                                                     int                       stride,
+                                                     unsigned long long        seq,
+                                                     unsigned*                 status,
+                                                     unsigned                  timeout_ms,
+                                                     hyteg_hip_stream_t        stream )
+{
+   if ( ngroups <= 0 )
+      return HYTEG_HIP_OK;
+   HH_REQUIRE( bases && group_ptr && entry_buf && entry_off, "reduce_shared_after_p2p: null pointer" );
+   HH_REQUIRE( npeers >= 0 && ( npeers == 0 || ( flags && status && stride >= 1 ) ), "reduce_shared_after_p2p: bad wait arguments" );
+   const ArrivalWait W{ flags, npeers, stride, seq, status, (unsigned long long) ( timeout_ms ? timeout_ms : 20000u ) * 100000ull };
+   const dim3        grid( ( ngroups + kThreads - 1 ) / kThreads ), block( kThreads );
+   if ( additive )
+      hipLaunchKernelGGL( ( sum_shared_kernel< true, true > ), grid, block, 0, as_stream( stream ), bases, group_ptr, entry_buf, entry_off,
+                          ngroups, n_writable, W );
+   else
+      hipLaunchKernelGGL( ( sum_shared_kernel< false, true > ), grid, block, 0, as_stream( stream ), bases, group_ptr, entry_buf, entry_off,
+                          ngroups, n_writable, W );
    HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;
 }

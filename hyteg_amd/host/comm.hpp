@@ -34,6 +34,16 @@ struct ExchangePlan
    }
 };
 
+// what the reduce kernel of an exchange has to wait for itself (hyteg_hip_reduce_shared_after_p2p)
+struct ArrivalWait
+{
+   const unsigned long long* flags = nullptr;
+   int                       npeers = 0, stride = 0;
+   unsigned long long        seq    = 0;
+   unsigned*                 status = nullptr;
+   unsigned                  timeoutMs = 0;
+};
+
 // Moves plan.sendBuffer (segments per peer) into the peers' plan.recvBuffer.  `key` = cls + 2 * dofKind identifies the
 // plan of a level (boundary class 0 / 1; vertex-DoF / edge-DoF arrays).
 class Transport
@@ -58,6 +68,11 @@ class Transport
    // where the reduce kernel finds the received segments (concatenated per peer) of the exchange that exchangeEnd has just
    // completed; valid until the next exchangeBegin of the plan
    virtual double* recvBase( const ExchangePlan& plan, int /*level*/, int /*key*/ ) { return plan.recvBuffer; }
+   // true: exchangeEnd has NOT made the compute stream wait for the arrival; the reduce kernel does it itself with `w`
+   virtual bool arrivalWait( const ExchangePlan&, int /*level*/, int /*key*/, ArrivalWait& /*w*/ ) { return false; }
+   // true: the exchange of this plan is ordered against whatever stream `compute` is at each call (not against a stream
+   // fixed at set-up), so the caller may run it on a side stream next to other kernels
+   virtual bool anyStream( int /*level*/, int /*key*/ ) const { return false; }
    // raises if a device-side wait of this transport has timed out since the last call (synchronises the stream)
    virtual void check( hyteg_hip_stream_t ) {}
 };
@@ -163,6 +178,7 @@ class RcclTransport : public Transport
       hipCheck( hyteg_hip_stream_synchronize( commStream_ ), "RcclTransport: sync" );
    }
    bool        collective() const override { return false; }
+   bool        anyStream( int, int ) const override { return true; }
    const char* name() const override { return "rccl"; }
 
  private:
@@ -220,6 +236,8 @@ class P2PTransport : public Transport
       hipCheck( hyteg_hip_stream_synchronize( nullptr ), "P2PTransport: sync" );
       if ( const char* e = std::getenv( "HYTEG_HIP_P2P_TIMEOUT_MS" ) )
          timeoutMs_ = (unsigned) std::atoi( e );
+      if ( const char* e = std::getenv( "HYTEG_HIP_P2P_FUSED_WAIT" ) ) // 0: a wait kernel of its own in front of the reduce kernel
+         fusedWait_ = std::atoi( e ) != 0;
    }
    ~P2PTransport() override
    {
@@ -350,9 +368,26 @@ class P2PTransport : public Transport
       if ( !S->inFlight )
          throw std::runtime_error( "P2PTransport: exchangeEnd without exchangeBegin" );
       S->inFlight = false;
+      if ( fusedWait_ )
+         return; // the reduce kernel waits (arrivalWait)
       hipCheck( hyteg_hip_p2p_wait( reinterpret_cast< const unsigned long long* >( static_cast< char* >( arena_ ) + S->flagOff ),
                                     (int) plan.peers.size(), kFlagStride, S->seq, dStatus_, timeoutMs_, compute ),
                 "P2PTransport: wait" );
+   }
+   bool arrivalWait( const ExchangePlan& plan, int level, int key, ArrivalWait& w ) override
+   {
+      PlanState* S = find( level, key );
+      if ( !S )
+         return inner_->arrivalWait( plan, level, key, w );
+      if ( !fusedWait_ || plan.peers.empty() )
+         return false;
+      w.flags     = reinterpret_cast< const unsigned long long* >( static_cast< char* >( arena_ ) + S->flagOff );
+      w.npeers    = (int) plan.peers.size();
+      w.stride    = kFlagStride;
+      w.seq       = S->seq;
+      w.status    = dStatus_;
+      w.timeoutMs = timeoutMs_;
+      return true;
    }
    double* recvBase( const ExchangePlan& plan, int level, int key ) override
    {
@@ -378,6 +413,7 @@ class P2PTransport : public Transport
    }
    void        allreduceSum( double* values, int n ) override { inner_->allreduceSum( values, n ); }
    bool        collective() const override { return inner_->collective(); }
+   bool        anyStream( int level, int key ) const override { return connected( level, key ) || inner_->anyStream( level, key ); }
    const char* name() const override { return "p2p"; }
 
  private:
@@ -412,6 +448,7 @@ class P2PTransport : public Transport
    bool                                         opened_    = false;
    unsigned*                                    dStatus_   = nullptr;
    unsigned                                     timeoutMs_ = 0;
+   bool                                         fusedWait_ = true;
    hyteg_hip_stream_t                           lastCompute_ = nullptr;
    std::map< std::pair< int, int >, PlanState > plans_;
 };

@@ -64,7 +64,10 @@ class P1ConstantOperator
          shellDst = tmp.get();
       }
       // 1. this cell's share of the shared macro-face/edge/vertex DoFs (tiny kernels), 2. start the halo exchange,
-      // 3. the interior stencil while the exchange is in flight, 4. reduce the shares
+      // 3. the interior stencil while the exchange is in flight, 4. reduce the shares.  1, 2 and 4 only touch shared points:
+      // with a stream-agnostic transport they can form a chain on a side stream next to 3 (PrimitiveStorage::SideChain;
+      // opt-in, measured slower than one stream).
+      PrimitiveStorage::SideChain chain( *storage_, storage_->sideChainUsable( (int) level, flag, 0 ) );
       forCells( [&]( uint_t c, const MacroCell& cell ) {
          const auto& S = getCellStencils( cell.id, level );
          hipCheck( hyteg_hip_p1_apply_cell_boundary( shellDst->getCellPointer( c, level ), src.getCellPointer( c, level ), (int) level,
@@ -74,6 +77,7 @@ class P1ConstantOperator
                    "apply: boundary" );
       } );
       shellDst->beginSumSharedCopies( level, flag );
+      chain.toMain();
       forCells( [&]( uint_t c, const MacroCell& cell ) {
          const unsigned mask = storage_->maskFor( cell, flag );
          if ( ( mask & HYTEG_HIP_MASK_INNER ) && level >= HYTEG_HIP_MIN_LEVEL )
@@ -82,7 +86,9 @@ class P1ConstantOperator
                                                updateType == Replace ? HYTEG_HIP_REPLACE : HYTEG_HIP_ADD, storage_->stream() ),
                       "apply: cell" );
       } );
+      chain.toSide();
       shellDst->endSumSharedCopies( level, flag );
+      chain.join();
       if ( shellDst != &dst )
       {
          // dst += tmp on the shell points selected by flag

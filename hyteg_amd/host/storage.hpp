@@ -130,6 +130,13 @@ class PrimitiveStorage
          hyteg_hip_free( dotWorkspace_ );
       for ( void* p : scratchAll_ )
          hyteg_hip_free( p );
+      if ( sideStream_ )
+      {
+         hyteg_hip_stream_synchronize( sideStream_ );
+         hyteg_hip_event_destroy( forked_ );
+         hyteg_hip_event_destroy( joined_ );
+         hyteg_hip_stream_destroy( sideStream_ );
+      }
    }
    PrimitiveStorage( const PrimitiveStorage& )            = delete;
    PrimitiveStorage& operator=( const PrimitiveStorage& ) = delete;
@@ -273,6 +280,94 @@ class PrimitiveStorage
    }
    TimingTree* getTimingTree() const { return timingTree_.get(); }
    hyteg_hip_stream_t stream() const { return stream_; }
+
+   // ---- side stream for the shared-point chain of an operator application -------------------------------------------
+   // In apply() the chain boundary shares -> pack -> [exchange] -> reduce touches only shared points of dst and the interior
+   // kernel only interior points.  With a transport that orders the exchange against the stream it is called on (RCCL, peer
+   // to peer) the chain runs on a second stream next to the interior kernel: SideChain forks it off the storage's stream
+   // (event), toMain() / toSide() select where the next launches go, join() makes the storage's stream wait for the chain.
+   // OFF by default (HYTEG_AMD_SIDE_STREAM=1 enables it; =2 also on one rank, to measure): the two cross-stream event
+   // dependencies per apply cost more than the overlap gains -- two level-8 cells on one rank 39.4 -> 49.3 us per apply,
+   // two ranks sharing a GPU 39.7 -> 150-170 us (profiles/r02_p2p_probe.txt).
+   bool sideChainUsable( int level, DoFType flag, int dofKind ) const
+   {
+      if ( sideEnabled_ < 0 )
+      {
+         const char* e = std::getenv( "HYTEG_AMD_SIDE_STREAM" );
+         sideEnabled_  = e ? std::atoi( e ) : 0;
+      }
+      if ( sideEnabled_ == 2 && !mainStream_ ) // measurement aid: also on one rank (local shared points only)
+         return true;
+      if ( nranks_ == 1 || !transport_ )
+         return false;
+      if ( !sideEnabled_ || mainStream_ )
+         return false;
+      bool any = false;
+      for ( int cls = 0; cls < 2; ++cls )
+         if ( testFlag( boundaryTypeOf( cls == 1 ), flag ) && !exchangePlan( level, cls, dofKind ).peers.empty() )
+         {
+            if ( !transport_->anyStream( level, cls + 2 * dofKind ) )
+               return false;
+            any = true;
+         }
+      return any;
+   }
+   class SideChain
+   {
+    public:
+      SideChain( const PrimitiveStorage& st, bool use )
+      : st_( st )
+      , open_( use )
+      {
+         if ( !open_ )
+            return;
+         if ( !st_.sideStream_ )
+         {
+            hipCheck( hyteg_hip_stream_create( &st_.sideStream_ ), "side chain: stream_create" );
+            hipCheck( hyteg_hip_event_create( &st_.forked_ ), "side chain: event_create" );
+            hipCheck( hyteg_hip_event_create( &st_.joined_ ), "side chain: event_create" );
+         }
+         hipCheck( hyteg_hip_event_record( st_.forked_, st_.stream_ ), "side chain: record" );
+         hipCheck( hyteg_hip_stream_wait_event( st_.sideStream_, st_.forked_ ), "side chain: wait" );
+         st_.mainStream_ = st_.stream_;
+         st_.stream_     = st_.sideStream_;
+      }
+      void toMain() const
+      {
+         if ( open_ )
+            st_.stream_ = st_.mainStream_;
+      }
+      void toSide() const
+      {
+         if ( open_ )
+            st_.stream_ = st_.sideStream_;
+      }
+      void join()
+      {
+         if ( !open_ )
+            return;
+         open_                  = false;
+         hyteg_hip_stream_t main = st_.mainStream_;
+         st_.stream_             = main;
+         st_.mainStream_         = nullptr;
+         hipCheck( hyteg_hip_event_record( st_.joined_, st_.sideStream_ ), "side chain: record" );
+         hipCheck( hyteg_hip_stream_wait_event( main, st_.joined_ ), "side chain: wait" );
+      }
+      ~SideChain()
+      {
+         if ( open_ ) // left by an exception: back to the storage's stream, which then waits for whatever the chain holds
+         {
+            st_.stream_     = st_.mainStream_;
+            st_.mainStream_ = nullptr;
+            if ( hyteg_hip_event_record( st_.joined_, st_.sideStream_ ) == HYTEG_HIP_OK )
+               hyteg_hip_stream_wait_event( st_.stream_, st_.joined_ );
+         }
+      }
+
+    private:
+      const PrimitiveStorage& st_;
+      bool                    open_;
+   };
    // ---- transport of the shared-point exchange (storages distributed over several ranks) ----
    void setCommHooks( const CommHooks& h ) { transport_ = std::make_shared< HookTransport >( h ); }
    void setTransport( std::shared_ptr< Transport > t ) { transport_ = std::move( t ); }
@@ -364,12 +459,19 @@ class PrimitiveStorage
          if ( host.ngroups() == 0 )
             continue;
          const ExchangePlan& plan  = devicePlan( level, cls, dofKind );
-         double**            bases = basesTable( arrays, plan, nranks_ > 1 && !plan.peers.empty() ? transport_->recvBase( plan, level, key ) : plan.recvBuffer );
-         hipCheck( additive ? hyteg_hip_sum_shared( bases, plan.dGroupPtr, plan.dEntryBuf, plan.dEntryOff, plan.ngroups(),
-                                                    (int) arrays.size(), stream_ )
-                            : hyteg_hip_copy_shared( bases, plan.dGroupPtr, plan.dEntryBuf, plan.dEntryOff, plan.ngroups(),
-                                                     (int) arrays.size(), stream_ ),
-                   "exchange: reduce" );
+         const bool          remote = nranks_ > 1 && !plan.peers.empty();
+         double**            bases  = basesTable( arrays, plan, remote ? transport_->recvBase( plan, level, key ) : plan.recvBuffer );
+         ArrivalWait         w;
+         if ( remote && transport_->arrivalWait( plan, level, key, w ) )
+            hipCheck( hyteg_hip_reduce_shared_after_p2p( bases, plan.dGroupPtr, plan.dEntryBuf, plan.dEntryOff, plan.ngroups(), (int) arrays.size(),
+                                                         additive ? 1 : 0, w.flags, w.npeers, w.stride, w.seq, w.status, w.timeoutMs, stream_ ),
+                      "exchange: wait + reduce" );
+         else
+            hipCheck( additive ? hyteg_hip_sum_shared( bases, plan.dGroupPtr, plan.dEntryBuf, plan.dEntryOff, plan.ngroups(),
+                                                       (int) arrays.size(), stream_ )
+                               : hyteg_hip_copy_shared( bases, plan.dGroupPtr, plan.dEntryBuf, plan.dEntryOff, plan.ngroups(),
+                                                        (int) arrays.size(), stream_ ),
+                      "exchange: reduce" );
       }
    }
    // device table [ local cell arrays ..., receive segment of peer 0, peer 1, ... ] (cached by content)
@@ -714,7 +816,10 @@ class PrimitiveStorage
    std::vector< MacroPrimitive >                           faces_, edges_, vertices_;
    std::vector< int >                                      localCells_;
    DoFType                                                 boundaryType_ = DirichletBoundary;
-   hyteg_hip_stream_t                                      stream_       = nullptr;
+   mutable hyteg_hip_stream_t                              stream_       = nullptr;
+   mutable hyteg_hip_stream_t                              sideStream_ = nullptr, mainStream_ = nullptr;
+   mutable hyteg_hip_event_t                               forked_ = nullptr, joined_ = nullptr;
+   mutable int                                             sideEnabled_ = -1;
    std::shared_ptr< Transport >                            transport_;
    std::shared_ptr< TimingTree >                           timingTree_;
    mutable void *                                          dotResult_ = nullptr, *dotWorkspace_ = nullptr;

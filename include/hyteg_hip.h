@@ -782,6 +782,22 @@ HYTEG_HIP_API int hyteg_hip_p2p_pack( const hyteg_hip_p2p_peer_t* peers,
                                       unsigned long long          seq,
                                       unsigned*                   counter,
                                       hyteg_hip_stream_t          stream );
+/* hyteg_hip_sum_shared ( additive != 0 ) / hyteg_hip_copy_shared whose workgroups first wait like hyteg_hip_p2p_wait: the
+ * wait kernel and the reduce kernel of an exchange in one launch */
+HYTEG_HIP_API int hyteg_hip_reduce_shared_after_p2p( double* const*            bases,
+                                                     const int*                group_ptr,
+                                                     const int*                entry_buf,
+                                                     const int*                entry_off,
+                                                     int                       ngroups,
+                                                     int                       n_writable,
+                                                     int                       additive,
+                                                     const unsigned long long* flags,
+                                                     int                       npeers,
+                                                     int                       stride,
+                                                     unsigned long long        seq,
+                                                     unsigned*                 status,
+                                                     unsigned                  timeout_ms,
+                                                     hyteg_hip_stream_t        stream );
 HYTEG_HIP_API int hyteg_hip_p2p_wait( const unsigned long long* flags,
                                       int                       npeers,
                                       int                       stride,
