@@ -136,12 +136,21 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if world not in MESH_FOR_WORLD:
         raise SystemExit(f"bench.py supports 1, 2, 4 or 8 GPUs (one macro-cell per GPU), not {world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
     # rehearsal on a box with fewer GPUs than ranks (development only): HYTEG_BENCH_BACKEND=gloo HYTEG_BENCH_SHARE_GPU=1
     backend = os.environ.get("HYTEG_BENCH_BACKEND", "nccl")
     if os.environ.get("HYTEG_BENCH_SHARE_GPU") == "1":
-        local_rank = local_rank % torch.cuda.device_count()
+        local_rank = local_rank % max(1, torch.cuda.device_count())
+    # N > 1: before this process touches its GPU, a child process per rank tries the peer-to-peer exchange on its own
+    # (hyteg_amd/p2p_canary.py: IPC mappings between the ranks' GPUs, the real pack / wait kernels, values checked) -- if the
+    # GPUs cannot reach each other's memory that way, it is the canary that fails, not the benchmark
+    canary = None
+    try_p2p = world > 1 and os.environ.get("HYTEG_BENCH_P2P", "1") != "0"
+    if try_p2p:
+        from hyteg_amd import p2p_canary
+
+        canary = p2p_canary.launch(rank, world, local_rank, f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -213,7 +222,12 @@ def main():
     # before and after the timed region; otherwise the run is (re)done on RCCL.  HYTEG_BENCH_P2P=0 skips the attempt.
     p2p = {"tried": False}
     check_pairs = [0, 1, 0, 1 % nbuf, 0]  # both slot parities, repeated
-    if world > 1 and os.environ.get("HYTEG_BENCH_P2P", "1") != "0":
+    if try_p2p:
+        ok, text = p2p_canary.finish(canary)
+        if not all_ranks(ok):
+            try_p2p = False
+            ctx.transport_note = f"peer-to-peer canary failed on some rank (this rank: {'ok' if ok else text.strip()[-200:]}): run on {ctx.transport}"
+    if try_p2p:
         reference = results(check_pairs)
         p2p["tried"] = True
         if ctx.enable_p2p():
@@ -333,7 +347,7 @@ def main():
                                   + ("ncclSend/ncclRecv groups issued by the C++ host layer on a communication stream (RCCL over xGMI), "
                                      "event-ordered, overlapped with the interior kernel" if ctx.transport == "rccl" else
                                      f"pack kernel stores into the neighbour GPUs' IPC-mapped {ctx.p2p_arena['kind']} arenas over xGMI, "
-                                     "one-wave wait kernel before the reduce kernel, no library call per exchange; results equal to the "
+                                     "the reduce kernel waits for their sequence numbers, no library call per exchange; canary process passed, results equal to the "
                                      f"'{ctx.inner_transport}' transport's bit for bit on every rank before and after the timed region"
                                      if ctx.transport == "p2p" else
                                      "torch.distributed all_to_all hooks (rehearsal transport)")

@@ -806,6 +806,7 @@ struct P2RowsArgs
    const Tile* tiles; // TILES_ROWS of the vertex array, capacity 64; pad[0], pad[1] = the tile's first index at widths N-1, N-2
    int         ntiles;
    unsigned    vbytes, ebytes; // sizes of the vertex- and edge-DoF arrays
+   int         xcd_chunk;      // row blocks per XCD: block b works on chunk b % 8 (0: blocks in launch order)
 };
 constexpr int kRowsWaves = 4;
 
@@ -855,6 +856,15 @@ __device__ inline void p2_rows_kind( const P2RowsArgs& A, const double ( &U )[kS
 template < int UPDATE, bool RESTRICTED = false >
 __device__ inline void p2_rows_body( const P2RowsArgs& A, int block )
 {
+   // Workgroups b, b + 8, ... run on the same XCD: they take consecutive row groups of ONE chunk of the cell, so that the
+   // source rows neighbouring destination rows share (every source row serves ~7 destination rows) are found in that XCD's
+   // L2 instead of being fetched by up to four L2s
+   if ( A.xcd_chunk > 0 )
+   {
+      if ( ( block >> 3 ) >= A.xcd_chunk )
+         return;
+      block = ( block & 7 ) * A.xcd_chunk + ( block >> 3 );
+   }
    const int t = __builtin_amdgcn_readfirstlane( block * kRowsWaves + ( (int) threadIdx.x >> 6 ) );
    if ( t >= A.ntiles )
       return;
@@ -1257,7 +1267,17 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell_kinds( double*            
       const int n = F.N - 1;
       R.vbytes    = (unsigned) ( tet64( F.N ) * 8 );
       R.ebytes    = (unsigned) ( ( 6 * tet64( n ) + tet64( n - 1 ) ) * 8 );
-      const unsigned rowBlocks = (unsigned) ( ( tt.count + kRowsWaves - 1 ) / kRowsWaves );
+      unsigned rowBlocks = (unsigned) ( ( tt.count + kRowsWaves - 1 ) / kRowsWaves );
+      R.xcd_chunk        = 0;
+      static const bool xcdRows = [] {
+         const char* e = std::getenv( "HYTEG_HIP_P2_XCD_ROWS" );
+         return !( e && e[0] == '0' );
+      }();
+      if ( xcdRows && rowBlocks >= 64 )
+      {
+         R.xcd_chunk = (int) ( ( rowBlocks + 7 ) / 8 );
+         rowBlocks   = 8u * (unsigned) R.xcd_chunk;
+      }
       const unsigned shell     = mask & HYTEG_HIP_MASK_SHELL;
       const int      nb        = shell ? nbx : 0;
       if ( kind_mask != 0xFFu )

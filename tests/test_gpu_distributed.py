@@ -286,3 +286,15 @@ def test_rccl_backend_single_rank():
         assert np.array_equal(applied[gid], ref_applied[gid])
         assert np.array_equal(cycled[gid], ref_cycled[gid])
         assert np.array_equal(swept[gid], ref_swept[gid])
+
+
+def test_p2p_canary_between_processes_on_one_gpu():
+    """hyteg_amd/p2p_canary.py (what bench.py --gpus N runs before it tries the peer-to-peer transport): three processes map
+    each other's arenas through HIP IPC, exchange six rounds with the real pack / wait kernels and check every value"""
+    sys.path.insert(0, str(ROOT))
+    from hyteg_amd import p2p_canary
+
+    tag = f"test_{os.getpid()}_{_free_port()}"
+    procs = [p2p_canary.launch(r, 3, 0, tag) for r in range(3)]
+    outs = [p2p_canary.finish(p) for p in procs]
+    assert all(ok for ok, _ in outs), outs

@@ -10,8 +10,8 @@ run() { # name, extra env...
 import json,sys
 d=json.loads(sys.stdin.read()); print('$name', 'us per step', round(d['ms_per_step']*1e3,2), d['config']['halo_exchange'][:40])"
 }
-run side_fused A=1
-run noside_fused HYTEG_AMD_SIDE_STREAM=0
-run side_waitkernel HYTEG_HIP_P2P_FUSED_WAIT=0
-run noside_waitkernel HYTEG_AMD_SIDE_STREAM=0 HYTEG_HIP_P2P_FUSED_WAIT=0
-run side_fused_again A=1
+run default A=1
+grep -h "canary\|transport" $O/bench_default.err | head -5 || true
+tail -1 $O/bench_default.json | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print(d['config']['halo_exchange'])"
