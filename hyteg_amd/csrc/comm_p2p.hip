@@ -19,25 +19,12 @@
 #include <cstring>
 
 #include "common.hpp"
+#include "p2p_device.hpp"
 
 namespace hyteg_hip {
 namespace {
 
 constexpr int kPackThreads = 256;
-
-// No release fence in the pack kernel: on gfx942/gfx950 a system- (or agent-) scope release is an L2 write-back
-// (buffer_wbl2), and one per workgroup made the kernel last 31 us instead of 3.4 (exp/p2p_probe.py).  Instead the values are
-// written with system-scope write-through stores (sc0 sc1: they do not stay in this GPU's L2, and the arena is uncached on
-// the owner's side), a wave waits until its stores have been acknowledged (s_waitcnt vmcnt(0)) before its workgroup
-// reports in, and the last workgroup -- which has observed every other workgroup's report -- writes the flag words.
-__device__ __forceinline__ void store_through( double* p, double v )
-{
-   __hip_atomic_store( p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
-}
-__device__ __forceinline__ void stores_acknowledged()
-{
-   asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
-}
 
 __global__ __launch_bounds__( kPackThreads ) void p2p_pack_kernel( const hyteg_hip_p2p_peer_t* __restrict__ peers,
                                                                    int                        npeers,
@@ -50,15 +37,8 @@ __global__ __launch_bounds__( kPackThreads ) void p2p_pack_kernel( const hyteg_h
 {
    const int k = blockIdx.x * kPackThreads + threadIdx.x;
    if ( k < n )
-   {
-      const double v = bases[entry_buf[k]][entry_off[k]];
-      // segments are concatenated per peer: find the one k lies in
-      int p = 0;
-      while ( p + 1 < npeers && k >= peers[p + 1].start )
-         ++p;
-      store_through( peers[p].slot[seq & 1ull] + ( k - peers[p].start ), v );
-   }
-   stores_acknowledged();
+      p2p::send_value( peers, npeers, k, seq, bases[entry_buf[k]][entry_off[k]] );
+   p2p::stores_acknowledged();
    __syncthreads();
    if ( threadIdx.x == 0 )
    {
@@ -66,8 +46,7 @@ __global__ __launch_bounds__( kPackThreads ) void p2p_pack_kernel( const hyteg_h
       if ( done == gridDim.x - 1 )
       {
          __hip_atomic_store( counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ); // ready for the next exchange
-         for ( int p = 0; p < npeers; ++p )
-            __hip_atomic_store( peers[p].flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+         p2p::publish( peers, npeers, seq );
       }
    }
 }

@@ -2,6 +2,7 @@
 // (points on its macro-faces/edges/vertices), masked vector kernels, masked dot, and the additive exchange of
 // shared points.  The shell has O(4^L) points, so these kernels are latency- rather than bandwidth-relevant.
 #include "common.hpp"
+#include "shell.hpp"
 
 using namespace hyteg_hip;
 
@@ -9,72 +10,7 @@ namespace {
 
 constexpr int kThreads = 256;
 
-struct Slots14x15
-{
-   double w[14][15];
-};
-
-__constant__ int kOffs[15][3] = { { 0, 0, -1 }, { 1, 0, -1 }, { -1, 1, -1 }, { 0, 1, -1 }, { 0, -1, 0 },
-                                  { 1, -1, 0 }, { -1, 0, 0 }, { 0, 0, 0 },   { 1, 0, 0 },  { -1, 1, 0 },
-                                  { 0, 1, 0 },  { 0, -1, 1 }, { 1, -1, 1 },  { -1, 0, 1 }, { 0, 0, 1 } };
-
-// slot of the macro-primitive a point lies on (see p1_transfer.hip / MacroCellIndexing.cpp:36-91), -1 interior
-__device__ inline int shell_slot( int N, int x, int y, int z )
-{
-   const int f0 = ( z == 0 ), f1 = ( y == 0 ), f2 = ( x == 0 ), f3 = ( x + y + z == N - 1 );
-   const int cnt = f0 + f1 + f2 + f3;
-   if ( cnt == 0 )
-      return -1;
-   if ( cnt == 1 )
-      return 6 + ( f0 ? 0 : f1 ? 1 : f2 ? 2 : 3 );
-   if ( cnt == 2 )
-   {
-      if ( f0 )
-         return f1 ? 0 : ( f2 ? 1 : 2 );
-      if ( f1 )
-         return f2 ? 3 : 4;
-      return 5;
-   }
-   if ( f0 && f1 && f2 )
-      return 10;
-   if ( f0 && f1 && f3 )
-      return 11;
-   if ( f0 && f2 && f3 )
-      return 12;
-   return 13;
-}
-
-// Enumerates every shell point exactly once: q in [0, 4 tri(N)) -> (x,y,z,slot); returns false for the
-// duplicates (a point on an edge/vertex is visited through its lowest-numbered face only) and padding.
-__device__ inline bool shell_point( int N, int q, int& x, int& y, int& z, int& slot )
-{
-   const int T = tri( N );
-   if ( q >= 4 * T )
-      return false;
-   const int f = q / T, r = q - f * T;
-   const int j = row_of( N, r );
-   const int i = r - row_start( N, j );
-   switch ( f )
-   {
-   case 0:
-      x = i, y = j, z = 0;
-      break;
-   case 1:
-      x = i, y = 0, z = j;
-      break;
-   case 2:
-      x = 0, y = i, z = j;
-      break;
-   default:
-      x = i, y = j, z = N - 1 - i - j;
-      break;
-   }
-   const int lowest = ( z == 0 ) ? 0 : ( y == 0 ) ? 1 : ( x == 0 ) ? 2 : 3;
-   if ( lowest != f )
-      return false;
-   slot = shell_slot( N, x, y, z );
-   return true;
-}
+using namespace hyteg_hip::shell;
 
 __global__ __launch_bounds__( kThreads ) void p1_apply_shell_kernel( double* __restrict__ dst,
                                                                       const double* __restrict__ src,
@@ -87,17 +23,9 @@ __global__ __launch_bounds__( kThreads ) void p1_apply_shell_kernel( double* __r
    int       x, y, z, slot;
    if ( !shell_point( N, q, x, y, z, slot ) || !( ( mask >> slot ) & 1u ) )
       return;
-   double acc = 0.0;
-#pragma unroll
-   for ( int k = 0; k < 15; ++k )
-   {
-      const int nx = x + kOffs[k][0], ny = y + kOffs[k][1], nz = z + kOffs[k][2];
-      if ( nx < 0 || ny < 0 || nz < 0 || nx + ny + nz > N - 1 )
-         continue;
-      acc = fma( S.w[slot][k], src[cell_index( N, nx, ny, nz )], acc );
-   }
-   const int i = cell_index( N, x, y, z );
-   dst[i]      = update == HYTEG_HIP_ADD ? acc + dst[i] : acc;
+   const double acc = share( S, src, N, x, y, z, slot );
+   const int    i   = cell_index( N, x, y, z );
+   dst[i]           = update == HYTEG_HIP_ADD ? acc + dst[i] : acc;
 }
 
 struct VecArgsM

@@ -1,6 +1,6 @@
 set -e
 O=$GRAFT_REPO_ROOT/gpurun_out/r02p2p; mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_gpu_distributed.py tests/test_gpu_p2_config4.py -x -q -m gpu > $O/pytest_dist.txt 2>&1 || { tail -60 $O/pytest_dist.txt; exit 1; }
+timeout -k 10 900 python -m pytest tests/test_gpu_distributed.py tests/test_gpu_faces.py tests/test_gpu_host.py -x -q -m gpu > $O/pytest_dist.txt 2>&1 || { tail -60 $O/pytest_dist.txt; exit 1; }
 tail -3 $O/pytest_dist.txt
 export HYTEG_BENCH_BACKEND=gloo HYTEG_BENCH_SHARE_GPU=1
 run() { # name, extra env...
@@ -11,7 +11,3 @@ import json,sys
 d=json.loads(sys.stdin.read()); print('$name', 'us per step', round(d['ms_per_step']*1e3,2), d['config']['halo_exchange'][:40])"
 }
 run default A=1
-grep -h "canary\|transport" $O/bench_default.err | head -5 || true
-tail -1 $O/bench_default.json | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print(d['config']['halo_exchange'])"
