@@ -217,7 +217,10 @@ struct ArrivalWait
    unsigned long long        timeout_ticks;
 };
 
-template < bool SUM, bool WAIT = false >
+// plans with at least this many groups take the 2-slot form of the reduce kernel
+constexpr int kSmallBatchFrom = 4096;
+
+template < bool SUM, bool WAIT = false, int KB = 8 >
 __global__ __launch_bounds__( kThreads ) void sum_shared_kernel( double* const* __restrict__ bases,
                                                                   const int* __restrict__ group_ptr,
                                                                   const int* __restrict__ entry_buf,
@@ -255,8 +258,9 @@ __global__ __launch_bounds__( kThreads ) void sum_shared_kernel( double* const* 
    const int lo = group_ptr[g], hi = group_ptr[g + 1];
    // The copies of a group are read in batches of 8 with all index loads, then all base-pointer loads, then all value
    // loads in flight together (a rolled loop pays three dependent memory round trips per copy: 6 us for a launch that
-   // moves a few KB); the sum itself runs in the order of the entries, as before.
-   constexpr int kBatch = 8;
+   // moves a few KB); the sum itself runs in the order of the entries, as before.  KB = 2 for the plans of fine levels, whose
+   // groups are almost all macro-face points with two copies (8 slots per group would quadruple their index and value loads).
+   constexpr int kBatch = KB;
    double        s      = 0.0;
    for ( int e0 = lo; e0 < ( SUM ? hi : lo + 1 ); e0 += kBatch )
    {
@@ -572,8 +576,12 @@ HYTEG_HIP_API int hyteg_hip_sum_shared( double* const*     bases,
    if ( ngroups <= 0 )
       return HYTEG_HIP_OK;
    HH_REQUIRE( bases && group_ptr && entry_buf && entry_off, "sum_shared: null pointer" );
-   hipLaunchKernelGGL( ( sum_shared_kernel< true, false > ), dim3( ( ngroups + kThreads - 1 ) / kThreads ), dim3( kThreads ), 0,
-                       as_stream( stream ), bases, group_ptr, entry_buf, entry_off, ngroups, n_writable, ArrivalWait{} );
+   if ( ngroups >= kSmallBatchFrom )
+      hipLaunchKernelGGL( ( sum_shared_kernel< true, false, 2 > ), dim3( ( ngroups + kThreads - 1 ) / kThreads ), dim3( kThreads ), 0,
+                          as_stream( stream ), bases, group_ptr, entry_buf, entry_off, ngroups, n_writable, ArrivalWait{} );
+   else
+      hipLaunchKernelGGL( ( sum_shared_kernel< true, false, 8 > ), dim3( ( ngroups + kThreads - 1 ) / kThreads ), dim3( kThreads ), 0,
+                          as_stream( stream ), bases, group_ptr, entry_buf, entry_off, ngroups, n_writable, ArrivalWait{} );
    HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;
 }
@@ -589,8 +597,12 @@ HYTEG_HIP_API int hyteg_hip_copy_shared( double* const*     bases,
    if ( ngroups <= 0 )
       return HYTEG_HIP_OK;
    HH_REQUIRE( bases && group_ptr && entry_buf && entry_off, "copy_shared: null pointer" );
-   hipLaunchKernelGGL( ( sum_shared_kernel< false, false > ), dim3( ( ngroups + kThreads - 1 ) / kThreads ), dim3( kThreads ), 0,
-                       as_stream( stream ), bases, group_ptr, entry_buf, entry_off, ngroups, n_writable, ArrivalWait{} );
+   if ( ngroups >= kSmallBatchFrom )
+      hipLaunchKernelGGL( ( sum_shared_kernel< false, false, 2 > ), dim3( ( ngroups + kThreads - 1 ) / kThreads ), dim3( kThreads ), 0,
+                          as_stream( stream ), bases, group_ptr, entry_buf, entry_off, ngroups, n_writable, ArrivalWait{} );
+   else
+      hipLaunchKernelGGL( ( sum_shared_kernel< false, false, 8 > ), dim3( ( ngroups + kThreads - 1 ) / kThreads ), dim3( kThreads ), 0,
+                          as_stream( stream ), bases, group_ptr, entry_buf, entry_off, ngroups, n_writable, ArrivalWait{} );
    HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;
 }
@@ -616,11 +628,18 @@ HYTEG_HIP_API int hyteg_hip_reduce_shared_after_p2p( double* const*            b
    HH_REQUIRE( npeers >= 0 && ( npeers == 0 || ( flags && status && stride >= 1 ) ), "reduce_shared_after_p2p: bad wait arguments" );
    const ArrivalWait W{ flags, npeers, stride, seq, status, (unsigned long long) ( timeout_ms ? timeout_ms : 20000u ) * 100000ull };
    const dim3        grid( ( ngroups + kThreads - 1 ) / kThreads ), block( kThreads );
-   if ( additive )
-      hipLaunchKernelGGL( ( sum_shared_kernel< true, true > ), grid, block, 0, as_stream( stream ), bases, group_ptr, entry_buf, entry_off,
+   const bool small = ngroups >= kSmallBatchFrom;
+   if ( additive && small )
+      hipLaunchKernelGGL( ( sum_shared_kernel< true, true, 2 > ), grid, block, 0, as_stream( stream ), bases, group_ptr, entry_buf, entry_off,
+                          ngroups, n_writable, W );
+   else if ( additive )
+      hipLaunchKernelGGL( ( sum_shared_kernel< true, true, 8 > ), grid, block, 0, as_stream( stream ), bases, group_ptr, entry_buf, entry_off,
+                          ngroups, n_writable, W );
+   else if ( small )
+      hipLaunchKernelGGL( ( sum_shared_kernel< false, true, 2 > ), grid, block, 0, as_stream( stream ), bases, group_ptr, entry_buf, entry_off,
                           ngroups, n_writable, W );
    else
-      hipLaunchKernelGGL( ( sum_shared_kernel< false, true > ), grid, block, 0, as_stream( stream ), bases, group_ptr, entry_buf, entry_off,
+      hipLaunchKernelGGL( ( sum_shared_kernel< false, true, 8 > ), grid, block, 0, as_stream( stream ), bases, group_ptr, entry_buf, entry_off,
                           ngroups, n_writable, W );
    HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;

@@ -76,18 +76,32 @@ __device__ inline bool shell_point( int N, int q, int& x, int& y, int& z, int& s
 }
 
 // this cell's share of ( A src ) at shell point (x, y, z) of macro-primitive `slot`: the neighbours inside the cell, in the
-// order of the weights
+// order of the weights.  All fifteen values and weights are loaded before the first FMA (a loop that skips the neighbours
+// outside the cell pays one dependent memory round trip per neighbour: 7 us for a launch over one macro-face); a neighbour
+// outside the cell reads the point itself and is skipped by a select, so the sum is the same FMA chain as before.
+// Neighbour indices by layout algebra from the point's own index (w = length of row 0 of slice z):
+//   same slice: row y -> y + 1: + ( w - y ), y -> y - 1: - ( w - y + 1 );  slice z - 1: - tri( w + 1 ) + y';  z + 1: + tri( w ) - y'
 __device__ inline double share( const Slots14x15& S, const double* __restrict__ src, int N, int x, int y, int z, int slot )
 {
-   double acc = 0.0;
+   const int w  = N - z;
+   const int i0 = cell_index( N, x, y, z );
+   double    v[15], c[15];
+   bool      ok[15];
 #pragma unroll
    for ( int k = 0; k < 15; ++k )
    {
-      const int nx = x + kOffs[k][0], ny = y + kOffs[k][1], nz = z + kOffs[k][2];
-      if ( nx < 0 || ny < 0 || nz < 0 || nx + ny + nz > N - 1 )
-         continue;
-      acc = fma( S.w[slot][k], src[cell_index( N, nx, ny, nz )], acc );
+      const int dx = kOffs[k][0], dy = kOffs[k][1], dz = kOffs[k][2];
+      const int nx = x + dx, ny = y + dy, nz = z + dz;
+      ok[k]        = !( nx < 0 || ny < 0 || nz < 0 || nx + ny + nz > N - 1 );
+      const int rowDelta   = dy == 0 ? 0 : ( dy > 0 ? ( w - y ) : -( w - y + 1 ) );
+      const int sliceDelta = dz == 0 ? 0 : ( dz > 0 ? tri( w ) - ny : ny - tri( w + 1 ) );
+      v[k]                 = src[ok[k] ? i0 + sliceDelta + rowDelta + dx : i0];
+      c[k]                 = S.w[slot][k];
    }
+   double acc = 0.0;
+#pragma unroll
+   for ( int k = 0; k < 15; ++k )
+      acc = ok[k] ? fma( c[k], v[k], acc ) : acc;
    return acc;
 }
 
