@@ -272,17 +272,29 @@ struct ApplyB
    double        relax;
 };
 
+// All fifteen values and weights are loaded before the first FMA; a neighbour outside the cell reads the point itself and
+// is skipped by a select (same FMA chain as a loop that skips it, without one dependent memory round trip per neighbour).
+// Neighbour indices by layout algebra from p.i, as in shell.hpp.
 __device__ inline double stencil_sum( const double* __restrict__ w, const double* __restrict__ src, int N, const Point& p )
 {
-   double acc = 0.0;
+   const int W = N - p.z;
+   double    v[15], c[15];
+   bool      ok[15];
 #pragma unroll
    for ( int k = 0; k < 15; ++k )
    {
-      const int nx = p.x + kOffsB[k][0], ny = p.y + kOffsB[k][1], nz = p.z + kOffsB[k][2];
-      if ( nx < 0 || ny < 0 || nz < 0 || nx + ny + nz > N - 1 )
-         continue;
-      acc = fma( w[k], src[cell_index( N, nx, ny, nz )], acc );
+      const int dx = kOffsB[k][0], dy = kOffsB[k][1], dz = kOffsB[k][2];
+      const int nx = p.x + dx, ny = p.y + dy, nz = p.z + dz;
+      ok[k]        = !( nx < 0 || ny < 0 || nz < 0 || nx + ny + nz > N - 1 );
+      const int rowDelta   = dy == 0 ? 0 : ( dy > 0 ? ( W - p.y ) : -( W - p.y + 1 ) );
+      const int sliceDelta = dz == 0 ? 0 : ( dz > 0 ? tri( W ) - ny : ny - tri( W + 1 ) );
+      v[k]                 = src[ok[k] ? p.i + sliceDelta + rowDelta + dx : p.i];
+      c[k]                 = w[k];
    }
+   double acc = 0.0;
+#pragma unroll
+   for ( int k = 0; k < 15; ++k )
+      acc = ok[k] ? fma( c[k], v[k], acc ) : acc;
    return acc;
 }
 
@@ -350,20 +362,30 @@ __global__ __launch_bounds__( kThreads ) void batch_restrict_kernel( const Trans
       const Point p = decode( tl, Nc, u );
       if ( !p.ok || !( ( mask >> p.cls ) & 1u ) )
          continue;
+      // the fourteen fine values and their scalings are loaded before the first sum (a loop that skips the neighbours outside
+      // the cell pays dependent round trips per neighbour); the sum is the same sequence of separately rounded terms
+      const int centre = cell_index( Nf, 2 * p.x, 2 * p.y, 2 * p.z );
+      double    fv[14], sc[14];
+      bool      ok[14];
+#pragma unroll
+      for ( int k = 0; k < 14; ++k )
+      {
+         const int fx = 2 * p.x + kNB14B[k][0], fy = 2 * p.y + kNB14B[k][1], fz = 2 * p.z + kNB14B[k][2];
+         ok[k]        = !( fx < 0 || fy < 0 || fz < 0 || fx + fy + fz > Nf - 1 );
+         const int fc = ok[k] ? point_class( Nf, fx, fy, fz ) : 14;
+         fv[k]        = fine[ok[k] ? cell_index( Nf, fx, fy, fz ) : centre];
+         // products and sums rounded separately (no FMA contraction): the per-cell kernels of p1_transfer.hip do the same, so
+         // that both give the same bits as the reference's scalar loops
+         sc[k] = ( fc == 14 ? 1.0 : inv[fc] ) * 0.5;
+      }
       double acc   = 0.0;
       bool   first = true;
 #pragma unroll
       for ( int k = 0; k < 14; ++k )
       {
-         const int fx = 2 * p.x + kNB14B[k][0], fy = 2 * p.y + kNB14B[k][1], fz = 2 * p.z + kNB14B[k][2];
-         if ( fx < 0 || fy < 0 || fz < 0 || fx + fy + fz > Nf - 1 )
-            continue;
-         const int    fc   = point_class( Nf, fx, fy, fz );
-         // products and sums rounded separately (no FMA contraction): the per-cell kernels of p1_transfer.hip do the same, so
-         // that both give the same bits as the reference's scalar loops
-         const double term = mul_rn( ( fc == 14 ? 1.0 : inv[fc] ) * 0.5, fine[cell_index( Nf, fx, fy, fz )] );
-         acc               = first ? term : add_rn( acc, term );
-         first             = false;
+         const double term = mul_rn( sc[k], fv[k] );
+         acc               = ok[k] ? ( first ? term : add_rn( acc, term ) ) : acc;
+         first             = first && !ok[k];
       }
       const int    fc   = point_class( Nf, 2 * p.x, 2 * p.y, 2 * p.z );
       const double term = mul_rn( fc == 14 ? 1.0 : inv[fc], fine[cell_index( Nf, 2 * p.x, 2 * p.y, 2 * p.z )] );
