@@ -45,6 +45,7 @@ SIGNATURES = {
     "hyteg_hip_p2p_arena_close": (_i, [_vp]),
     "hyteg_hip_p2p_pack": (_i, [_vp, _i, _vp, _vp, _vp, _i, C.c_ulonglong, _vp, _vp]),
     "hyteg_hip_p2p_wait": (_i, [_vp, _i, _i, C.c_ulonglong, _vp, C.c_uint, _vp]),
+    "hyteg_hip_p1_apply_cell_boundary_p2p": (_i, [_vp, _vp, _i, _vp, C.c_uint, _i, _vp, _vp, _vp, _i, C.c_ulonglong, _vp, _vp]),
     "hyteg_hip_reduce_shared_after_p2p": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, C.c_ulonglong, _vp, C.c_uint, _vp]),
     "hyteg_hip_graph_begin_capture": (_i, [_vp]),
     "hyteg_hip_graph_end_capture": (_i, [_vp, C.POINTER(_vp)]),

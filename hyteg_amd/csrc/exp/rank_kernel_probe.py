@@ -113,6 +113,35 @@ def two(k):
     reduce(k)
 
 
+# CSR over the shell enumeration of the boundary kernel: q = face * tri(N) + row_start(N, j) + i -> entries of the send enumeration
+T = N * (N + 1) // 2
+by_off = {}
+for kk, off in enumerate(np.concatenate(segs)):
+    by_off.setdefault(int(off), []).append(kk)
+first_h = np.zeros(4 * T + 1, dtype=np.int32)
+list_h = []
+for f in range(4):
+    for j in range(N):
+        for i in range(N - j):
+            q = f * T + (j * N - j * (j - 1) // 2) + i
+            x, y, z = {0: (i, j, 0), 1: (i, 0, j), 2: (0, i, j), 3: (i, j, N - 1 - i - j)}[f]
+            lowest = 0 if z == 0 else (1 if y == 0 else (2 if x == 0 else 3))
+            if lowest == f:
+                list_h += by_off.get(capi.cell_index(level, x, y, z), [])
+            first_h[q + 1] = len(list_h)
+assert len(list_h) == n
+first_d = torch.from_numpy(first_h).to(dev)
+list_d = torch.tensor(list_h + [0], dtype=torch.int32, device=dev)
+
+
+def three(k):
+    seq[0] += 1
+    ck(L.hyteg_hip_p1_apply_cell_boundary_p2p(dsts[k].data_ptr(), srcs[k].data_ptr(), level, ws, mask_shell, 0, first_d.data_ptr(), list_d.data_ptr(),
+                                              d_peers.data_ptr(), nfaces, seq[0], counters.data_ptr(), cur), "boundary + send")
+    ck(L.hyteg_hip_p1_apply_cell(dsts[k].data_ptr(), srcs[k].data_ptr(), level, w, 0, cur), "apply")
+    reduce(k)
+
+
 def interior(k):
     ck(L.hyteg_hip_p1_apply_cell(dsts[k].data_ptr(), srcs[k].data_ptr(), level, w, 0, cur), "apply")
 
@@ -130,7 +159,13 @@ if have_rank and not os.environ.get("HYTEG_HIP_RANK_DBG"):
     assert torch.equal(ref, dsts[0]) and int(status.item()) == 0, "rank kernel differs from the four launches"
 reps = 400
 print(f"level {level}, {nfaces} shared face(s), {n} values per exchange")
+dsts[0].zero_()
+three(0)
+torch.cuda.synchronize()
+assert torch.equal(ref, dsts[0]) and int(status.item()) == 0, "shares + send differs from the four launches"
 for name, fn in (("interior kernel alone", interior), ("four launches (shares, pack, interior, wait+reduce)", four),
+                 ("three launches (shares + send, interior, wait+reduce)", three), ("four launches once more", four),
+                 ("three launches once more", three),
                  ("two launches (rank kernel, wait+reduce)", two), ("four launches again", four), ("two launches again", two)):
     if fn is two and not have_rank:
         continue

@@ -2,6 +2,7 @@
 // (points on its macro-faces/edges/vertices), masked vector kernels, masked dot, and the additive exchange of
 // shared points.  The shell has O(4^L) points, so these kernels are latency- rather than bandwidth-relevant.
 #include "common.hpp"
+#include "p2p_device.hpp"
 #include "shell.hpp"
 
 using namespace hyteg_hip;
@@ -26,6 +27,47 @@ __global__ __launch_bounds__( kThreads ) void p1_apply_shell_kernel( double* __r
    const double acc = share( S, src, N, x, y, z, slot );
    const int    i   = cell_index( N, x, y, z );
    dst[i]           = update == HYTEG_HIP_ADD ? acc + dst[i] : acc;
+}
+
+// The shares of a rank's ONE macro-cell, delivered as they are computed: a point whose share other ranks need (send_first /
+// send_list: its indices in the send enumeration of the exchange plan, CSR over the shell enumeration q) stores it straight into
+// the peers' receive slots, and the last workgroup publishes the sequence number -- hyteg_hip_p1_apply_cell_boundary and
+// hyteg_hip_p2p_pack in one launch, without the pack kernel's gather.
+__global__ __launch_bounds__( kThreads ) void p1_apply_shell_send_kernel( double* __restrict__ dst,
+                                                                           const double* __restrict__ src,
+                                                                           int              N,
+                                                                           unsigned         mask,
+                                                                           int              update,
+                                                                           const Slots14x15 S,
+                                                                           const int* __restrict__ send_first,
+                                                                           const int* __restrict__ send_list,
+                                                                           const hyteg_hip_p2p_peer_t* __restrict__ peers,
+                                                                           int                npeers,
+                                                                           unsigned long long seq,
+                                                                           unsigned*          counter )
+{
+   const int q = blockIdx.x * kThreads + threadIdx.x;
+   int       x, y, z, slot;
+   if ( shell_point( N, q, x, y, z, slot ) && ( ( mask >> slot ) & 1u ) )
+   {
+      const double acc = share( S, src, N, x, y, z, slot );
+      const int    i   = cell_index( N, x, y, z );
+      const double val = update == HYTEG_HIP_ADD ? acc + dst[i] : acc;
+      dst[i]           = val;
+      for ( int j = send_first[q]; j < send_first[q + 1]; ++j )
+         p2p::send_value( peers, npeers, send_list[j], seq, val );
+   }
+   p2p::stores_acknowledged();
+   __syncthreads();
+   if ( threadIdx.x == 0 )
+   {
+      const unsigned done = __hip_atomic_fetch_add( counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+      if ( done == gridDim.x - 1 )
+      {
+         __hip_atomic_store( counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+         p2p::publish( peers, npeers, seq );
+      }
+   }
 }
 
 struct VecArgsM
@@ -428,6 +470,37 @@ HYTEG_HIP_API int hyteg_hip_p1_apply_cell_boundary( double*            dst,
    const int N = ( 1 << level ) + 1;
    hipLaunchKernelGGL( p1_apply_shell_kernel, dim3( shell_blocks( N ) ), dim3( kThreads ), 0, as_stream( stream ), dst, src, N,
                        mask & HYTEG_HIP_MASK_SHELL, update, S );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_p1_apply_cell_boundary_p2p( double*                     dst,
+                                                        const double*               src,
+                                                        int                         level,
+                                                        const double*               w_slots,
+                                                        unsigned                    mask,
+                                                        int                         update,
+                                                        const int*                  send_first,
+                                                        const int*                  send_list,
+                                                        const hyteg_hip_p2p_peer_t* peers,
+                                                        int                         npeers,
+                                                        unsigned long long          seq,
+                                                        unsigned*                   counter,
+                                                        hyteg_hip_stream_t          stream )
+{
+   HH_REQUIRE( dst && src && w_slots, "p1_apply_cell_boundary_p2p: null pointer" );
+   HH_REQUIRE( shell_level_ok( level ), "p1_apply_cell_boundary_p2p: level out of range [0,11]" );
+   HH_REQUIRE( dst != src, "p1_apply_cell_boundary_p2p: src and dst must not alias" );
+   HH_REQUIRE( update == HYTEG_HIP_REPLACE || update == HYTEG_HIP_ADD, "p1_apply_cell_boundary_p2p: bad update type" );
+   HH_REQUIRE( send_first && send_list && peers && npeers > 0 && counter && seq > 0, "p1_apply_cell_boundary_p2p: bad exchange arguments" );
+   Slots14x15 S;
+   for ( int s = 0; s < 14; ++s )
+      for ( int k = 0; k < 15; ++k )
+         S.w[s][k] = w_slots[15 * s + k];
+   const int N = ( 1 << level ) + 1;
+   // launched even if the mask selects nothing: the peers wait for the sequence number
+   hipLaunchKernelGGL( p1_apply_shell_send_kernel, dim3( shell_blocks( N ) ), dim3( kThreads ), 0, as_stream( stream ), dst, src, N,
+                       mask & HYTEG_HIP_MASK_SHELL, update, S, send_first, send_list, peers, npeers, seq, counter );
    HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;
 }

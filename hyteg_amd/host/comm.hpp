@@ -44,6 +44,15 @@ struct ArrivalWait
    unsigned                  timeoutMs = 0;
 };
 
+// what a kernel needs to deliver the values of an exchange itself, as it computes them (hyteg_hip_p1_apply_cell_boundary_p2p)
+struct PackArgs
+{
+   const hyteg_hip_p2p_peer_t* peers   = nullptr;
+   int                         npeers  = 0;
+   unsigned long long          seq     = 0;
+   unsigned*                   counter = nullptr;
+};
+
 // Moves plan.sendBuffer (segments per peer) into the peers' plan.recvBuffer.  `key` = cls + 2 * dofKind identifies the
 // plan of a level (boundary class 0 / 1; vertex-DoF / edge-DoF arrays).
 class Transport
@@ -68,6 +77,9 @@ class Transport
    // where the reduce kernel finds the received segments (concatenated per peer) of the exchange that exchangeEnd has just
    // completed; valid until the next exchangeBegin of the plan
    virtual double* recvBase( const ExchangePlan& plan, int /*level*/, int /*key*/ ) { return plan.recvBuffer; }
+   // Instead of pack(): true = the caller's own kernel delivers the values of this exchange with `a` (the exchange has
+   // begun; exchangeBegin must still be called, exchangeEnd as usual); false = not supported, nothing has happened.
+   virtual bool packArgs( const ExchangePlan&, int /*level*/, int /*key*/, PackArgs& /*a*/, hyteg_hip_stream_t ) { return false; }
    // true: exchangeEnd has NOT made the compute stream wait for the arrival; the reduce kernel does it itself with `w`
    virtual bool arrivalWait( const ExchangePlan&, int /*level*/, int /*key*/, ArrivalWait& /*w*/ ) { return false; }
    // true: the exchange of this plan is ordered against whatever stream `compute` is at each call (not against a stream
@@ -351,6 +363,22 @@ class P2PTransport : public Transport
       hipCheck( hyteg_hip_p2p_pack( S->dPeers, (int) plan.peers.size(), bases, plan.dSendBuf, plan.dSendOff, plan.totalSend(), S->seq,
                                     S->dCounter, compute ),
                 "P2PTransport: pack" );
+      return true;
+   }
+   bool packArgs( const ExchangePlan& plan, int level, int key, PackArgs& a, hyteg_hip_stream_t compute ) override
+   {
+      PlanState* S = find( level, key );
+      if ( !S || plan.peers.empty() )
+         return false;
+      if ( S->inFlight )
+         throw std::runtime_error( "P2PTransport: second exchange of a plan begun before the first one has ended" );
+      S->inFlight  = true;
+      lastCompute_ = compute;
+      ++S->seq;
+      a.peers   = S->dPeers;
+      a.npeers  = (int) plan.peers.size();
+      a.seq     = S->seq;
+      a.counter = S->dCounter;
       return true;
    }
    void exchangeBegin( const ExchangePlan& plan, int level, int key, hyteg_hip_stream_t compute ) override

@@ -238,6 +238,13 @@ class P1Function
    // launched in between (the interior apply overlaps the halo exchange).
    void beginSumSharedCopies( uint_t level, DoFType flag = All ) const { exchangeBegin( level, flag ); }
    void endSumSharedCopies( uint_t level, DoFType flag = All ) const { exchangeEnd( level, flag, true ); }
+   // beginSumSharedCopies for a caller whose boundary-share kernel delivers the shares itself
+   // (PrimitiveStorage::sharedExchangeBeginByShares); flag: effective flag
+   bool beginSumSharedCopiesByShares( uint_t level, DoFType flag, PrimitiveStorage::ShareSend& out ) const
+   {
+      checkLevel( level );
+      return storage_->sharedExchangeBeginByShares( (int) level, flag, out );
+   }
 
    void copyCellToHost( uint_t c, uint_t level, double* host ) const
    {

@@ -68,15 +68,29 @@ class P1ConstantOperator
       // with a stream-agnostic transport they can form a chain on a side stream next to 3 (PrimitiveStorage::SideChain;
       // opt-in, measured slower than one stream).
       PrimitiveStorage::SideChain chain( *storage_, storage_->sideChainUsable( (int) level, flag, 0 ) );
+      // a rank with ONE macro-cell that exchanges peer to peer: the share kernel stores the shares into the peers' slots itself
+      PrimitiveStorage::ShareSend send;
+      const bool bySharesKernel = shellDst->beginSumSharedCopiesByShares( level, flag, send );
       forCells( [&]( uint_t c, const MacroCell& cell ) {
          const auto& S = getCellStencils( cell.id, level );
+         if ( bySharesKernel )
+         {
+            hipCheck( hyteg_hip_p1_apply_cell_boundary_p2p( shellDst->getCellPointer( c, level ), src.getCellPointer( c, level ), (int) level,
+                                                            &S.slots[0][0], storage_->maskFor( cell, flag ),
+                                                            ( updateType == Add && shellDst == &dst ) ? HYTEG_HIP_ADD : HYTEG_HIP_REPLACE,
+                                                            send.first, send.list, send.a.peers, send.a.npeers, send.a.seq, send.a.counter,
+                                                            storage_->stream() ),
+                      "apply: boundary + send" );
+            return;
+         }
          hipCheck( hyteg_hip_p1_apply_cell_boundary( shellDst->getCellPointer( c, level ), src.getCellPointer( c, level ), (int) level,
                                                      &S.slots[0][0], storage_->maskFor( cell, flag ),
                                                      ( updateType == Add && shellDst == &dst ) ? HYTEG_HIP_ADD : HYTEG_HIP_REPLACE,
                                                      storage_->stream() ),
                    "apply: boundary" );
       } );
-      shellDst->beginSumSharedCopies( level, flag );
+      if ( !bySharesKernel )
+         shellDst->beginSumSharedCopies( level, flag );
       chain.toMain();
       forCells( [&]( uint_t c, const MacroCell& cell ) {
          const unsigned mask = storage_->maskFor( cell, flag );

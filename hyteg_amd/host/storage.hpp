@@ -446,6 +446,53 @@ class PrimitiveStorage
          T.exchangeBegin( plan, level, key, stream_ );
       }
    }
+   // sharedExchangeBegin for a rank with ONE macro-cell whose boundary-share kernel delivers the shares itself
+   // (hyteg_hip_p1_apply_cell_boundary_p2p).  Possible if exactly one boundary class under `flag` has peers and the transport
+   // hands out pack arguments (peer to peer).  true: the exchange has begun -- the caller MUST launch that kernel with `out`;
+   // false: nothing has happened, use the boundary kernel + sharedExchangeBegin.  Taken for exchanges of at least
+   // HYTEG_AMD_SHARE_SEND_MIN values (default 60000; 0 = never): with loop-back peers on one GPU an apply with three shared
+   // level-8 macro-faces (97k values) takes 29.9 instead of 33.6 us, one with a single face (32k) 22.7 instead of 21.0 --
+   // every workgroup of the share kernel then waits for write-through stores (profiles/r02_p2p_probe.txt).
+   struct ShareSend
+   {
+      PackArgs   a;
+      const int *first = nullptr, *list = nullptr; // CSR over the shell enumeration of the boundary kernel
+   };
+   bool sharedExchangeBeginByShares( int level, DoFType flag, ShareSend& out ) const
+   {
+      if ( nranks_ == 1 || !transport_ || localCells_.size() != 1 )
+         return false;
+      static const int minValues = [] {
+         const char* e = std::getenv( "HYTEG_AMD_SHARE_SEND_MIN" );
+         return e ? std::atoi( e ) : 60000;
+      }();
+      if ( minValues <= 0 )
+         return false;
+      int active = -1;
+      for ( int cls = 0; cls < 2; ++cls )
+         if ( testFlag( boundaryTypeOf( cls == 1 ), flag ) && !exchangePlan( level, cls, 0 ).peers.empty() )
+         {
+            if ( active >= 0 )
+               return false;
+            active = cls;
+         }
+      if ( active < 0 || exchangePlan( level, active, 0 ).totalSend() < minValues )
+         return false;
+      const ExchangePlan& plan = devicePlan( level, active, 0 );
+      const auto&         tbl  = shareSendTable( level, active, plan );
+      if ( !transport_->packArgs( plan, level, active, out.a, stream_ ) )
+         return false;
+      out.first = tbl.first, out.list = tbl.list;
+      // as sharedExchangeBegin: a collective transport is entered for the class without peers as well
+      for ( int cls = 0; cls < 2; ++cls )
+      {
+         if ( !testFlag( boundaryTypeOf( cls == 1 ), flag ) )
+            continue;
+         if ( cls == active || transport_->collective() )
+            transport_->exchangeBegin( devicePlan( level, cls, 0 ), level, cls, stream_ );
+      }
+      return true;
+   }
    void sharedExchangeEnd( const std::vector< double* >& arrays, int level, DoFType flag, int dofKind, bool additive ) const
    {
       for ( int cls = 0; cls < 2; ++cls )
@@ -473,6 +520,55 @@ class PrimitiveStorage
                                                         (int) arrays.size(), stream_ ),
                       "exchange: reduce" );
       }
+   }
+   // For the ONE local cell of this rank: which entries of the plan's send enumeration the shell point q of the boundary kernel
+   // (p1_boundary.hip shell_point: q = face * tri( N ) + row_start( N, j ) + i, a point on several faces through its lowest one)
+   // feeds, as CSR arrays on the device.
+   struct ShareSendTable
+   {
+      int *first = nullptr, *list = nullptr;
+   };
+   const ShareSendTable& shareSendTable( int level, int cls, const ExchangePlan& plan ) const
+   {
+      auto it = shareSendTables_.find( { level, cls } );
+      if ( it != shareSendTables_.end() )
+         return it->second;
+      const int64_t N = layout::width( level ), T = N * ( N + 1 ) / 2;
+      std::multimap< int, int > byOffset; // array offset -> send entry
+      for ( int k = 0; k < plan.totalSend(); ++k )
+      {
+         if ( plan.sendBuf[(size_t) k] != 0 )
+            throw std::runtime_error( "shareSendTable: more than one local cell" );
+         byOffset.emplace( plan.sendOff[(size_t) k], k );
+      }
+      std::vector< int > first( (size_t) ( 4 * T + 1 ), 0 ), list;
+      for ( int64_t f = 0; f < 4; ++f )
+         for ( int64_t j = 0; j < N; ++j )
+            for ( int64_t i = 0; i < N - j; ++i )
+            {
+               const int64_t q = f * T + ( j * N - j * ( j - 1 ) / 2 ) + i;
+               const int64_t x = f == 2 ? 0 : i, y = f == 0 || f == 3 ? j : ( f == 1 ? 0 : i ), z = f == 0 ? 0 : ( f == 3 ? N - 1 - i - j : j );
+               const int64_t lowest = z == 0 ? 0 : ( y == 0 ? 1 : ( x == 0 ? 2 : 3 ) );
+               if ( lowest == f )
+               {
+                  auto range = byOffset.equal_range( (int) layout::cellIndex( N, x, y, z ) );
+                  for ( auto e = range.first; e != range.second; ++e )
+                     list.push_back( e->second );
+               }
+               first[(size_t) q + 1] = (int) list.size();
+            }
+      // rows are visited in increasing q, so first[] is already cumulative -- but q runs face by face: make sure of it
+      for ( size_t q = 1; q < first.size(); ++q )
+         if ( first[q] < first[q - 1] )
+            throw std::runtime_error( "shareSendTable: enumeration out of order" );
+      if ( (int) list.size() != plan.totalSend() )
+         throw std::runtime_error( "shareSendTable: " + std::to_string( plan.totalSend() - (int) list.size() ) +
+                                   " send entries are not shell points of the cell" );
+      ShareSendTable t;
+      t.first = uploadVector( first );
+      list.push_back( 0 ); // never empty
+      t.list  = uploadVector( list );
+      return shareSendTables_.emplace( std::make_pair( level, cls ), t ).first->second;
    }
    // device table [ local cell arrays ..., receive segment of peer 0, peer 1, ... ] (cached by content)
    double** basesTable( const std::vector< double* >& arrays, const ExchangePlan& plan, double* recvBase ) const
@@ -826,6 +922,7 @@ class PrimitiveStorage
    mutable std::map< size_t, std::vector< double* > >      scratchFree_;
    mutable std::vector< void* >                            scratchAll_;
    mutable std::map< std::vector< double* >, double** >    pointerTables_;
+   mutable std::map< std::pair< int, int >, ShareSendTable > shareSendTables_;
    mutable double*                                         nncInv_        = nullptr;
    mutable int                                             batchMaxLevel_ = -2; // -2: read HYTEG_AMD_BATCH_MAX_LEVEL on first use
    // a rank with ONE macro-cell: levels up to this one use the generic batched kernels as well

@@ -782,6 +782,23 @@ HYTEG_HIP_API int hyteg_hip_p2p_pack( const hyteg_hip_p2p_peer_t* peers,
                                       unsigned long long          seq,
                                       unsigned*                   counter,
                                       hyteg_hip_stream_t          stream );
+/* hyteg_hip_p1_apply_cell_boundary + hyteg_hip_p2p_pack in one launch, for a rank that owns ONE macro-cell: a shell point q
+ * (the enumeration of the boundary kernel: q in [0, 4 tri(N)), face by face, row by row) whose share other ranks need stores it
+ * into the peers' slots as entries send_list[ send_first[q] .. send_first[q+1] ) of the plan's send enumeration; the last
+ * workgroup publishes seq.  send_first has 4 tri(N) + 1 entries.  Same values, bit for bit, as the two calls. */
+HYTEG_HIP_API int hyteg_hip_p1_apply_cell_boundary_p2p( double*                     dst,
+                                                        const double*               src,
+                                                        int                         level,
+                                                        const double*               w_slots /* host, 14 x 15 */,
+                                                        unsigned                    mask,
+                                                        int                         update,
+                                                        const int*                  send_first,
+                                                        const int*                  send_list,
+                                                        const hyteg_hip_p2p_peer_t* peers,
+                                                        int                         npeers,
+                                                        unsigned long long          seq,
+                                                        unsigned*                   counter,
+                                                        hyteg_hip_stream_t          stream );
 /* hyteg_hip_sum_shared ( additive != 0 ) / hyteg_hip_copy_shared whose workgroups first wait like hyteg_hip_p2p_wait: the
  * wait kernel and the reduce kernel of an exchange in one launch */
 HYTEG_HIP_API int hyteg_hip_reduce_shared_after_p2p( double* const*            bases,

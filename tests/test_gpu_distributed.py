@@ -58,6 +58,9 @@ def _run(host, storage, level, ctx=None):
 def _worker(rank, world, port, level, q, transport="auto", mesh=MESH):
     sys.path.insert(0, str(ROOT))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    # one macro-cell per rank + p2p: also at these small levels the share kernel delivers the shares itself (production: only
+    # exchanges of >= 60000 values)
+    os.environ["HYTEG_AMD_SHARE_SEND_MIN"] = "1"
     import torch
     import torch.distributed as dist
 
