@@ -854,21 +854,21 @@ __device__ inline void p2_rows_kind( const P2RowsArgs& A, const double ( &U )[kS
 // RESTRICTED: only some destination kinds are computed (A.F.kinds) and only their sources are loaded; the unrestricted form
 // keeps its loads free of branches (with one wave-uniform branch per load the full apply was 16 % slower)
 template < int UPDATE, bool RESTRICTED = false >
-__device__ inline void p2_rows_body( const P2RowsArgs& A, int block )
+__device__ inline void p2_rows_body( const P2RowsArgs& A, const Tile* tiles, int ntiles, int xcd_chunk, int block )
 {
    // Workgroups b, b + 8, ... run on the same XCD: they take consecutive row groups of ONE chunk of the cell, so that the
    // source rows neighbouring destination rows share (every source row serves ~7 destination rows) are found in that XCD's
    // L2 instead of being fetched by up to four L2s
-   if ( A.xcd_chunk > 0 )
+   if ( xcd_chunk > 0 )
    {
-      if ( ( block >> 3 ) >= A.xcd_chunk )
+      if ( ( block >> 3 ) >= xcd_chunk )
          return;
-      block = ( block & 7 ) * A.xcd_chunk + ( block >> 3 );
+      block = ( block & 7 ) * xcd_chunk + ( block >> 3 );
    }
    const int t = __builtin_amdgcn_readfirstlane( block * kRowsWaves + ( (int) threadIdx.x >> 6 ) );
-   if ( t >= A.ntiles )
+   if ( t >= ntiles )
       return;
-   const Tile tl   = A.tiles[t];
+   const Tile tl   = tiles[t];
    const int  lane = threadIdx.x & 63;
    const int  N    = A.F.N;
    const int  y = tl.ya, z = tl.z, x = tl.yb + lane;
@@ -901,10 +901,13 @@ __device__ inline void p2_rows_body( const P2RowsArgs& A, int block )
    }
    ( std::make_integer_sequence< int, 8 >{} );
 }
+// the three values a wave needs before it can fetch its tile are leading scalar arguments: the command processor preloads them
+// into SGPRs (-amdgpu-kernarg-preload-count=4), so the tile load does not wait for a kernel-argument load (as in the P1 apply;
+// here without a measurable difference: 41.0 vs 40.7 us at level 7)
 template < int UPDATE, bool RESTRICTED >
-__global__ __launch_bounds__( 64 * kRowsWaves, 2 ) void p2_rows_kernel( const P2RowsArgs A )
+__global__ __launch_bounds__( 64 * kRowsWaves, 2 ) void p2_rows_kernel( const Tile* tiles, int ntiles, int xcd_chunk, const P2RowsArgs A )
 {
-   p2_rows_body< UPDATE, RESTRICTED >( A, (int) blockIdx.x );
+   p2_rows_body< UPDATE, RESTRICTED >( A, tiles, ntiles, xcd_chunk, (int) blockIdx.x );
 }
 
 // Boundary DoFs in stencil form (levels >= 2): which adjacent micro-cells exist depends only on the macro-primitive the DoF
@@ -1006,7 +1009,8 @@ __global__ __launch_bounds__( kThreads ) void p2_boundary_kernel( const P2ClassA
 // instead of after them
 static_assert( kThreads == 64 * kRowsWaves, "the fused launch uses one block shape" );
 template < int UPDATE >
-__global__ __launch_bounds__( kThreads, 2 ) void p2_apply_fused_kernel( const P2RowsArgs A, unsigned shellMask, int nbx )
+__global__ __launch_bounds__( kThreads, 2 ) void p2_apply_fused_kernel( const Tile* tiles, int ntiles, int xcd_chunk, const P2RowsArgs A,
+                                                                        unsigned shellMask, int nbx )
 {
    if ( (int) blockIdx.x < 8 * nbx )
    {
@@ -1016,7 +1020,7 @@ __global__ __launch_bounds__( kThreads, 2 ) void p2_apply_fused_kernel( const P2
       p2_boundary_dispatch( B, (int) blockIdx.x / nbx, (int) blockIdx.x % nbx );
       return;
    }
-   p2_rows_body< UPDATE >( A, (int) blockIdx.x - 8 * nbx );
+   p2_rows_body< UPDATE >( A, tiles, ntiles, xcd_chunk, (int) blockIdx.x - 8 * nbx );
 }
 
 // host: does micro-cell (type t, index m) lie inside a macro-cell of width N?
@@ -1290,21 +1294,23 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell_kinds( double*            
             hipLaunchKernelGGL( p2_boundary_kernel, dim3( (unsigned) nbx, 8 ), dim3( kThreads ), 0, s, B );
          }
          if ( update == HYTEG_HIP_ADD )
-            hipLaunchKernelGGL( ( p2_rows_kernel< HYTEG_HIP_ADD, true > ), dim3( rowBlocks ), dim3( kThreads ), 0, s, R );
+            hipLaunchKernelGGL( ( p2_rows_kernel< HYTEG_HIP_ADD, true > ), dim3( rowBlocks ), dim3( kThreads ), 0, s, R.tiles, R.ntiles, R.xcd_chunk, R );
          else
-            hipLaunchKernelGGL( ( p2_rows_kernel< HYTEG_HIP_REPLACE, true > ), dim3( rowBlocks ), dim3( kThreads ), 0, s, R );
+            hipLaunchKernelGGL( ( p2_rows_kernel< HYTEG_HIP_REPLACE, true > ), dim3( rowBlocks ), dim3( kThreads ), 0, s, R.tiles, R.ntiles, R.xcd_chunk, R );
       }
       else if ( nb == 0 )
       {
          if ( update == HYTEG_HIP_ADD )
-            hipLaunchKernelGGL( ( p2_rows_kernel< HYTEG_HIP_ADD, false > ), dim3( rowBlocks ), dim3( kThreads ), 0, s, R );
+            hipLaunchKernelGGL( ( p2_rows_kernel< HYTEG_HIP_ADD, false > ), dim3( rowBlocks ), dim3( kThreads ), 0, s, R.tiles, R.ntiles, R.xcd_chunk, R );
          else
-            hipLaunchKernelGGL( ( p2_rows_kernel< HYTEG_HIP_REPLACE, false > ), dim3( rowBlocks ), dim3( kThreads ), 0, s, R );
+            hipLaunchKernelGGL( ( p2_rows_kernel< HYTEG_HIP_REPLACE, false > ), dim3( rowBlocks ), dim3( kThreads ), 0, s, R.tiles, R.ntiles, R.xcd_chunk, R );
       }
       else if ( update == HYTEG_HIP_ADD )
-         hipLaunchKernelGGL( p2_apply_fused_kernel< HYTEG_HIP_ADD >, dim3( 8 * nb + rowBlocks ), dim3( kThreads ), 0, s, R, shell, nb );
+         hipLaunchKernelGGL( p2_apply_fused_kernel< HYTEG_HIP_ADD >, dim3( 8 * nb + rowBlocks ), dim3( kThreads ), 0, s, R.tiles, R.ntiles, R.xcd_chunk, R, shell,
+                             nb );
       else
-         hipLaunchKernelGGL( p2_apply_fused_kernel< HYTEG_HIP_REPLACE >, dim3( 8 * nb + rowBlocks ), dim3( kThreads ), 0, s, R, shell, nb );
+         hipLaunchKernelGGL( p2_apply_fused_kernel< HYTEG_HIP_REPLACE >, dim3( 8 * nb + rowBlocks ), dim3( kThreads ), 0, s, R.tiles, R.ntiles, R.xcd_chunk, R, shell,
+                             nb );
       HH_CHECK_HIP( hipGetLastError() );
       return HYTEG_HIP_OK;
    }
