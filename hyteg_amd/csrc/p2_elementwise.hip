@@ -901,13 +901,150 @@ __device__ inline void p2_rows_body( const P2RowsArgs& A, const Tile* tiles, int
    }
    ( std::make_integer_sequence< int, 8 >{} );
 }
+// ---- the same with each source ROW loaded once (round 2, after the counters: 1.0 M load instructions per level-7 launch at
+// ~16 cycles each in the CU's address / L1 path are what the row kernel above is bound by -- TCP_TOTAL_CACHE_ACCESSES 18.4 M,
+// L1 hit rate 95 %, L1 -> L2 latency 260 cycles, 56 % of the wave cycles waiting for instructions).  The 89 sources are 44
+// distinct rows (kind, dy, dz) read at dx = -1, 0, +1: a wave loads each row once, lane l holding x0 - 1 + l, and takes the
+// x-neighbours from the neighbouring lanes (DPP wave shifts, as the P1 apply does); it produces 62 positions (lanes 1..62).
+// Same sources at the same addresses, same FMA order: bit-identical to p2_rows_body.
+struct RowList
+{
+   int      n;
+   int      kind[64], dy[64], dz[64];
+   unsigned users[64]; // destination kinds that read the row
+   int      ofSrc[160]; // row of source i
+};
+constexpr RowList build_row_list()
+{
+   RowList R{};
+   for ( int i = 0; i < kSrc.n; ++i )
+   {
+      int r = -1;
+      for ( int k = 0; k < R.n; ++k )
+         if ( R.kind[k] == kSrc.kind[i] && R.dy[k] == kSrc.dy[i] && R.dz[k] == kSrc.dz[i] )
+            r = k;
+      if ( r < 0 )
+      {
+         r         = R.n++;
+         R.kind[r] = kSrc.kind[i], R.dy[r] = kSrc.dy[i], R.dz[r] = kSrc.dz[i];
+      }
+      R.users[r] |= kSrcUsers.m[i];
+      R.ofSrc[i] = r;
+   }
+   return R;
+}
+constexpr RowList kRows = build_row_list();
+static_assert( kRows.n <= 64, "row list" );
+
+__device__ inline double p2_lane_minus_1( double v )
+{
+   int lo = __double2loint( v ), hi = __double2hiint( v );
+   lo     = __builtin_amdgcn_mov_dpp( lo, 0x138, 0xf, 0xf, true ); // wave_shr:1
+   hi     = __builtin_amdgcn_mov_dpp( hi, 0x138, 0xf, 0xf, true );
+   return __hiloint2double( hi, lo );
+}
+__device__ inline double p2_lane_plus_1( double v )
+{
+   int lo = __double2loint( v ), hi = __double2hiint( v );
+   lo     = __builtin_amdgcn_mov_dpp( lo, 0x130, 0xf, 0xf, true ); // wave_shl:1
+   hi     = __builtin_amdgcn_mov_dpp( hi, 0x130, 0xf, 0xf, true );
+   return __hiloint2double( hi, lo );
+}
+
+constexpr int kRowsDppCapacity = 62;
+
+template < int C, int UPDATE >
+__device__ inline void p2_rows_kind_dpp( const P2RowsArgs& A, const double ( &R )[kRows.n], const int ( &i0 )[3], int lane, int x, int y, int z,
+                                         int cnt, __amdgpu_buffer_rsrc_t rdV, __amdgpu_buffer_rsrc_t rdE )
+{
+   constexpr int NQ  = KindStencilOf< C >::value.n;
+   constexpr int OFF = stencil_offset( C );
+   typedef const __attribute__( ( address_space( 4 ) ) ) double* cptr_t;
+   const cptr_t w   = (cptr_t) ( A.F.table + OFF );
+   double       acc = 0.0;
+   [&]< int... Q >( std::integer_sequence< int, Q... > ) {
+      ( ( [&] {
+           constexpr int I  = SrcIndex< C >::value.idx[Q];
+           constexpr int DX = kSrc.dx[I];
+           const double  r  = R[kRows.ofSrc[I]];
+           const double  u  = DX == 0 ? r : ( DX > 0 ? p2_lane_plus_1( r ) : p2_lane_minus_1( r ) );
+           acc              = fma( w[Q], u, acc );
+        }() ),
+        ... );
+   }
+   ( std::make_integer_sequence< int, NQ >{} );
+   acc                 = A.F.alpha * acc;
+   const int  N        = A.F.N, n = N - 1;
+   constexpr int c     = C == 0 ? 0 : ( C == 7 ? 2 : 1 );
+   const int  bk       = C == 0 ? 0 : ( C - 1 ) * (int) tet32( (unsigned) n );
+   const bool on       = lane >= 1 && lane <= cnt && p2_inner< C >( N, x, y, z );
+   const int  voff     = on ? ( bk + i0[c] + lane - 1 ) * 8 : -8;
+   const __amdgpu_buffer_rsrc_t rd = C == 0 ? rdV : rdE;
+   if constexpr ( UPDATE == HYTEG_HIP_ADD )
+   {
+      const p2_v2i o = __builtin_amdgcn_raw_buffer_load_b64( rd, voff, 0, 0 );
+      acc            = __hiloint2double( o.y, o.x ) + acc;
+   }
+   __builtin_amdgcn_raw_buffer_store_b64( p2_v2i{ __double2loint( acc ), __double2hiint( acc ) }, rd, voff, 0, 0 );
+}
+
+template < int UPDATE, bool RESTRICTED = false >
+__device__ inline void p2_rows_body_dpp( const P2RowsArgs& A, const Tile* tiles, int ntiles, int xcd_chunk, int block )
+{
+   if ( xcd_chunk > 0 )
+   {
+      if ( ( block >> 3 ) >= xcd_chunk )
+         return;
+      block = ( block & 7 ) * xcd_chunk + ( block >> 3 );
+   }
+   const int t = __builtin_amdgcn_readfirstlane( block * kRowsWaves + ( (int) threadIdx.x >> 6 ) );
+   if ( t >= ntiles )
+      return;
+   const Tile tl   = tiles[t]; // capacity 62
+   const int  lane = threadIdx.x & 63;
+   const int  N    = A.F.N;
+   const int  y = tl.ya, z = tl.z, x = tl.yb - 1 + lane;
+   const int  i0[3] = { tl.a, tl.pad[0], tl.pad[1] };
+   const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc( const_cast< double* >( A.F.srcV ), 0, A.vbytes, 0x00020000 );
+   const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc( const_cast< double* >( A.F.srcE ), 0, A.ebytes, 0x00020000 );
+   const __amdgpu_buffer_rsrc_t rdV = __builtin_amdgcn_make_buffer_rsrc( A.F.dstV, 0, A.vbytes, 0x00020000 );
+   const __amdgpu_buffer_rsrc_t rdE = __builtin_amdgcn_make_buffer_rsrc( A.F.dstE, 0, A.ebytes, 0x00020000 );
+   const int lane8 = lane * 8;
+
+   double R[kRows.n];
+   [&]< int... I >( std::integer_sequence< int, I... > ) {
+      ( ( [&] {
+           constexpr int K = kRows.kind[I], DY = kRows.dy[I], DZ = kRows.dz[I];
+           double        u = 0.0;
+           if ( !RESTRICTED || ( kRows.users[I] & A.F.kinds ) )
+           {
+              // p2_rows_base is biased by one element: + lane8 addresses x0 - 1 + lane
+              const int    voff = p2_rows_base< K, DY, DZ >( i0, N, y, z ) + lane8;
+              const p2_v2i v    = __builtin_amdgcn_raw_buffer_load_b64( K == 0 ? rsV : rsE, voff, 0, 0 );
+              u                 = __hiloint2double( v.y, v.x );
+           }
+           R[I] = u;
+        }() ),
+        ... );
+   }
+   ( std::make_integer_sequence< int, kRows.n >{} );
+
+   [&]< int... C >( std::integer_sequence< int, C... > ) {
+      ( ( ( !RESTRICTED || ( ( A.F.kinds >> C ) & 1u ) ) ? p2_rows_kind_dpp< C, UPDATE >( A, R, i0, lane, x, y, z, tl.cnt, rdV, rdE ) : (void) 0 ), ... );
+   }
+   ( std::make_integer_sequence< int, 8 >{} );
+}
+
 // the three values a wave needs before it can fetch its tile are leading scalar arguments: the command processor preloads them
 // into SGPRs (-amdgpu-kernarg-preload-count=4), so the tile load does not wait for a kernel-argument load (as in the P1 apply;
 // here without a measurable difference: 41.0 vs 40.7 us at level 7)
-template < int UPDATE, bool RESTRICTED >
+template < int UPDATE, bool RESTRICTED, bool DPP = false >
 __global__ __launch_bounds__( 64 * kRowsWaves, 2 ) void p2_rows_kernel( const Tile* tiles, int ntiles, int xcd_chunk, const P2RowsArgs A )
 {
-   p2_rows_body< UPDATE, RESTRICTED >( A, tiles, ntiles, xcd_chunk, (int) blockIdx.x );
+   if constexpr ( DPP )
+      p2_rows_body_dpp< UPDATE, RESTRICTED >( A, tiles, ntiles, xcd_chunk, (int) blockIdx.x );
+   else
+      p2_rows_body< UPDATE, RESTRICTED >( A, tiles, ntiles, xcd_chunk, (int) blockIdx.x );
 }
 
 // Boundary DoFs in stencil form (levels >= 2): which adjacent micro-cells exist depends only on the macro-primitive the DoF
@@ -1008,7 +1145,7 @@ __global__ __launch_bounds__( kThreads ) void p2_boundary_kernel( const P2ClassA
 // -- thread per DoF, a long chain of index arithmetic and dependent loads -- come first and run beside the row waves
 // instead of after them
 static_assert( kThreads == 64 * kRowsWaves, "the fused launch uses one block shape" );
-template < int UPDATE >
+template < int UPDATE, bool DPP = false >
 __global__ __launch_bounds__( kThreads, 2 ) void p2_apply_fused_kernel( const Tile* tiles, int ntiles, int xcd_chunk, const P2RowsArgs A,
                                                                         unsigned shellMask, int nbx )
 {
@@ -1020,7 +1157,10 @@ __global__ __launch_bounds__( kThreads, 2 ) void p2_apply_fused_kernel( const Ti
       p2_boundary_dispatch( B, (int) blockIdx.x / nbx, (int) blockIdx.x % nbx );
       return;
    }
-   p2_rows_body< UPDATE >( A, tiles, ntiles, xcd_chunk, (int) blockIdx.x - 8 * nbx );
+   if constexpr ( DPP )
+      p2_rows_body_dpp< UPDATE >( A, tiles, ntiles, xcd_chunk, (int) blockIdx.x - 8 * nbx );
+   else
+      p2_rows_body< UPDATE >( A, tiles, ntiles, xcd_chunk, (int) blockIdx.x - 8 * nbx );
 }
 
 // host: does micro-cell (type t, index m) lie inside a macro-cell of width N?
@@ -1261,9 +1401,14 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell_kinds( double*            
    const bool rows  = ( mask & HYTEG_HIP_MASK_INNER ) && level >= 3 && !perThread;
    if ( rows )
    {
-      // inner DoFs by rows (p2_rows_body); the boundary DoFs, if asked for, in the same launch
+      // inner DoFs by rows (p2_rows_body_dpp: every source row loaded once, 62 positions per wave; HYTEG_HIP_P2_ROWS_DPP=0 selects
+      // p2_rows_body: every source loaded, 64 positions); the boundary DoFs, if asked for, in the same launch
+      static const bool dpp = [] {
+         const char* e = std::getenv( "HYTEG_HIP_P2_ROWS_DPP" );
+         return !( e && e[0] == '0' );
+      }();
       TileTable tt;
-      const int rc = get_tiles( level, TILES_ROWS, 64, &tt );
+      const int rc = get_tiles( level, TILES_ROWS, dpp ? kRowsDppCapacity : 64, &tt );
       if ( rc != HYTEG_HIP_OK )
          return rc;
       P2RowsArgs R;
@@ -1282,8 +1427,27 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell_kinds( double*            
          R.xcd_chunk = (int) ( ( rowBlocks + 7 ) / 8 );
          rowBlocks   = 8u * (unsigned) R.xcd_chunk;
       }
-      const unsigned shell     = mask & HYTEG_HIP_MASK_SHELL;
-      const int      nb        = shell ? nbx : 0;
+      const unsigned shell = mask & HYTEG_HIP_MASK_SHELL;
+      const int      nb    = shell ? nbx : 0;
+      const dim3     block( kThreads );
+#define P2_LAUNCH_ROWS( UPD, RES )                                                                                                            \
+   do                                                                                                                                          \
+   {                                                                                                                                           \
+      if ( dpp )                                                                                                                               \
+         hipLaunchKernelGGL( ( p2_rows_kernel< UPD, RES, true > ), dim3( rowBlocks ), block, 0, s, R.tiles, R.ntiles, R.xcd_chunk, R );      \
+      else                                                                                                                                     \
+         hipLaunchKernelGGL( ( p2_rows_kernel< UPD, RES, false > ), dim3( rowBlocks ), block, 0, s, R.tiles, R.ntiles, R.xcd_chunk, R );     \
+   } while ( 0 )
+#define P2_LAUNCH_FUSED( UPD )                                                                                                                 \
+   do                                                                                                                                          \
+   {                                                                                                                                           \
+      if ( dpp )                                                                                                                               \
+         hipLaunchKernelGGL( ( p2_apply_fused_kernel< UPD, true > ), dim3( 8 * nb + rowBlocks ), block, 0, s, R.tiles, R.ntiles, R.xcd_chunk, \
+                             R, shell, nb );                                                                                                   \
+      else                                                                                                                                     \
+         hipLaunchKernelGGL( ( p2_apply_fused_kernel< UPD, false > ), dim3( 8 * nb + rowBlocks ), block, 0, s, R.tiles, R.ntiles,            \
+                             R.xcd_chunk, R, shell, nb );                                                                                      \
+   } while ( 0 )
       if ( kind_mask != 0xFFu )
       {
          // some kinds only: the boundary DoFs (their kernel skips the other kinds) in their own launch, the rows restricted
@@ -1294,23 +1458,23 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell_kinds( double*            
             hipLaunchKernelGGL( p2_boundary_kernel, dim3( (unsigned) nbx, 8 ), dim3( kThreads ), 0, s, B );
          }
          if ( update == HYTEG_HIP_ADD )
-            hipLaunchKernelGGL( ( p2_rows_kernel< HYTEG_HIP_ADD, true > ), dim3( rowBlocks ), dim3( kThreads ), 0, s, R.tiles, R.ntiles, R.xcd_chunk, R );
+            P2_LAUNCH_ROWS( HYTEG_HIP_ADD, true );
          else
-            hipLaunchKernelGGL( ( p2_rows_kernel< HYTEG_HIP_REPLACE, true > ), dim3( rowBlocks ), dim3( kThreads ), 0, s, R.tiles, R.ntiles, R.xcd_chunk, R );
+            P2_LAUNCH_ROWS( HYTEG_HIP_REPLACE, true );
       }
       else if ( nb == 0 )
       {
          if ( update == HYTEG_HIP_ADD )
-            hipLaunchKernelGGL( ( p2_rows_kernel< HYTEG_HIP_ADD, false > ), dim3( rowBlocks ), dim3( kThreads ), 0, s, R.tiles, R.ntiles, R.xcd_chunk, R );
+            P2_LAUNCH_ROWS( HYTEG_HIP_ADD, false );
          else
-            hipLaunchKernelGGL( ( p2_rows_kernel< HYTEG_HIP_REPLACE, false > ), dim3( rowBlocks ), dim3( kThreads ), 0, s, R.tiles, R.ntiles, R.xcd_chunk, R );
+            P2_LAUNCH_ROWS( HYTEG_HIP_REPLACE, false );
       }
       else if ( update == HYTEG_HIP_ADD )
-         hipLaunchKernelGGL( p2_apply_fused_kernel< HYTEG_HIP_ADD >, dim3( 8 * nb + rowBlocks ), dim3( kThreads ), 0, s, R.tiles, R.ntiles, R.xcd_chunk, R, shell,
-                             nb );
+         P2_LAUNCH_FUSED( HYTEG_HIP_ADD );
       else
-         hipLaunchKernelGGL( p2_apply_fused_kernel< HYTEG_HIP_REPLACE >, dim3( 8 * nb + rowBlocks ), dim3( kThreads ), 0, s, R.tiles, R.ntiles, R.xcd_chunk, R, shell,
-                             nb );
+         P2_LAUNCH_FUSED( HYTEG_HIP_REPLACE );
+#undef P2_LAUNCH_ROWS
+#undef P2_LAUNCH_FUSED
       HH_CHECK_HIP( hipGetLastError() );
       return HYTEG_HIP_OK;
    }

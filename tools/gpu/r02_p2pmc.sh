@@ -1,0 +1,29 @@
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r02p2pmc
+mkdir -p $O
+i=0
+while read -r C; do
+  i=$((i+1))
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/s$i -- python3 $R/tools/bench_p2_apply.py --levels 7 --reps 5 > $O/s$i.log 2>&1 || echo "set $i failed: $C"
+done <<'SETS'
+SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM
+SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_WAIT_INST_LDS
+TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum
+TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
+TCP_TOTAL_CACHE_ACCESSES_sum TCP_TA_TCP_STATE_READ_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum
+TA_BUSY_avr TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
+SETS
+python3 - "$O" <<'PY'
+import csv, glob, sys, collections
+O = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(f"{O}/s*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "p2_rows_kernel<0, false>" in r["Kernel_Name"] or "p2_rows_kernel<0,false>" in r["Kernel_Name"]:
+            agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, cs in agg.items():
+    print(k)
+    for c, v in sorted(cs.items()):
+        print(f"   {c:40s} n={len(v):4d} mean={sum(v)/len(v):16.1f}")
+PY
