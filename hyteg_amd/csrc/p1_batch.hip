@@ -224,14 +224,15 @@ __global__ __launch_bounds__( kThreads ) void batch_dot_kernel( const DotB A )
    __shared__ bool last;
    if ( threadIdx.x == 0 )
    {
-      A.partial[blockIdx.x] = r;
-      __threadfence(); // the partial sum is visible device-wide (the XCDs do not share an L2) before the ticket is taken
-      last = atomicAdd( A.counter, 1u ) == gridDim.x - 1;
+      // written through to memory (agent-scope store: the XCDs do not share an L2) and acknowledged before the ticket is taken;
+      // no release fence -- that is an L2 write-back per workgroup on this architecture (see dot_finish in p1_vector.hip)
+      __hip_atomic_store( A.partial + blockIdx.x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+      asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+      last = __hip_atomic_fetch_add( A.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) == gridDim.x - 1;
    }
    __syncthreads();
    if ( !last )
       return;
-   __threadfence();
    double sum = 0.0;
    for ( int k = threadIdx.x; k < (int) gridDim.x; k += kThreads )
       sum += __hip_atomic_load( A.partial + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
@@ -239,8 +240,8 @@ __global__ __launch_bounds__( kThreads ) void batch_dot_kernel( const DotB A )
    const double grand = block_sum_b( sum, sh );
    if ( threadIdx.x == 0 )
    {
-      *A.result  = grand;
-      *A.counter = 0u;
+      *A.result = grand;
+      __hip_atomic_store( A.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
       if ( A.cg )
          cg_scalars_update( A.cg, A.cgPhase, A.relTol, A.absTol );
    }

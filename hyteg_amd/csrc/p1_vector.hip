@@ -156,6 +156,36 @@ __device__ inline double block_sum( double v, double* sh /* >= kThreads/64 */ )
    return r; // valid in thread 0
 }
 
+// One launch: every workgroup writes its partial sum through to memory (agent-scope store: the 8 XCDs do not share an L2),
+// waits until the store is acknowledged and takes a ticket; the workgroup that draws the last ticket reduces the partial sums,
+// in the same fixed order whichever it is (the order of p1_dot_final_kernel).  No release fence: on this architecture a
+// device-scope fence is an L2 write-back per workgroup (round 1 measured 38.5 instead of 12.8 us for a level-8 dot with ~1000
+// workgroups in one launch).  Without fences the one-launch form at that size costs 15.2 against 11.6 us for two launches, so it
+// stays reserved for few workgroups.
+__device__ inline void dot_finish( double r, double* partial, unsigned* counter, double* result, double* sh )
+{
+   __shared__ bool last;
+   if ( threadIdx.x == 0 )
+   {
+      __hip_atomic_store( partial + blockIdx.x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+      asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+      last = __hip_atomic_fetch_add( counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) == gridDim.x - 1;
+   }
+   __syncthreads();
+   if ( !last )
+      return;
+   double sum = 0.0;
+   for ( int k = threadIdx.x; k < (int) gridDim.x; k += kThreads )
+      sum += __hip_atomic_load( partial + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+   __syncthreads(); // sh is reused
+   const double grand = block_sum( sum, sh );
+   if ( threadIdx.x == 0 )
+   {
+      *result = grand;
+      __hip_atomic_store( counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+   }
+}
+
 __global__ __launch_bounds__( kThreads ) void p1_dot_partial_kernel( const double* __restrict__ a,
                                                                       const double* __restrict__ b,
                                                                       const Tile* tiles,
@@ -195,28 +225,7 @@ __global__ __launch_bounds__( kThreads ) void p1_dot_partial_kernel( const doubl
          partial[blockIdx.x] = r;
       return;
    }
-   // one launch: the workgroup that finishes last reduces the partial sums, in the same fixed order whichever it is
-   __shared__ bool last;
-   if ( threadIdx.x == 0 )
-   {
-      partial[blockIdx.x] = r;
-      __threadfence(); // visible device-wide (the XCDs do not share an L2) before the ticket is taken
-      last = atomicAdd( counter, 1u ) == gridDim.x - 1;
-   }
-   __syncthreads();
-   if ( !last )
-      return;
-   __threadfence();
-   double sum = 0.0;
-   for ( int k = threadIdx.x; k < (int) gridDim.x; k += kThreads )
-      sum += __hip_atomic_load( partial + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-   __syncthreads(); // sh is reused
-   const double grand = block_sum( sum, sh );
-   if ( threadIdx.x == 0 )
-   {
-      *result  = grand;
-      *counter = 0u;
-   }
+   dot_finish( r, partial, counter, result, sh );
 }
 
 // Dot product over the inner points enumerated by the brick tasks of the z-march apply (NY rows x nz slices x 62 lanes):
@@ -226,8 +235,10 @@ template < int NY >
 __global__ __launch_bounds__( kThreads ) void p1_dot_brick_kernel( const double* __restrict__ a,
                                                                     const double* __restrict__ b,
                                                                     const BrickTask* __restrict__ tasks,
-                                                                    int     ntasks,
-                                                                    double* partial )
+                                                                    int       ntasks,
+                                                                    double*   partial,
+                                                                    unsigned* counter,
+                                                                    double*   result )
 {
    __shared__ double sh[kThreads / 64];
    const int         lane = threadIdx.x & 63;
@@ -262,8 +273,13 @@ __global__ __launch_bounds__( kThreads ) void p1_dot_brick_kernel( const double*
       }
    }
    const double r = block_sum( acc, sh );
-   if ( threadIdx.x == 0 )
-      partial[blockIdx.x] = r;
+   if ( result == nullptr )
+   {
+      if ( threadIdx.x == 0 )
+         partial[blockIdx.x] = r;
+      return;
+   }
+   dot_finish( r, partial, counter, result, sh );
 }
 
 __global__ __launch_bounds__( kThreads ) void p1_dot_final_kernel( const double* partial, int n, double* result )
@@ -367,7 +383,10 @@ HYTEG_HIP_API int hyteg_hip_p1_dot_cell( const double*      a,
       if ( rc != HYTEG_HIP_OK )
          return rc;
       const int nb = std::min( kDotBlocks, ( bt.count + kThreads / 64 - 1 ) / ( kThreads / 64 ) );
-      hipLaunchKernelGGL( p1_dot_brick_kernel< 4 >, dim3( nb ), dim3( kThreads ), 0, as_stream( stream ), a, b, bt.dev, bt.count, partial );
+      // two launches: with ~500 workgroups the one-launch form (dot_finish) is slower -- 15.2 vs 11.6 us at level 8: every
+      // workgroup ends with a write-through store, its acknowledgement and a ticket, and the last one reads 500 partial sums
+      hipLaunchKernelGGL( p1_dot_brick_kernel< 4 >, dim3( nb ), dim3( kThreads ), 0, as_stream( stream ), a, b, bt.dev, bt.count, partial,
+                          (unsigned*) nullptr, (double*) nullptr );
       hipLaunchKernelGGL( p1_dot_final_kernel, dim3( 1 ), dim3( kThreads ), 0, as_stream( stream ), partial, nb, result_dev );
       HH_CHECK_HIP( hipGetLastError() );
       return HYTEG_HIP_OK;
@@ -375,9 +394,7 @@ HYTEG_HIP_API int hyteg_hip_p1_dot_cell( const double*      a,
    const int nblocks = tt.count < kDotBlocks ? ( tt.count > 0 ? tt.count : 1 ) : kDotBlocks;
    if ( nblocks <= kDotSingleLaunchBlocks )
    {
-      // few workgroups (coarse levels): the one that finishes last reduces the partial sums -- one launch.  With ~1000
-      // workgroups the tickets (device-scope atomics on one address, ~25 ns each) cost more than a second launch:
-      // measured 38.5 vs 12.8 us at level 8.
+      // few workgroups (coarse levels): the one that finishes last reduces the partial sums -- one launch (dot_finish)
       unsigned* counter = nullptr;
       rc                = dot_counter( as_stream( stream ), &counter );
       if ( rc != HYTEG_HIP_OK )
