@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <map>
 #include <mutex>
+#include <tuple>
 #include <vector>
 
 #include <atomic>
@@ -275,6 +276,31 @@ struct SorBlockTable
    std::vector< int > wavefrontStart; // size nwavefronts + 1
 };
 
+// the non-empty blocks of a level by block wavefront T = P + Q + R (entries of byT may be empty)
+static std::vector< std::vector< SorBlock > > sor_blocks_by_wavefront( int level )
+{
+   const int n  = 1 << level;
+   const int nb = ( n + kB - 1 ) / kB;
+   std::vector< std::vector< SorBlock > > byT( 3 * nb );
+   for ( int R = 0; R < nb; ++R )
+      for ( int Q = R; Q < nb; ++Q )
+         for ( int P = Q; P < nb; ++P )
+         {
+            // non-empty iff some interior point: r>=1, q>=r+1, p>=q+1, p<=n-1 within the block ranges
+            const int rmin = std::max( 1, R * kB ), rmax = std::min( n - 3, R * kB + kB - 1 );
+            if ( rmin > rmax )
+               continue;
+            const int qmin = std::max( rmin + 1, Q * kB ), qmax = std::min( n - 2, Q * kB + kB - 1 );
+            if ( qmin > qmax )
+               continue;
+            const int pmin = std::max( qmin + 1, P * kB ), pmax = std::min( n - 1, P * kB + kB - 1 );
+            if ( pmin > pmax )
+               continue;
+            byT[P + Q + R].push_back( SorBlock{ (short) P, (short) Q, (short) R, 0 } );
+         }
+   return byT;
+}
+
 int get_sor_blocks( int level, const SorBlockTable** out )
 {
    static std::mutex                                   mtx;
@@ -286,25 +312,7 @@ int get_sor_blocks( int level, const SorBlockTable** out )
    auto                          it  = cache.find( key );
    if ( it == cache.end() )
    {
-      const int n  = 1 << level;
-      const int nb = ( n + kB - 1 ) / kB;
-      std::vector< std::vector< SorBlock > > byT( 3 * nb );
-      for ( int R = 0; R < nb; ++R )
-         for ( int Q = R; Q < nb; ++Q )
-            for ( int P = Q; P < nb; ++P )
-            {
-               // non-empty iff some interior point: r>=1, q>=r+1, p>=q+1, p<=n-1 within the block ranges
-               const int rmin = std::max( 1, R * kB ), rmax = std::min( n - 3, R * kB + kB - 1 );
-               if ( rmin > rmax )
-                  continue;
-               const int qmin = std::max( rmin + 1, Q * kB ), qmax = std::min( n - 2, Q * kB + kB - 1 );
-               if ( qmin > qmax )
-                  continue;
-               const int pmin = std::max( qmin + 1, P * kB ), pmax = std::min( n - 1, P * kB + kB - 1 );
-               if ( pmin > pmax )
-                  continue;
-               byT[P + Q + R].push_back( SorBlock{ (short) P, (short) Q, (short) R, 0 } );
-            }
+      const std::vector< std::vector< SorBlock > > byT = sor_blocks_by_wavefront( level );
       SorBlockTable           tab;
       std::vector< SorBlock > flat;
       tab.wavefrontStart.push_back( 0 );
@@ -328,6 +336,60 @@ int get_sor_blocks( int level, const SorBlockTable** out )
    return HYTEG_HIP_OK;
 }
 
+
+// Several consecutive sweeps of the same direction as ONE pipeline of launches.  A sweep alone is 46 launches at level 8, each
+// with at most 36 of the 256 CUs busy.  Sweep s + 1 may process a block as soon as sweep s is done with every block it reads old
+// values from -- the blocks B + (a,b,c), a,b,c in {0,1}, i.e. up to wavefront T(B) + 3 -- and sweep s never reads a block that
+// sweep s + 1 has already touched as long as sweep s + 1 stays at least 4 wavefronts behind.  So step tau of the pipeline
+// launches the blocks of wavefront tau - 4 s of every sweep s in one grid: S sweeps take 46 + 4 ( S - 1 ) launches instead of
+// 46 S, with the same arithmetic in the same order per point (bit-identical to S calls of the sweep).
+constexpr int kSorSweepLag = 4;
+struct SorPipelineTable
+{
+   const SorBlock*    dev = nullptr;
+   std::vector< int > stepStart; // size nsteps + 1
+};
+int get_sor_pipeline( int level, int nsweeps, bool backwards, const SorPipelineTable** out )
+{
+   static std::mutex                                                    mtx;
+   static std::map< std::tuple< int, int, int, bool >, SorPipelineTable > cache;
+   int                                                                  dev = 0;
+   HH_CHECK_HIP( hipGetDevice( &dev ) );
+   std::lock_guard< std::mutex > lock( mtx );
+   auto                          key = std::make_tuple( dev, level, nsweeps, backwards );
+   auto                          it  = cache.find( key );
+   if ( it == cache.end() )
+   {
+      const std::vector< std::vector< SorBlock > > byT = sor_blocks_by_wavefront( level );
+      const int                                    nT  = (int) byT.size();
+      SorPipelineTable                             tab;
+      std::vector< SorBlock >                      flat;
+      tab.stepStart.push_back( 0 );
+      for ( int tau = 0; tau < nT + kSorSweepLag * ( nsweeps - 1 ); ++tau )
+      {
+         for ( int sw = 0; sw < nsweeps; ++sw )
+         {
+            const int k = tau - kSorSweepLag * sw; // position of sweep sw in its own order
+            if ( k < 0 || k >= nT )
+               continue;
+            const auto& v = byT[(size_t) ( backwards ? nT - 1 - k : k )];
+            flat.insert( flat.end(), v.begin(), v.end() );
+         }
+         if ( (int) flat.size() > tab.stepStart.back() )
+            tab.stepStart.push_back( (int) flat.size() );
+      }
+      if ( !flat.empty() )
+      {
+         void* p = nullptr;
+         HH_CHECK_HIP( hipMalloc( &p, flat.size() * sizeof( SorBlock ) ) );
+         HH_CHECK_HIP( hipMemcpy( p, flat.data(), flat.size() * sizeof( SorBlock ), hipMemcpyHostToDevice ) );
+         tab.dev = static_cast< const SorBlock* >( p );
+      }
+      it = cache.emplace( key, std::move( tab ) ).first;
+   }
+   *out = &it->second;
+   return HYTEG_HIP_OK;
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // Levels <= 5 of a batch: the whole cell array (<= 6,545 entries) lives in LDS and ONE workgroup runs all hyperplanes
@@ -509,6 +571,60 @@ HYTEG_HIP_API int hyteg_hip_p1_sor_cells( int                  ncells,
          hipLaunchKernelGGL( p1_sor_block_batch_kernel, dim3( hi - lo, e - k + 1 ), dim3( kB * kB ), 0, as_stream( stream ), B );
       }
       k = e + 1;
+   }
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_p1_sor_cell_sweeps( double*            u,
+                                                const double*      rhs,
+                                                int                level,
+                                                const double*      w,
+                                                double             relax,
+                                                int                backwards,
+                                                int                nsweeps,
+                                                hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( u && rhs && w, "p1_sor_cell_sweeps: null pointer" );
+   HH_REQUIRE( level_ok( level ), "p1_sor_cell_sweeps: level out of range [2,11]" );
+   HH_REQUIRE( u != rhs, "p1_sor_cell_sweeps: u and rhs must not alias" );
+   HH_REQUIRE( w[7] != 0.0, "p1_sor_cell_sweeps: zero centre weight" );
+   HH_REQUIRE( nsweeps >= 0 && nsweeps <= 64, "p1_sor_cell_sweeps: nsweeps must be 0..64" );
+   static const bool pipeline = [] {
+      const char* e = std::getenv( "HYTEG_HIP_SOR_PIPELINE" ); // 0: one sweep after the other
+      return !( e && e[0] == '0' );
+   }();
+   const int algo = g_sorAlgorithm.load( std::memory_order_relaxed );
+   if ( nsweeps <= 1 || !pipeline || level < 5 || use_dataflow( level ) || algo == HYTEG_HIP_SOR_PLANES )
+   {
+      for ( int k = 0; k < nsweeps; ++k )
+      {
+         const int rc = hyteg_hip_p1_sor_cell( u, rhs, level, w, relax, backwards, stream );
+         if ( rc != HYTEG_HIP_OK )
+            return rc;
+      }
+      return HYTEG_HIP_OK;
+   }
+   const SorPipelineTable* tab = nullptr;
+   int                     rc  = get_sor_pipeline( level, nsweeps, backwards != 0, &tab );
+   if ( rc != HYTEG_HIP_OK )
+      return rc;
+   SorBlockArgs B;
+   B.u               = u;
+   B.rhs             = rhs;
+   B.N               = ( 1 << level ) + 1;
+   B.backwards       = backwards ? 1 : 0;
+   B.relax           = relax;
+   B.one_minus_relax = 1.0 + ( -relax );
+   B.invc            = 1.0 / w[7];
+   for ( int k = 0; k < 15; ++k )
+      B.st.w[k] = w[k];
+   const int nsteps = (int) tab->stepStart.size() - 1;
+   for ( int k = 0; k < nsteps; ++k )
+   {
+      const int lo = tab->stepStart[k], hi = tab->stepStart[k + 1];
+      B.blocks     = tab->dev + lo;
+      hipLaunchKernelGGL( p1_sor_block_kernel, dim3( hi - lo ), dim3( kB * kB ), 0, as_stream( stream ), B );
    }
    HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;

@@ -173,6 +173,34 @@ class P1ConstantOperator
       } );
    }
 
+   // `steps` consecutive sweeps of smooth_sor (what a multigrid cycle's pre- / post-smoothing loop does,
+   // GeometricMultigridSolver.hpp:209-215).  Where no shared or boundary point is swept (every macro-cell's shell is fixed: one
+   // macro-cell with Dirichlet values, or cells whose common faces are not selected by the flag) the sweeps of a cell do not
+   // see anybody else's updates in between, and from level 5 on they run as one pipeline of block wavefronts
+   // (hyteg_hip_p1_sor_cell_sweeps: bit-identical to the loop, 46 + 4 ( steps - 1 ) launches instead of 46 steps at level 8).
+   void smooth_sor_steps( const P1Function< double >& dst, const P1Function< double >& rhs, double relax, uint_t level, DoFType flagIn,
+                          uint_t steps, bool backwards = false ) const
+   {
+      const DoFType flag     = dst.effectiveFlag( flagIn );
+      bool          anyShell = false;
+      forCells( [&]( uint_t, const MacroCell& cell ) { anyShell = anyShell || ( storage_->maskFor( cell, flag ) & HYTEG_HIP_MASK_SHELL ); } );
+      if ( steps <= 1 || anyShell || storage_->numRanks() != 1 || storage_->useBatchSor( level ) || level < 5 )
+      {
+         for ( uint_t k = 0; k < steps; ++k )
+            smooth_sor( dst, rhs, relax, level, flagIn, backwards );
+         return;
+      }
+      ScopedTimer timerOp( storage_->getTimingTree(), "Operator P1Function to P1Function" ), timerSor( storage_->getTimingTree(), backwards ? "SOR backwards" : "SOR" );
+      if ( &dst == &rhs )
+         throw std::runtime_error( "smooth_sor: dst and rhs must differ" );
+      forCells( [&]( uint_t c, const MacroCell& cell ) {
+         if ( storage_->maskFor( cell, flag ) & HYTEG_HIP_MASK_INNER )
+            hipCheck( hyteg_hip_p1_sor_cell_sweeps( dst.getCellPointer( c, level ), rhs.getCellPointer( c, level ), (int) level,
+                                                    getCellStencils( cell.id, level ).inner, relax, backwards ? 1 : 0, (int) steps,
+                                                    storage_->stream() ),
+                      "smooth_sor_steps: cell" );
+      } );
+   }
    // P1Operator::smooth_sor / smooth_gs, P1Operator.hpp:322-418: macro-vertices, -edges, -faces, -cells (reversed for
    // backwards), each class with the values the reference's communication schedule gives it.  Cell-centric form:
    //  rest  = (stencil sum over the neighbours outside the primitive's closure), summed over cells by ONE exchange,

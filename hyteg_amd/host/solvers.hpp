@@ -182,6 +182,14 @@ class SORSmoother : public Solver< OperatorType >
       else
          Solver< OperatorType >::solveMany( A, xs, bs, level );
    }
+   // the `steps` sweeps of a pre- / post-smoothing phase at once: pipelined where the operator can (smooth_sor_steps)
+   void solveSteps( const OperatorType& A, const FunctionType& x, const FunctionType& b, uint_t level, uint_t steps ) override
+   {
+      if constexpr ( std::is_same< FunctionType, P1Function< double > >::value )
+         A.smooth_sor_steps( x, b, relax_, level, flag_, steps );
+      else
+         Solver< OperatorType >::solveSteps( A, x, b, level, steps );
+   }
 
  private:
    double  relax_;

@@ -201,6 +201,19 @@ HYTEG_HIP_API int hyteg_hip_p1_sor_cell( double*            u,
                                          double             relax,
                                          int                backwards,
                                          hyteg_hip_stream_t stream );
+/* nsweeps consecutive sweeps of the same direction: what a smoother's pre- / post-smoothing loop does to a macro-cell
+ * whose boundary values do not change between the sweeps (GeometricMultigridSolver.hpp:209-215 calling
+ * P1ConstantOperator::smooth_sor).  Same result, bit for bit, as nsweeps calls of hyteg_hip_p1_sor_cell; from level 5 on
+ * the sweeps run as one pipeline of block wavefronts (sweep s + 1 four wavefronts behind sweep s), 46 + 4 ( nsweeps - 1 )
+ * launches instead of 46 nsweeps at level 8. */
+HYTEG_HIP_API int hyteg_hip_p1_sor_cell_sweeps( double*            u,
+                                                const double*      rhs,
+                                                int                level,
+                                                const double*      w /* host, 15 */,
+                                                double             relax,
+                                                int                backwards,
+                                                int                nsweeps,
+                                                hyteg_hip_stream_t stream );
 
 /* ---- a6: vector kernels on the cell interior ---------------------------------------------------------
  * assign:  dst = sum_k c_k src_k      replaces assign_3D_macrocell_vertexdof_{1,2,3}_rhs_function(s)

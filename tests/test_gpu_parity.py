@@ -222,6 +222,30 @@ def test_sor_level8_default_form_vs_the_sequential_oracle(env, relax, backwards)
     assert _rel(u.cpu().numpy(), ref) < 1e-12
 
 
+@pytest.mark.parametrize("level,nsweeps,relax,backwards", [(5, 3, 1.0, False), (6, 2, 1.0, True), (7, 3, 0.8, False), (8, 3, 1.0, False),
+                                                             (8, 4, 1.3, True), (4, 3, 1.0, False)])
+def test_pipelined_sweeps_equal_consecutive_sweeps_bit_for_bit(env, level, nsweeps, relax, backwards):
+    """hyteg_hip_p1_sor_cell_sweeps: n sweeps as one pipeline of block wavefronts (sweep s + 1 four wavefronts behind sweep s) must
+    give exactly the bits of n calls of hyteg_hip_p1_sor_cell, which the tests above compare with the sequential oracle
+    (level 4: no pipeline, the entry point loops)."""
+    torch, capi, po = env
+    rng = np.random.default_rng(500 + level + nsweeps)
+    w = po.assemble_cell_stencil(SKEW_TET, level)
+    n = po.cell_size(level)
+    u_h, rhs_h = rng.random(n), rng.random(n) * w[7]
+    a, b, rhs = _dev(torch, u_h), _dev(torch, u_h), _dev(torch, rhs_h)
+    for _ in range(nsweeps):
+        capi.p1_sor_cell(a.data_ptr(), rhs.data_ptr(), level, w, relax, backwards, _stream(torch))
+    capi.p1_sor_cell_sweeps(b.data_ptr(), rhs.data_ptr(), level, w, relax, nsweeps, backwards, _stream(torch))
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    if level <= 6:  # and directly against the sequential oracle
+        ref = u_h.copy()
+        for _ in range(nsweeps):
+            po.sor_cell(ref, rhs_h, level, w, relax, backwards, fast=False)
+        assert _rel(b.cpu().numpy(), ref) < 1e-12
+
+
 @pytest.mark.parametrize("level", [2, 4, 6])
 def test_vector_kernels(env, level):
     torch, capi, po = env

@@ -89,6 +89,10 @@ def main():
         timeit(f"SOR backward sweep ({name})", lambda k: capi.p1_sor_cell(p(B, k), p(A, k), L, w, 1.0, True, sh), 24 * inner, inner,
                r=max(3, reps // 40))
     capi.set_sor_algorithm(capi.SOR_AUTO)
+    # the sweeps of a smoothing phase as one pipeline of block wavefronts (bytes / DoFs of ALL the sweeps of a call)
+    for ns in (2, 3, 4):
+        timeit(f"SOR {ns} forward sweeps, pipelined (per call)", lambda k: capi.p1_sor_cell_sweeps(p(B, k), p(A, k), L, w, 1.0, ns, False, sh),
+               ns * 24 * inner, ns * inner, r=max(3, reps // 40))
     # Gauss-Seidel on the cell's macro-vertices/-edges/-faces (what a multi-cell sweep adds per cell); octahedron weights
     sys.path.insert(0, str(ROOT / "tests"))
     import hostutil as hu  # noqa: E402
