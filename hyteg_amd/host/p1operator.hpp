@@ -247,7 +247,7 @@ class P1ConstantOperator
          restSlot.reset( new P1Function< double >( "sor_rest", storage_, level, level ) );
       P1Function< double >& rest = *restSlot;
       auto                 sweepShell = [&]( unsigned bits ) {
-         if ( storage_->useBatch( level ) )
+         if ( storage_->useBatchSor( level ) )
          {
             const auto masks = storage_->masksFor( flag, false, bits & HYTEG_HIP_MASK_SHELL );
             storage_->forCellChunks( [&]( int first, int count ) {
@@ -266,7 +266,7 @@ class P1ConstantOperator
                       "smooth_sor: rest" );
          } );
          rest.sumSharedCopies( level, flag );
-         if ( storage_->useBatch( level ) )
+         if ( storage_->useBatchSor( level ) )
          {
             const auto masks = storage_->masksFor( flag, false, bits & HYTEG_HIP_MASK_SHELL );
             storage_->forCellChunks( [&]( int first, int count ) {

@@ -211,9 +211,20 @@ class PrimitiveStorage
       return localCells_.size() > 1 && (int) level <= batchMaxLevel_;
    }
    // the one-workgroup Gauss-Seidel sweep of small cells (levels <= 5) also pays off for a single cell: 1 launch instead of ~3n
+   // The macro-cell sweep of SOR / Gauss-Seidel: also above the batch level the cells of a rank share their launches -- a cell's
+   // sweep is 46 dependent launches at level 8 with at most 36 workgroups each, so eight cells one after the other leave the GPU
+   // idle eight times as long as eight cells per launch (hyteg_hip_p1_sor_cells: grid.y = cell).  HYTEG_AMD_BATCH_SOR_ALL=0: only
+   // up to the batch level, as for the other kernels.
    bool useBatchSor( uint_t level ) const
    {
-      return useBatch( level ) || ( !localCells_.empty() && level <= 5 && batchMaxLevel_ >= 0 && (int) level <= batchMaxLevel_ );
+      if ( useBatch( level ) || ( !localCells_.empty() && level <= 5 && batchMaxLevel_ >= 0 && (int) level <= batchMaxLevel_ ) )
+         return true;
+      static const bool all = [] {
+         const char* e = std::getenv( "HYTEG_AMD_BATCH_SOR_ALL" );
+         return !( e && e[0] == '0' );
+      }();
+      useBatch( level ); // reads HYTEG_AMD_BATCH_MAX_LEVEL on first use
+      return all && localCells_.size() > 1 && batchMaxLevel_ >= 0 && level <= 10;
    }
    void setBatchMaxLevel( int l ) { batchMaxLevel_ = l; }
    std::vector< unsigned > masksFor( DoFType flag, bool owned = false, unsigned keep = HYTEG_HIP_MASK_ALL ) const
