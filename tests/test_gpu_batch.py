@@ -169,6 +169,19 @@ def test_vcycle_with_batched_kernels_equals_the_per_cell_kernels(env, mesh, lo, 
     assert abs(db - dc) <= 1e-9 * abs(dc)
 
 
+def test_gauss_seidel_sweeps_shared_between_cells_above_the_batch_level(env):
+    """Above the batch level only the Gauss-Seidel / SOR sweeps (macro-cell sweep, rest, shell sweeps) share their launches
+    between the cells of a rank (PrimitiveStorage::useBatchSor): a V(2,2) cycle over levels 6-7 of a 2-cell mesh with the batch
+    level at 5 against the same cycle with per-cell launches throughout."""
+    torch, capi, host, po = env
+    xb, rb, db = _vcycle(host, "pyramid_2el", 6, 7, host.GAUSS_SEIDEL, 5)
+    xc, rc, dc = _vcycle(host, "pyramid_2el", 6, 7, host.GAUSS_SEIDEL, -1)
+    scale = max(np.abs(a).max() for a in xc)
+    for a, b in zip(xb, xc):
+        assert np.abs(a - b).max() <= 1e-11 * scale
+    assert abs(db - dc) <= 1e-9 * abs(dc)
+
+
 @pytest.mark.parametrize("level", [2, 3, 4, 5, 6])
 @pytest.mark.parametrize("backwards", [False, True])
 def test_sor_cells_match_the_per_cell_sweeps(env, level, backwards):

@@ -1,7 +1,4 @@
 set -e
 O=$GRAFT_REPO_ROOT/gpurun_out/r02batchsor; mkdir -p $O
-timeout -k 10 900 python -m pytest tests/test_gpu_host.py tests/test_gpu_sor_shell.py tests/test_gpu_batch.py tests/test_gpu_large_levels.py -x -q -m gpu > $O/pytest.txt 2>&1 || { tail -40 $O/pytest.txt; exit 1; }
+timeout -k 10 900 python -m pytest tests/test_gpu_batch.py -x -q -m gpu -k "shared_between or vcycle" > $O/pytest.txt 2>&1 || { tail -40 $O/pytest.txt; exit 1; }
 tail -2 $O/pytest.txt
-timeout -k 10 300 python tools/vcycle_breakdown.py --mesh regular_octahedron_8el --max 7 2>&1 | grep -v amdgpu.ids | tail -8
-echo "--- HYTEG_AMD_BATCH_SOR_ALL=0"
-HYTEG_AMD_BATCH_SOR_ALL=0 timeout -k 10 300 python tools/vcycle_breakdown.py --mesh regular_octahedron_8el --max 7 2>&1 | grep -v amdgpu.ids | tail -8
