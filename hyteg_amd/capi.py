@@ -81,6 +81,7 @@ SIGNATURES = {
     "hyteg_hip_p1_dot_cell_masked": (_i, [_vp, _vp, _i, C.c_uint, _vp, _vp, _vp]),
     "hyteg_hip_p1_restrict_cell_masked": (_i, [_vp, _vp, _i, _dp, C.c_uint, _vp]),
     "hyteg_hip_p1_prolongate_cell_masked": (_i, [_vp, _vp, _i, _dp, C.c_uint, _vp]),
+    "hyteg_hip_p1_prolongate_cell_masked_update": (_i, [_vp, _vp, _i, _dp, C.c_uint, _i, _vp]),
     "hyteg_hip_sum_shared": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "hyteg_hip_copy_shared": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "hyteg_hip_p1_copy_face_to_cell": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -707,6 +707,17 @@ HYTEG_HIP_API int hyteg_hip_p1_prolongate_cell_masked( const double*      coarse
    return prolongate_impl( coarse, fine, coarse_level, nnc, HYTEG_HIP_REPLACE, mask, stream );
 }
 
+HYTEG_HIP_API int hyteg_hip_p1_prolongate_cell_masked_update( const double*      coarse,
+                                                              double*            fine,
+                                                              int                coarse_level,
+                                                              const double*      nnc,
+                                                              unsigned           mask,
+                                                              int                update,
+                                                              hyteg_hip_stream_t stream )
+{
+   return prolongate_impl( coarse, fine, coarse_level, nnc, update, mask, stream );
+}
+
 static int prolongate_impl( const double* coarse, double* fine, int coarse_level, const double* nnc, int update, unsigned mask,
                             hyteg_hip_stream_t stream )
 {

@@ -14,6 +14,13 @@ class P1toP1LinearRestriction
  public:
    void restrict( const P1Function< double >& function, const uint_t& sourceLevel, const DoFType& flagIn ) const
    {
+      restrictInto( function, function, sourceLevel, flagIn );
+   }
+   // restriction of `fineFunction` at sourceLevel into `function` at sourceLevel - 1: what a multigrid cycle does with
+   // restrict( tmp ) followed by b.assign( { 1 }, { tmp }, sourceLevel - 1 ) (GeometricMultigridSolver.hpp:262-266), without the copy
+   void restrictInto( const P1Function< double >& fineFunction, const P1Function< double >& function, const uint_t& sourceLevel,
+                      const DoFType& flagIn ) const
+   {
       ScopedTimer timerRestrict( function.getStorage()->getTimingTree(), "P1toP1LinearRestriction" );
       const DoFType flag = function.effectiveFlag( flagIn ); // the function's boundary condition decides what `Inner` means
       auto         storage = function.getStorage();
@@ -22,7 +29,7 @@ class P1toP1LinearRestriction
       {
          const auto masks = storage->masksFor( flag );
          storage->forCellChunks( [&]( int first, int count ) {
-            const auto co = function.cellPointers( dstLevel, first, count ), fi = function.cellPointers( sourceLevel, first, count );
+            const auto co = function.cellPointers( dstLevel, first, count ), fi = fineFunction.cellPointers( sourceLevel, first, count );
             hipCheck( hyteg_hip_p1_restrict_cells( count, co.data(), fi.data(), (int) dstLevel, storage->nncInvDevice() + (size_t) first * 14,
                                                    masks.data() + first, storage->stream() ),
                       "restrict (batched)" );
@@ -34,7 +41,7 @@ class P1toP1LinearRestriction
       {
          const MacroCell& cell = storage->getLocalCell( c );
          const auto       nnc  = storage->numNeighborCells( cell );
-         hipCheck( hyteg_hip_p1_restrict_cell_masked( function.getCellPointer( c, dstLevel ), function.getCellPointer( c, sourceLevel ),
+         hipCheck( hyteg_hip_p1_restrict_cell_masked( function.getCellPointer( c, dstLevel ), fineFunction.getCellPointer( c, sourceLevel ),
                                                       (int) dstLevel, nnc.data(), storage->maskFor( cell, flag ), storage->stream() ),
                    "restrict" );
       }
@@ -50,12 +57,34 @@ class P1toP1LinearProlongation
    {
       run( function, function, sourceLevel, flag );
    }
-   void prolongateAndAdd( const P1Function< double >& function, const uint_t& sourceLevel, const DoFType& flag ) const
+   void prolongateAndAdd( const P1Function< double >& function, const uint_t& sourceLevel, const DoFType& flagIn ) const
    {
+      const DoFType& flag = flagIn;
       // the prolongated correction is formed in a temporary (Replace), summed over cells on shared points, then added.
       // The temporary needs no initialisation: the masked kernel writes every point `flag` selects, the sum over
       // shared copies and the add read only those.
       auto                 storage = function.getStorage();
+      // no shell point selected (a macro-cell whose boundary values are fixed): nothing is shared, the kernel adds in place
+      {
+         const DoFType flag     = function.effectiveFlag( flagIn );
+         bool          anyShell = storage->numRanks() > 1 || storage->useBatch( sourceLevel + 1 );
+         for ( uint_t c = 0; c < storage->getNumberOfLocalCells() && !anyShell; ++c )
+            anyShell = ( storage->maskFor( storage->getLocalCell( c ), flag ) & HYTEG_HIP_MASK_SHELL ) != 0;
+         if ( !anyShell )
+         {
+            ScopedTimer timerProlongate( storage->getTimingTree(), "P1toP1LinearProlongation" );
+            for ( uint_t c = 0; c < storage->getNumberOfLocalCells(); ++c )
+            {
+               const MacroCell& cell = storage->getLocalCell( c );
+               const auto       nnc  = storage->numNeighborCells( cell );
+               hipCheck( hyteg_hip_p1_prolongate_cell_masked_update( function.getCellPointer( c, sourceLevel ),
+                                                                     function.getCellPointer( c, sourceLevel + 1 ), (int) sourceLevel,
+                                                                     nnc.data(), storage->maskFor( cell, flag ), HYTEG_HIP_ADD, storage->stream() ),
+                         "prolongateAndAdd" );
+            }
+            return;
+         }
+      }
       P1Function< double > tmp( "prolongate_tmp", storage, sourceLevel + 1, sourceLevel + 1, true );
       tmp.setBoundaryConditionAllInner( function.hasAllInnerBoundaryCondition() );
       run( function, tmp, sourceLevel, flag );

@@ -558,8 +558,13 @@ class GeometricMultigridSolver : public Solver< OperatorType >
       }
       {
          ScopedTimer tl( tt, levelName ), tr( tt, "Restriction" );
-         restrictionOperator_->restrict( tmp_, level, flag_ );
-         b.assign( { 1.0 }, { tmp_ }, level - 1, flag_ );
+         if constexpr ( std::is_same< RestrictionType, P1toP1LinearRestriction >::value )
+            restrictionOperator_->restrictInto( tmp_, b, level, flag_ ); // restrict + assign without the copy
+         else
+         {
+            restrictionOperator_->restrict( tmp_, level, flag_ );
+            b.assign( { 1.0 }, { tmp_ }, level - 1, flag_ );
+         }
          x.interpolate( 0.0, level - 1 );
       }
       solveRecursively( A, x, b, level - 1 );

@@ -338,6 +338,16 @@ HYTEG_HIP_API int hyteg_hip_p1_prolongate_cell_masked( const double*      coarse
                                                        const double*      nnc /* host, 14 */,
                                                        unsigned           mask,
                                                        hyteg_hip_stream_t stream );
+/* the same with an update type: ADD adds the interpolant to the selected interior points (bit 14) and, like
+ * hyteg_hip_p1_prolongate_cell, overwrites the selected shell points -- with an interior-only mask it is
+ * P1toP1LinearProlongation::prolongateAndAdd on a macro-cell whose shell is not selected, in one launch */
+HYTEG_HIP_API int hyteg_hip_p1_prolongate_cell_masked_update( const double*      coarse,
+                                                              double*            fine,
+                                                              int                coarse_level,
+                                                              const double*      nnc /* host, 14 */,
+                                                              unsigned           mask,
+                                                              int                update,
+                                                              hyteg_hip_stream_t stream );
 
 /* a3 on the macro-cell boundary: SOR / Gauss-Seidel on the macro-vertices, macro-edges and macro-faces around one cell
  * (vertexdof::macrovertex::smooth_sor, VertexDoFMacroVertex.hpp:231-251; P1Operator::smooth_sor_edge,
