@@ -66,6 +66,7 @@ SIGNATURES = {
     "hyteg_hip_axpy_f32_into_f64": (_i, [_vp, _vp, _d, _sz, _vp]),
     "hyteg_hip_p1_jacobi_cell": (_i, [_vp, _vp, _vp, _vp, _i, _dp, _d, _vp]),
     "hyteg_hip_p1_sor_cell": (_i, [_vp, _vp, _i, _dp, _d, _i, _vp]),
+    "hyteg_hip_p1_residual_cell": (_i, [_vp, _vp, _vp, _i, _dp, _vp]),
     "hyteg_hip_p1_sor_cell_sweeps": (_i, [_vp, _vp, _i, _dp, _d, _i, _i, _vp]),
     "hyteg_hip_set_sor_algorithm": (_i, [_i]),
     "hyteg_hip_p1_assign_cell": (_i, [_vp, _i, C.POINTER(_vp), _dp, _i, _vp]),
@@ -289,6 +290,10 @@ def set_sor_algorithm(algorithm: int) -> None:
 
 def p1_sor_cell(u, rhs, level, w, relax, backwards=False, stream=0):
     check(lib().hyteg_hip_p1_sor_cell(u, rhs, level, _w15(w), float(relax), int(backwards), stream), "p1_sor_cell")
+
+
+def p1_residual_cell(dst, rhs, src, level, w, stream=0):
+    check(lib().hyteg_hip_p1_residual_cell(dst, rhs, src, level, _w15(w), stream), "p1_residual_cell")
 
 
 def p1_sor_cell_sweeps(u, rhs, level, w, relax, nsweeps, backwards=False, stream=0):

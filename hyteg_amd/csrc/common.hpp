@@ -131,7 +131,8 @@ enum ApplyMode
 {
    APPLY_REPLACE = 0,
    APPLY_ADD     = 1,
-   APPLY_JACOBI  = 2
+   APPLY_JACOBI  = 2,
+   APPLY_RESIDUAL = 3 // dst = rhs - A src
 };
 
 struct Stencil15

@@ -221,7 +221,7 @@ __device__ inline void zmarch_body( const ZMarchArgs& A, const BrickTask* tasks,
    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc( const_cast< void* >( A.src ), 0, A.bytes, 0x00020000 );
    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc( A.dst, 0, A.bytes, 0x00020000 );
    const __amdgpu_buffer_rsrc_t rr =
-       __builtin_amdgcn_make_buffer_rsrc( const_cast< void* >( MODE == APPLY_JACOBI ? A.rhs : A.src ), 0, A.bytes, 0x00020000 );
+       __builtin_amdgcn_make_buffer_rsrc( const_cast< void* >( ( MODE == APPLY_JACOBI || MODE == APPLY_RESIDUAL ) ? A.rhs : A.src ), 0, A.bytes, 0x00020000 );
    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(
        const_cast< void* >( ( MODE == APPLY_JACOBI && A.invdiag ) ? A.invdiag : A.src ), 0, A.bytes, 0x00020000 );
 
@@ -358,6 +358,8 @@ __device__ inline void zmarch_body( const ZMarchArgs& A, const BrickTask* tasks,
             out = acc;
          else if ( MODE == APPLY_ADD )
             out = acc + EX0[s][j];
+         else if ( MODE == APPLY_RESIDUAL )
+            out = EX0[s][j] - acc; // the bits of assign( { 1, -1 }, { rhs, A src } ): one rounding of rhs - acc either way
          else
             out = a0 + relax * ( EX1[s][j] * ( EX0[s][j] - acc ) );
          // outputs are lanes 1 .. min( 62, R - 2 - xb ) of slices that exist: one unsigned compare of (lane - 1)

@@ -80,7 +80,7 @@ int launch_zmarch_lz( T* dst, const T* src, const T* rhs, const T* invdiag, int 
    // dst of Add is read exactly once per element and written right after: nontemporal load (18.6 -> 17.2 us).  rhs /
    // inverse diagonal of Jacobi are re-read by the next sweep of the smoother and stay plain (nontemporal: 12.4 -> 17.6 us
    // when they are still in the Infinity Cache, -2% when they are not).
-   constexpr int kExAux = MODE == APPLY_ADD ? 2 : 0;
+   constexpr int kExAux = MODE == APPLY_ADD ? 2 : 0; // (the right-hand side of the residual mode is re-read by the cycle: plain)
    const dim3 grid( nblocks ), block( 64 * kZMarchWavesPerBlock );
    if constexpr ( !std::is_same< T, double >::value )
    {
@@ -201,6 +201,19 @@ HYTEG_HIP_API int hyteg_hip_p1_jacobi_cell_f32( float*             dst,
    HH_REQUIRE( dst != src, "p1_jacobi_cell_f32: src and dst must not alias" );
    HH_REQUIRE( w[7] != 0.0, "p1_jacobi_cell_f32: zero centre weight" );
    return launch_zmarch< APPLY_JACOBI, float >( dst, src, rhs, invdiag, level, w, relax, as_stream( stream ) );
+}
+
+HYTEG_HIP_API int hyteg_hip_p1_residual_cell( double*            dst,
+                                              const double*      rhs,
+                                              const double*      src,
+                                              int                level,
+                                              const double*      w,
+                                              hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( dst && rhs && src && w, "p1_residual_cell: null pointer" );
+   HH_REQUIRE( level >= HYTEG_HIP_MIN_LEVEL && level <= 10, "p1_residual_cell: level out of range [2,10]" );
+   HH_REQUIRE( dst != src, "p1_residual_cell: src and dst must not alias" );
+   return launch_zmarch< APPLY_RESIDUAL >( dst, src, rhs, (const double*) nullptr, level, w, 0.0, as_stream( stream ) );
 }
 
 HYTEG_HIP_API int hyteg_hip_p1_apply_kernel_name( int level, int update, char* buf, size_t buflen )

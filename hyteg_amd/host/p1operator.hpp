@@ -116,6 +116,29 @@ class P1ConstantOperator
       }
    }
 
+   // r = b - A x on the points `flag` selects: apply followed by assign( { 1, -1 }, { b, r } ) as the multigrid cycle writes it
+   // (GeometricMultigridSolver.hpp:240-246); where no shell point is selected (one macro-cell with fixed boundary values) the
+   // interior kernel forms the difference itself -- one launch, the same bits
+   void residual( const P1Function< double >& x, const P1Function< double >& b, const P1Function< double >& r, uint_t level, DoFType flagIn ) const
+   {
+      const DoFType flag     = r.effectiveFlag( flagIn );
+      bool          anyShell = storage_->numRanks() > 1 || storage_->useBatch( level ) || level < HYTEG_HIP_MIN_LEVEL || level > 10 || &x == &r;
+      forCells( [&]( uint_t, const MacroCell& cell ) { anyShell = anyShell || ( storage_->maskFor( cell, flag ) & HYTEG_HIP_MASK_SHELL ); } );
+      if ( anyShell )
+      {
+         apply( x, r, level, flagIn );
+         r.assign( { 1.0, -1.0 }, { b, r }, level, flagIn );
+         return;
+      }
+      ScopedTimer timerOp( storage_->getTimingTree(), "Operator P1Function to P1Function" ), timerApply( storage_->getTimingTree(), "Apply" );
+      forCells( [&]( uint_t c, const MacroCell& cell ) {
+         if ( storage_->maskFor( cell, flag ) & HYTEG_HIP_MASK_INNER )
+            hipCheck( hyteg_hip_p1_residual_cell( r.getCellPointer( c, level ), b.getCellPointer( c, level ), x.getCellPointer( c, level ),
+                                                  (int) level, getCellStencils( cell.id, level ).inner, storage_->stream() ),
+                      "residual: cell" );
+      } );
+   }
+
    // P1Operator::smooth_jac, P1Operator.hpp:429-447
    void smooth_jac( const P1Function< double >& dst, const P1Function< double >& rhs, const P1Function< double >& src, double relax,
                     uint_t level, DoFType flagIn ) const

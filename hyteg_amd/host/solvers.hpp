@@ -367,6 +367,17 @@ class CGSolver : public Solver< OperatorType >
 // Generic over the operator's function type and the grid-transfer operators, like the reference (which takes
 // RestrictionOperator< FunctionType > / ProlongationOperator< FunctionType >): P1 functions with the linear transfer by
 // default, P1StokesFunction with P1P1StokesToP1P1Stokes{Restriction,Prolongation} (stokes.hpp).
+// does the operator offer residual( x, b, r, level, flag )?
+template < class OperatorType, class FunctionType, class = void >
+struct HasResidual : std::false_type
+{};
+template < class OperatorType, class FunctionType >
+struct HasResidual< OperatorType, FunctionType,
+                    std::void_t< decltype( std::declval< const OperatorType& >().residual( std::declval< const FunctionType& >(), std::declval< const FunctionType& >(),
+                                                                                           std::declval< const FunctionType& >(), uint_t( 0 ), All ) ) > >
+: std::true_type
+{};
+
 template < class OperatorType, class RestrictionType = P1toP1LinearRestriction, class ProlongationType = P1toP1LinearProlongation >
 class GeometricMultigridSolver : public Solver< OperatorType >
 {
@@ -553,8 +564,13 @@ class GeometricMultigridSolver : public Solver< OperatorType >
       }
       {
          ScopedTimer tl( tt, levelName ), tr( tt, "Residual" );
-         A.apply( x, tmp_, level, flag_ );
-         tmp_.assign( { 1.0, -1.0 }, { b, tmp_ }, level, flag_ );
+         if constexpr ( HasResidual< OperatorType, FunctionType >::value )
+            A.residual( x, b, tmp_, level, flag_ ); // apply + assign, in one launch where the operator can
+         else
+         {
+            A.apply( x, tmp_, level, flag_ );
+            tmp_.assign( { 1.0, -1.0 }, { b, tmp_ }, level, flag_ );
+         }
       }
       {
          ScopedTimer tl( tt, levelName ), tr( tt, "Restriction" );

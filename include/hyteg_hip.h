@@ -215,6 +215,16 @@ HYTEG_HIP_API int hyteg_hip_p1_sor_cell_sweeps( double*            u,
                                                 int                nsweeps,
                                                 hyteg_hip_stream_t stream );
 
+/* dst = rhs - A src on the cell interior in one launch: what a multigrid cycle computes with apply + assign( { 1, -1 } )
+ * (GeometricMultigridSolver.hpp:240-246: A.apply( x, tmp ); tmp.assign( { 1.0, -1.0 }, { b, tmp } )); the same bits as the two
+ * calls.  dst may be rhs, not src.  Levels 2..10. */
+HYTEG_HIP_API int hyteg_hip_p1_residual_cell( double*            dst,
+                                              const double*      rhs,
+                                              const double*      src,
+                                              int                level,
+                                              const double*      w /* host, 15 */,
+                                              hyteg_hip_stream_t stream );
+
 /* ---- a6: vector kernels on the cell interior ---------------------------------------------------------
  * assign:  dst = sum_k c_k src_k      replaces assign_3D_macrocell_vertexdof_{1,2,3}_rhs_function(s)
  *   src/hyteg/p1functionspace/generatedKernels/assign_3D_macrocell_vertexdof_*.cpp

@@ -222,6 +222,29 @@ def test_sor_level8_default_form_vs_the_sequential_oracle(env, relax, backwards)
     assert _rel(u.cpu().numpy(), ref) < 1e-12
 
 
+@pytest.mark.parametrize("level", [2, 4, 7, 8])
+def test_residual_in_one_launch_has_the_bits_of_apply_and_assign(env, level):
+    """hyteg_hip_p1_residual_cell: rhs - A src formed by the interior kernel = apply followed by assign( { 1, -1 }, { rhs, A src } )
+    (the two steps of GeometricMultigridSolver.hpp:240-246), bit for bit, and both equal the oracle's apply to 1e-13."""
+    torch, capi, po = env
+    rng = np.random.default_rng(900 + level)
+    w = po.assemble_cell_stencil(SKEW_TET, level)
+    n = po.cell_size(level)
+    x_h, b_h = rng.random(n), rng.random(n)
+    x, b = _dev(torch, x_h), _dev(torch, b_h)
+    two = _dev(torch, np.full(n, 7.0))
+    one = _dev(torch, np.full(n, 7.0))
+    capi.p1_apply_cell(two.data_ptr(), x.data_ptr(), level, w, 0, _stream(torch))
+    capi.p1_assign_cell(two.data_ptr(), [1.0, -1.0], [b.data_ptr(), two.data_ptr()], level, _stream(torch))
+    capi.p1_residual_cell(one.data_ptr(), b.data_ptr(), x.data_ptr(), level, w, _stream(torch))
+    torch.cuda.synchronize()
+    assert torch.equal(one, two)  # boundary entries untouched (7.0) in both
+    ax = np.zeros(n)
+    po.apply_cell(ax, x_h, level, w, po.REPLACE)
+    inner = po.inner_mask(level)
+    assert _rel(one.cpu().numpy()[inner], (b_h - ax)[inner]) < 1e-13
+
+
 @pytest.mark.parametrize("level,nsweeps,relax,backwards", [(5, 3, 1.0, False), (6, 2, 1.0, True), (7, 3, 0.8, False), (8, 3, 1.0, False),
                                                              (8, 4, 1.3, True), (4, 3, 1.0, False)])
 def test_pipelined_sweeps_equal_consecutive_sweeps_bit_for_bit(env, level, nsweeps, relax, backwards):
