@@ -109,8 +109,7 @@ class MixedPrecisionJacobiSmoother : public Solver< OperatorType >
    {
       if ( level >= HYTEG_HIP_MIN_LEVEL && level <= 10 && fp32Sweeps_ > 0 )
       {
-         A.apply( x, r_, level, flag_ );
-         r_.assign( { 1.0, -1.0 }, { b, r_ }, level, flag_ );
+         A.residual( x, b, r_, level, flag_ ); // apply + assign( { 1, -1 } ), one launch where no shell point is selected
          const size_t n = (size_t) layout::cellSize( (int) level );
          for ( uint_t c = 0; c < storage_->getNumberOfLocalCells(); ++c )
          {
@@ -494,7 +493,9 @@ class GeometricMultigridSolver : public Solver< OperatorType >
          const char* e = std::getenv( "HYTEG_AMD_GRAPHS" );
          return e && e[0] == '1';
       }();
-      return ( useGraphs_ || envOn ) && storage_->numRanks() == 1;
+      // recorded cycles exist for P1 functions only: the Stokes composition uploads tables and synchronises inside its smoother
+      // (not legal while a stream is being recorded), the P2 cycle has not been tried
+      return ( useGraphs_ || envOn ) && storage_->numRanks() == 1 && std::is_same< FunctionType, P1Function< double > >::value;
    }
 
    void endSegment( Recording& rec )
