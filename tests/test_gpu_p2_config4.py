@@ -149,7 +149,7 @@ def _run_p2(host, po, hu, st, level):
     return out, dot, (out2, out3)
 
 
-def _worker(rank, world, port, level, q):
+def _worker(rank, world, port, level, q, transport="auto"):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -166,15 +166,23 @@ def _worker(rank, world, port, level, q):
     try:
         st = host.Storage.from_gmsh(MESHES / "cube_6el.msh", rank, world)
         st.set_stream(torch.cuda.current_stream().cuda_stream)
-        ctx = DistributedContext(st, [level], torch.device("cuda", 0), dof_kinds=(0, 1))  # vertex- and edge-DoF plans
-        assert ctx.transport == "hooks" and any(k[1] >= 2 for k in ctx.buffers), "edge-DoF plans must have peers on this mesh"
-        q.put((rank,) + _run_p2(host, po, hu, st, level))
+        ctx = DistributedContext(st, [level], torch.device("cuda", 0), dof_kinds=(0, 1), transport=transport)  # vertex- and edge-DoF plans
+        assert any(k[1] >= 2 for k in ctx.buffers), "edge-DoF plans must have peers on this mesh"
+        assert ctx.transport == ("p2p" if transport == "p2p" else "hooks"), ctx.transport_note
+        out = _run_p2(host, po, hu, st, level)
+        st.check_transport()
+        q.put((rank,) + out)
         dist.barrier()
+    except BaseException as e:
+        q.put(("error", rank, repr(e)))
+        raise
     finally:
         dist.destroy_process_group()
 
 
-def test_p2_apply_on_two_ranks_reproduces_the_single_rank_result():
+@pytest.mark.parametrize("transport", ["auto", "p2p"])
+def test_p2_apply_on_two_ranks_reproduces_the_single_rank_result(transport):
+    """transport "p2p": vertex- AND edge-DoF shares are stored straight into the other process's IPC-mapped arena (comm_p2p.hip)"""
     import torch
     import torch.multiprocessing as mp
 
@@ -190,10 +198,13 @@ def test_p2_apply_on_two_ranks_reproduces_the_single_rank_result():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, level, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, level, q, transport)) for r in range(2)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=120) for _ in range(2)]
+    results = []
+    for _ in range(2):
+        results.append(q.get(timeout=120))
+        assert results[-1][0] != "error", results[-1]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
