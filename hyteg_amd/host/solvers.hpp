@@ -113,16 +113,18 @@ class MixedPrecisionJacobiSmoother : public Solver< OperatorType >
          const size_t n = (size_t) layout::cellSize( (int) level );
          for ( uint_t c = 0; c < storage_->getNumberOfLocalCells(); ++c )
          {
-            float**     f  = buffersFor( c, level ); // rf, e0, e1
+            float**     f  = buffersFor( c, level ); // rf, e0, e1, zero
             const auto& st = A.getCellStencils( storage_->getLocalCell( c ).id, level );
             auto        s  = storage_->stream();
             hipCheck( hyteg_hip_convert_f64_to_f32( f[0], r_.getCellPointer( c, level ), n, s ), "mixed Jacobi: convert residual" );
-            hipCheck( hyteg_hip_memset_zero( f[1], n * sizeof( float ), s ), "mixed Jacobi: zero" );
-            float *src = f[1], *dst = f[2]; // f[2]'s boundary entries are zero since its allocation, its interior is overwritten
+            // the first sweep reads e = 0 from a buffer that is never written (no memset per step); the sweeps then alternate
+            // between e0 and e1, whose boundary entries are zero since their allocation and whose interior is overwritten
+            float *src = f[3], *dst = f[1];
             for ( uint_t k = 0; k < fp32Sweeps_; ++k )
             {
                hipCheck( hyteg_hip_p1_jacobi_cell_f32( dst, f[0], src, nullptr, (int) level, st.inner, relax_, s ), "mixed Jacobi: float sweep" );
-               std::swap( src, dst );
+               src = dst;
+               dst = dst == f[1] ? f[2] : f[1];
             }
             hipCheck( hyteg_hip_axpy_f32_into_f64( x.getCellPointer( c, level ), src, 1.0, n, s ), "mixed Jacobi: correction" );
          }
@@ -140,7 +142,7 @@ class MixedPrecisionJacobiSmoother : public Solver< OperatorType >
       {
          const size_t         bytes = (size_t) layout::cellSize( (int) level ) * sizeof( float );
          std::vector< float* > v;
-         for ( int k = 0; k < 3; ++k )
+         for ( int k = 0; k < 4; ++k )
          {
             void* q = nullptr;
             hipCheck( hyteg_hip_malloc( &q, bytes ), "mixed Jacobi: malloc" );
