@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--level", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--regions", type=int, default=25,
+                    help="the timed K-step region is repeated this many times (each one bracketed by barrier + synchronize); "
+                         "value / ms_per_step / launch_us are the MEDIAN region, min and first region are reported beside it")
     args = ap.parse_args()
 
     import numpy as np
@@ -144,7 +147,7 @@ def main():
     # (hyteg_amd/p2p_canary.py: IPC mappings between the ranks' GPUs, the real pack / wait kernels, values checked) -- if the
     # GPUs cannot reach each other's memory that way, it is the canary that fails, not the benchmark
     canary = None
-    try_p2p = world > 1 and os.environ.get("HYTEG_BENCH_P2P", "1") != "0"
+    try_p2p = world > 1 and os.environ.get("HYTEG_BENCH_P2P", "0") == "1"
     if try_p2p:
         from hyteg_amd import p2p_canary
 
@@ -243,13 +246,23 @@ def main():
                                 f"{ctx.inner_transport}")
         p2p["used_before"] = ctx.transport == "p2p"
 
-    def measure():
-        # untimed: every ring pair is touched (twice) whatever --warmup says, so that no first access (page tables, TLB) of a
-        # buffer falls into the timed region; then the W warm-up steps of the contract
-        for k in range(pre_warm):
-            step(k)
-        for k in range(args.warmup):
-            step(k)
+    def apply_steps(first, count):
+        # `count` applies, step k on ring pair (first + k) % nbuf, issued by the C++ host layer's own loop (what a C++
+        # application writes around apply(); one ctypes call for the whole region)
+        laplace.apply_cycle(srcs, dsts, level, host.Inner, host.Replace, first=first, steps=count)
+
+    copy_ptrs = [[(dsts[k].cell_pointer(c, level), srcs[k].cell_pointer(c, level)) for c in range(storage.n_local_cells)]
+                 for k in range(nbuf)]
+
+    def copy_steps(first, count):
+        # the copy floor: the same ring pairs, every cell array read once and written once (nontemporal), same stream
+        for k in range(first, first + count):
+            for d, s_ in copy_ptrs[k % nbuf]:
+                capi.calib_copy(d, s_, n, True, stream.cuda_stream)
+
+    def region(fn):
+        """EXACTLY K steps between barrier + synchronize on both sides (wall clock) and between two HIP events recorded on
+        the launch stream (device time)"""
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -257,18 +270,34 @@ def main():
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record(stream)
-        for k in range(args.steps):
-            step(k)
+        fn(0, args.steps)
         ev1.record(stream)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels are launched on
+        return time.perf_counter() - t0, ev0.elapsed_time(ev1)
+
+    def measure():
+        # untimed: every ring pair is touched (twice) whatever --warmup says, so that no first access (page tables, TLB) of a
+        # buffer falls into the timed region; then the W warm-up steps of the contract
+        apply_steps(0, pre_warm)
+        apply_steps(0, args.warmup)
+        # R regions of K steps each.  The copy floor (N = 1) is measured by R more regions AFTER the apply regions, not between
+        # them: a copy region in front of an apply region changes what the Infinity Cache holds and made short (K = 20) apply
+        # regions 19 % slower (profiles/r03_region_probe.txt)
+        walls, devs, copies = [], [], []
+        for r in range(max(1, args.regions)):
+            w_, d_ = region(apply_steps)
+            walls.append(w_)
+            devs.append(d_)
+        if world == 1 and os.environ.get("HYTEG_BENCH_COPY", "1") != "0":
+            copy_steps(0, nbuf)
+            for r in range(max(1, args.regions)):
+                copies.append(region(copy_steps)[1])
 
         # the same K steps once more, every step between its own pair of events (reported beside the region mean: an upper
-        # bound, the events themselves cost ~2.4 us each between two kernels)
+        # bound, an event between two kernels costs time of its own)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         evs[0].record(stream)
         for k in range(args.steps):
@@ -276,10 +305,10 @@ def main():
             evs[k + 1].record(stream)
         torch.cuda.synchronize()
         per_step_us = sorted(evs[k].elapsed_time(evs[k + 1]) * 1e3 for k in range(args.steps))
-        return elapsed, dev_ms, per_step_us
+        return walls, devs, copies, per_step_us
 
     pre_warm = 2 * nbuf
-    elapsed, dev_ms, per_step_us = measure()
+    walls, devs, copies, per_step_us = measure()
     if world > 1 and ctx.transport == "p2p":
         ok, err = True, ""
         try:
@@ -290,18 +319,27 @@ def main():
             ok, err = False, repr(e)
         if not all_ranks(ok):
             ctx.disable_p2p(f"peer-to-peer exchange failed its check after the timed region {err}: measured again on {ctx.inner_transport}")
-            elapsed, dev_ms, per_step_us = measure()
-    p2p["verified"] = world > 1 and ctx.transport == "p2p"
+            walls, devs, copies, per_step_us = measure()
+    p2p["verified_on_check_pairs"] = world > 1 and ctx.transport == "p2p"
     median_us = per_step_us[len(per_step_us) // 2]
 
     if dist is not None:
-        tmax = torch.tensor([elapsed, dev_ms, median_us], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        # MAX over ranks, region by region
+        tmax = torch.tensor(walls + devs + [median_us], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed, dev_ms, median_us = float(tmax[0]), float(tmax[1]), float(tmax[2])
+        R_ = len(walls)
+        walls, devs, median_us = [float(x) for x in tmax[:R_]], [float(x) for x in tmax[R_:2 * R_]], float(tmax[2 * R_])
+
+    def med(v):
+        v = sorted(v)
+        return v[len(v) // 2]
+
+    elapsed, dev_ms = med(walls), med(devs)
 
     if rank == 0:
         w = laplace.stencils(0, level)[0]
-        launch_us = dev_ms * 1e3 / args.steps  # one event pair around the whole timed region / K
+        launch_us = dev_ms * 1e3 / args.steps  # one event pair around a whole timed region / K, median region
+        copy_us = (med(copies) * 1e3 / args.steps / storage.n_local_cells) if copies else None
         cell_inner = capi.cell_inner_size(level)
         algo_bytes = 16 * cell_inner  # 8 B compulsory src read + 8 B dst write per DoF-update, one cell
         achieved = algo_bytes / (launch_us * 1e-6) / 1e9
@@ -365,15 +403,36 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_note,
                 "launch_us": launch_us,
+                "launch_us_min_region": min(devs) * 1e3 / args.steps,
+                "launch_us_first_region": devs[0] * 1e3 / args.steps,
+                "frac_min_region": (algo_bytes / (min(devs) * 1e-3 / args.steps) / 1e9 / HBM_PEAK_GBS) if world == 1 else None,
+                "copy_us": copy_us,
+                "copy_us_min_region": (min(copies) * 1e3 / args.steps / storage.n_local_cells) if copies else None,
+                "copy_bytes_per_launch": 16 * n if copies else None,
+                "frac_of_copy": (copy_us / launch_us) if copy_us else None,
                 "per_step_event_median_us": median_us,
                 "per_step_event_min_us": per_step_us[0],
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "note": "achieved = algorithmic bytes of one cell's interior kernel / launch_us; launch_us = time between two HIP"
-                        " events recorded on the launch stream around the K applies of the wall-clock region / K (N=1: one kernel"
-                        " per apply; every ring pair was touched before, so also 20 steps see no first accesses)."
-                        " per_step_event_median_us: the same K steps once more with an event pair around EACH apply -- an event"
-                        " between two kernels costs ~2.4 us on this device (12.1 vs 9.7 us), so it bounds the launch duration"
-                        " from above and is not used for the roofline figure",
+                        " events recorded on the launch stream around the K applies of a wall-clock region / K, MEDIAN over"
+                        " `regions` regions (N=1: one kernel per apply; every ring pair was touched before the first region)."
+                        " copy_us: the same measurement (same ring pairs, same stream, same events, `regions` regions of K copies"
+                        " after the apply regions) for hyteg_hip_calib_copy, the fastest copy kernel we know for this size"
+                        " (plain loads, nontemporal stores), which reads and writes every entry of the cell array once"
+                        " (copy_bytes_per_launch); frac_of_copy = copy_us / launch_us."
+                        " per_step_event_median_us: the K steps once more with an event pair around EACH apply -- an upper"
+                        " bound (the events cost time between the kernels), not used for the roofline figure",
+            },
+            "regions": {
+                "count": len(walls),
+                "reported": "median region (value, ms_per_step, roofline.launch_us); each region = exactly K steps between barrier + synchronize",
+                "ms_per_step_median": elapsed * 1e3 / args.steps,
+                "ms_per_step_min": min(walls) * 1e3 / args.steps,
+                "ms_per_step_first": walls[0] * 1e3 / args.steps,
+                "value_first_region": inner_dofs * args.steps / walls[0],
+                "value_best_region": inner_dofs * args.steps / min(walls),
+                "launch_us_all": [round(d * 1e3 / args.steps, 3) for d in devs],
+                "copy_us_all": [round(d * 1e3 / args.steps / storage.n_local_cells, 3) for d in copies],
             },
         }
         if world == 1 and not args.no_cpu_baseline:

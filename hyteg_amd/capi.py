@@ -26,6 +26,7 @@ SIGNATURES = {
     "hyteg_hip_upload": (_i, [_vp, _vp, _sz, _vp]),
     "hyteg_hip_download": (_i, [_vp, _vp, _sz, _vp]),
     "hyteg_hip_copy": (_i, [_vp, _vp, _sz, _vp]),
+    "hyteg_hip_calib_copy": (_i, [_vp, _vp, _i64, _i, _vp]),
     "hyteg_hip_stream_create": (_i, [C.POINTER(_vp)]),
     "hyteg_hip_stream_destroy": (_i, [_vp]),
     "hyteg_hip_stream_synchronize": (_i, [_vp]),
@@ -234,6 +235,11 @@ def event_record(ev, stream=0) -> None:
 
 def stream_wait_event(stream, ev) -> None:
     check(lib().hyteg_hip_stream_wait_event(stream, ev), "stream_wait_event")
+
+
+def calib_copy(dst, src, n, nontemporal=True, stream=0) -> None:
+    """streaming copy of n doubles (calibration of the practical bandwidth floor; bench.py roofline.copy_us)"""
+    check(lib().hyteg_hip_calib_copy(dst, src, n, 1 if nontemporal else 0, stream), "calib_copy")
 
 
 def p1_apply_kernel_name(level, update=REPLACE) -> str:

@@ -120,7 +120,7 @@ struct BrickTable
    bool             decodable = false; // z-chunk starts fit the kernel arguments (decode mode of the z-march kernel)
    int              zs[32]    = {};    // first task of z-chunk k, padded with count
 };
-int get_bricks( int level, int NY, int LZ, BrickTable* out );
+int get_bricks( int level, int NY, int LZ, BrickTable* out, int XS = 62 ); // XS: x-stride of the bricks (62, or 56 = aligned windows)
 
 // ticket counter of the single-launch reductions (p1_batch.hip), one per (device, stream); zero between launches
 int dot_counter( hipStream_t stream, unsigned** out );

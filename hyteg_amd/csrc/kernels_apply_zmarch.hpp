@@ -198,9 +198,15 @@ __device__ inline BrickTask zm_decode_task( const ZMarchArgs& A, int task )
 // re-reads it).  gfx950 "aux" bits: 1 = sc0, 2 = nt, 16 = sc1.
 // PFD: how many slices ahead of the one being computed the loads run.
 // T: value type of the arrays and of the arithmetic (double or float; the weights travel as doubles and are converted).
-template < int MODE, int NY, int LZ, int EX_AUX, bool DEC, int PFD, typename T >
+// XS: x-stride between neighbouring bricks = outputs per row segment.  62: lanes 1..62 of every row are stored (segments begin
+// at x = 1 + 62 k whatever the row's address).  56: ALIGNED store windows -- every row segment of a brick begins at the first
+// boundary of 8 entries of dst (doubles: 64 bytes) inside lanes 1..7 (at a boundary of 4 entries in lane 4 where it would fall
+// on lane 8) and is 56 entries long (doubles: 448 bytes), so that no 64-byte line of dst is written by two waves except the
+// first and the last line of a row (round 3: the PMC write traffic of the 62-wide form is 1.11 x the bytes of dst).
+template < int MODE, int NY, int LZ, int EX_AUX, bool DEC, int PFD, typename T, int XS = 62 >
 __device__ inline void zmarch_body( const ZMarchArgs& A, const BrickTask* tasks, int ntasks, int xcd_chunk )
 {
+   static_assert( XS == 62 || ( XS == 56 && !DEC ), "x-stride: 62 (plain) or 56 (aligned store windows, table mode)" );
    constexpr int SZ = (int) sizeof( T );
    ZM_TRACE( 0 );
    int b = blockIdx.x;
@@ -227,6 +233,8 @@ __device__ inline void zmarch_body( const ZMarchArgs& A, const BrickTask* tasks,
 
    const int lane_off = lane * SZ;
    const int ym       = t.y0 - 1; // first row held per slice
+   // aligned windows: entry index of dst's first byte in units of the value type, modulo one 64-byte line
+   const int dst_phase = XS == 56 ? (int) ( ( reinterpret_cast< uintptr_t >( A.dst ) / SZ ) & 7 ) : 0;
 
    // S[q][r]: slice z0-1+q, row ym+r (r = 0..NY+1), x = xb + lane.  q = 0..LZ+1.
    T S[LZ + 2][NY + 2];
@@ -362,10 +370,24 @@ __device__ inline void zmarch_body( const ZMarchArgs& A, const BrickTask* tasks,
             out = EX0[s][j] - acc; // the bits of assign( { 1, -1 }, { rhs, A src } ): one rounding of rhs - acc either way
          else
             out = a0 + relax * ( EX1[s][j] * ( EX0[s][j] - acc ) );
-         // outputs are lanes 1 .. min( 62, R - 2 - xb ) of slices that exist: one unsigned compare of (lane - 1)
-         const int      cnt = s < t.nz ? min( 62, R - 2 - t.xb ) : 0; // wave-uniform
-         const unsigned lm1 = (unsigned) ( lane - 1 );
-         zm_store2< T, kStAux >( rd, lm1 < (unsigned) max( cnt, 0 ) ? lane_off : -8, io * SZ, out );
+         if constexpr ( XS == 62 )
+         {
+            // outputs are lanes 1 .. min( 62, R - 2 - xb ) of slices that exist: one unsigned compare of (lane - 1)
+            const int      cnt = s < t.nz ? min( 62, R - 2 - t.xb ) : 0; // wave-uniform
+            const unsigned lm1 = (unsigned) ( lane - 1 );
+            zm_store2< T, kStAux >( rd, lm1 < (unsigned) max( cnt, 0 ) ? lane_off : -8, io * SZ, out );
+         }
+         else
+         {
+            // lanes [lo, hi): lo = the lane in 1..7 whose entry begins a 64-byte line of dst (lane 4 = a 32-byte boundary when
+            // that lane would be 8); the row's first brick starts at x = 1 instead; hi = lo + 56 clipped to the last inner x.
+            // A neighbour brick (xb + 56) computes the same lo for this row, so the windows tile the row.
+            int lo = ( ( -( io + dst_phase ) - 1 ) & 7 ) + 1; // 1 .. 8: first lane whose entry index is a multiple of 8
+            lo     = lo == 8 ? 4 : lo;
+            const int hi  = s < t.nz ? min( lo + 56, R - 1 - t.xb ) : 0;
+            const int lo1 = t.xb == 0 ? 1 : lo;
+            zm_store2< T, kStAux >( rd, (unsigned) ( lane - lo1 ) < (unsigned) max( hi - lo1, 0 ) ? lane_off : -8, io * SZ, out );
+         }
          io += R;
       }
    };
@@ -376,26 +398,26 @@ __device__ inline void zmarch_body( const ZMarchArgs& A, const BrickTask* tasks,
    ZM_TRACE( 4 );
 }
 
-template < int MODE, int NY, int LZ, int EX_AUX = 0, bool DEC = false, int PFD = 1, typename T = double >
+template < int MODE, int NY, int LZ, int EX_AUX = 0, bool DEC = false, int PFD = 1, typename T = double, int XS = 62 >
 __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_kernel( const ZMarchArgs A )
 {
-   zmarch_body< MODE, NY, LZ, EX_AUX, DEC, PFD, T >( A, A.tasks, A.ntasks, A.xcd_chunk );
+   zmarch_body< MODE, NY, LZ, EX_AUX, DEC, PFD, T, XS >( A, A.tasks, A.ntasks, A.xcd_chunk );
 }
 
 // The same kernel with the three values a wave needs before it can fetch its brick -- table pointer, task count, XCD chunk --
 // as leading scalar arguments: built with -mllvm -amdgpu-kernarg-preload-count=4 the command processor places them in SGPRs
 // at wave launch, so the task load does not wait for a kernel-argument load first (one scalar round trip less in the start-up
 // chain of DESIGN 3.1).  The rest of the arguments stay in the struct.
-template < int MODE, int NY, int LZ, int EX_AUX = 0, bool DEC = false, int PFD = 1, typename T = double >
+template < int MODE, int NY, int LZ, int EX_AUX = 0, bool DEC = false, int PFD = 1, typename T = double, int XS = 62 >
 __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_preload_kernel( const BrickTask* tasks, int ntasks, int xcd_chunk,
                                                                                               const ZMarchArgs A )
 {
-   zmarch_body< MODE, NY, LZ, EX_AUX, DEC, PFD, T >( A, tasks, ntasks, xcd_chunk );
+   zmarch_body< MODE, NY, LZ, EX_AUX, DEC, PFD, T, XS >( A, tasks, ntasks, xcd_chunk );
 }
 
-// host: bricks of NY rows x 62 outputs x LZ slices, ordered z-chunk, y-chunk, x-chunk (memory order); zs (optional)
+// host: bricks of NY rows x XS outputs x LZ slices, ordered z-chunk, y-chunk, x-chunk (memory order); zs (optional)
 // receives the first task index of every z-chunk followed by the total
-inline void build_brick_tasks( int level, int NY, int LZ, std::vector< BrickTask >& out, std::vector< int >* zs = nullptr )
+inline void build_brick_tasks( int level, int NY, int LZ, std::vector< BrickTask >& out, std::vector< int >* zs = nullptr, int XS = 62 )
 {
    const int N = ( 1 << level ) + 1;
    out.clear();
@@ -409,7 +431,7 @@ inline void build_brick_tasks( int level, int NY, int LZ, std::vector< BrickTask
       for ( int y0 = 1; y0 <= W - 3; y0 += NY )
       {
          const int xmax = W - y0 - 2; // last interior x of the brick's longest row
-         for ( int x0 = 1; x0 <= xmax; x0 += 62 )
+         for ( int x0 = 1; x0 <= xmax; x0 += XS )
          {
             BrickTask t{};
             t.xb = x0 - 1;

@@ -50,11 +50,22 @@ inline bool apply_preload_enabled()
    return v;
 }
 
-template < int MODE, int LZ, typename T = double >
+// HYTEG_HIP_APPLY_ALIGNED=1: bricks 56 outputs wide whose store windows begin on 64-byte boundaries of dst (XS = 56 of
+// kernels_apply_zmarch.hpp) instead of 62 outputs wide at x = 1 + 62 k
+inline bool apply_aligned_enabled()
+{
+   static const bool v = [] {
+      const char* e = getenv( "HYTEG_HIP_APPLY_ALIGNED" );
+      return e && e[0] == '1';
+   }();
+   return v;
+}
+
+template < int MODE, int LZ, typename T = double, int XS = 62 >
 int launch_zmarch_lz( T* dst, const T* src, const T* rhs, const T* invdiag, int level, const double* w, double relax, hipStream_t stream )
 {
    BrickTable bt;
-   int        rc = get_bricks( level, kBrickNY, LZ, &bt );
+   int        rc = get_bricks( level, kBrickNY, LZ, &bt, XS );
    if ( rc != HYTEG_HIP_OK )
       return rc;
    if ( bt.count == 0 )
@@ -82,7 +93,10 @@ int launch_zmarch_lz( T* dst, const T* src, const T* rhs, const T* invdiag, int 
    // when they are still in the Infinity Cache, -2% when they are not).
    constexpr int kExAux = MODE == APPLY_ADD ? 2 : 0; // (the right-hand side of the residual mode is re-read by the cycle: plain)
    const dim3 grid( nblocks ), block( 64 * kZMarchWavesPerBlock );
-   if constexpr ( !std::is_same< T, double >::value )
+   if constexpr ( XS != 62 )
+      hipLaunchKernelGGL( ( p1_apply_zmarch_preload_kernel< MODE, kBrickNY, LZ, kExAux, false, 2, T, XS > ), grid, block, 0, stream, A.tasks,
+                          A.ntasks, A.xcd_chunk, A );
+   else if constexpr ( !std::is_same< T, double >::value )
    {
       if ( apply_preload_enabled() )
          hipLaunchKernelGGL( ( p1_apply_zmarch_preload_kernel< MODE, kBrickNY, LZ, kExAux, false, 2, T > ), grid, block, 0, stream, A.tasks,
@@ -106,6 +120,9 @@ int launch_zmarch_lz( T* dst, const T* src, const T* rhs, const T* invdiag, int 
 template < int MODE, typename T = double >
 int launch_zmarch( T* dst, const T* src, const T* rhs, const T* invdiag, int level, const double* w, double relax, hipStream_t stream )
 {
+   if constexpr ( MODE == APPLY_REPLACE && std::is_same< T, double >::value )
+      if ( brick_lz( level ) == 8 && apply_aligned_enabled() )
+         return launch_zmarch_lz< MODE, 8, T, 56 >( dst, src, rhs, invdiag, level, w, relax, stream );
    if ( brick_lz( level ) == 8 )
       return launch_zmarch_lz< MODE, 8, T >( dst, src, rhs, invdiag, level, w, relax, stream );
    return launch_zmarch_lz< MODE, 4, T >( dst, src, rhs, invdiag, level, w, relax, stream );
@@ -235,6 +252,11 @@ HYTEG_HIP_API int hyteg_hip_p1_apply_kernel_name( int level, int update, char* b
    const bool dec = bt.decodable && apply_decode_enabled();
    const int  pfd = dec ? 1 : apply_prefetch_distance();
    const bool pre = !dec && pfd == 2 && apply_preload_enabled(); // as in launch_zmarch_lz
+   if ( mode == APPLY_REPLACE && lz == 8 && apply_aligned_enabled() )
+   {
+      snprintf( buf, buflen, "p1_apply_zmarch_preload_kernel<MODE=%d,NY=%d,LZ=%d,EX_AUX=0,DEC=0,PFD=2,XS=56>", mode, kBrickNY, lz );
+      return HYTEG_HIP_OK;
+   }
    snprintf( buf, buflen, "%s<MODE=%d,NY=%d,LZ=%d,EX_AUX=%d,DEC=%d,PFD=%d>", pre ? "p1_apply_zmarch_preload_kernel" : "p1_apply_zmarch_kernel", mode,
              kBrickNY, lz, mode == APPLY_ADD ? 2 : 0, dec ? 1 : 0, pfd );
    return HYTEG_HIP_OK;

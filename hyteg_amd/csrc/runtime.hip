@@ -117,13 +117,14 @@ int get_tiles( int level, TileKind kind, int capacity, TileTable* out )
    return HYTEG_HIP_OK;
 }
 
-int get_bricks( int level, int NY, int LZ, BrickTable* out )
+int get_bricks( int level, int NY, int LZ, BrickTable* out, int XS )
 {
    // hot path: the same (level, shape) is asked for on every launch
    thread_local int        lastKey[4] = { -1, -1, -1, -1 };
    thread_local BrickTable lastVal;
    int                     dev0 = 0;
    HH_CHECK_HIP( hipGetDevice( &dev0 ) );
+   NY = NY * 1000 + XS; // the key's shape entry carries the x-stride
    if ( lastKey[0] == dev0 && lastKey[1] == level && lastKey[2] == NY && lastKey[3] == LZ )
    {
       *out = lastVal;
@@ -145,11 +146,11 @@ int get_bricks( int level, int NY, int LZ, BrickTable* out )
    }
    std::vector< BrickTask > host;
    std::vector< int >       zs;
-   build_brick_tasks( level, NY, LZ, host, &zs );
+   build_brick_tasks( level, NY / 1000, LZ, host, &zs, XS );
    BrickTable bt;
    bt.count = (int) host.size();
    // decode mode: zs = starts of the z-chunks followed by the total
-   bt.decodable = (int) zs.size() - 1 <= kZMarchMaxZChunks && ( 1 << level ) - 3 <= 62 * kZMarchMaxStairs;
+   bt.decodable = XS == 62 && (int) zs.size() - 1 <= kZMarchMaxZChunks && ( 1 << level ) - 3 <= 62 * kZMarchMaxStairs;
    for ( int k = 0; k < kZMarchMaxZChunks; ++k )
       bt.zs[k] = k + 1 < (int) zs.size() ? zs[k] : bt.count;
    if ( bt.count > 0 )
@@ -347,6 +348,43 @@ HYTEG_HIP_API int hyteg_hip_graph_destroy( hyteg_hip_graph_t graph )
 {
    if ( graph )
       HH_CHECK_HIP( hipGraphExecDestroy( reinterpret_cast< hipGraphExec_t >( graph ) ) );
+   return HYTEG_HIP_OK;
+}
+
+// ---- calibration: streaming copy (the practical floor a stencil sweep is compared with) ---------------
+}
+
+namespace hyteg_hip {
+// one double per lane and step, plain loads, nontemporal stores, 2048 workgroups: the fastest of the copy kernels measured on
+// MI355X for one level-8 cell array (hyteg_amd/csrc/exp/copy_floor_probe.hip, profiles/r03_copy_floor_probe.txt: 7.5 us for
+// 22.9 MB in + 22.9 MB out; 16 bytes per lane 7.6-7.8; nontemporal loads 8.9-9.0; plain stores 9.7-10; hipMemcpyAsync 10.5)
+template < bool NT >
+__global__ __launch_bounds__( 256 ) void calib_copy_kernel( double* __restrict__ dst, const double* __restrict__ src, int64_t n )
+{
+   const int64_t stride = (int64_t) gridDim.x * 256;
+   for ( int64_t k = (int64_t) blockIdx.x * 256 + threadIdx.x; k < n; k += stride )
+   {
+      if constexpr ( NT )
+         __builtin_nontemporal_store( src[k], &dst[k] );
+      else
+         dst[k] = src[k];
+   }
+}
+} // namespace hyteg_hip
+
+extern "C" {
+HYTEG_HIP_API int hyteg_hip_calib_copy( double* dst, const double* src, int64_t n, int nontemporal, hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( dst && src && n > 0, "calib_copy: null pointer or empty array" );
+   HH_REQUIRE( ( reinterpret_cast< uintptr_t >( dst ) & 7 ) == 0 && ( reinterpret_cast< uintptr_t >( src ) & 7 ) == 0,
+               "calib_copy: arrays of doubles must be 8-byte aligned" );
+   int64_t blocks = ( n + 255 ) / 256;
+   blocks         = blocks > 2048 ? 2048 : blocks; // 8 workgroups per CU, grid-stride beyond that
+   if ( nontemporal )
+      hipLaunchKernelGGL( calib_copy_kernel< true >, dim3( (unsigned) blocks ), dim3( 256 ), 0, as_stream( stream ), dst, src, n );
+   else
+      hipLaunchKernelGGL( calib_copy_kernel< false >, dim3( (unsigned) blocks ), dim3( 256 ), 0, as_stream( stream ), dst, src, n );
+   HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;
 }
 

@@ -86,6 +86,11 @@ HYTEG_HIP_API int hyteg_hip_memset_zero( void* dev_ptr, size_t bytes, hyteg_hip_
 HYTEG_HIP_API int hyteg_hip_upload( void* dev_dst, const void* host_src, size_t bytes, hyteg_hip_stream_t stream );
 HYTEG_HIP_API int hyteg_hip_download( void* host_dst, const void* dev_src, size_t bytes, hyteg_hip_stream_t stream );
 HYTEG_HIP_API int hyteg_hip_copy( void* dev_dst, const void* dev_src, size_t bytes, hyteg_hip_stream_t stream );
+/* Calibration: a streaming copy kernel of n doubles (plain loads, nontemporal stores if `nontemporal`),
+ * the practical floor a sweep over the same bytes is compared with (bench.py: roofline.copy_us).  No reference
+ * counterpart (the reference's counterpart of this measurement is the STREAM table of its kerncraft machine files,
+ * data/kerncraftMachineFiles/SkylakeSP_Platinum-8147_2.7GHz.yml:412-420). */
+HYTEG_HIP_API int hyteg_hip_calib_copy( double* dst, const double* src, int64_t n, int nontemporal, hyteg_hip_stream_t stream );
 HYTEG_HIP_API int hyteg_hip_stream_create( hyteg_hip_stream_t* stream );
 HYTEG_HIP_API int hyteg_hip_stream_destroy( hyteg_hip_stream_t stream );
 HYTEG_HIP_API int hyteg_hip_stream_synchronize( hyteg_hip_stream_t stream );
