@@ -60,6 +60,7 @@ SIGNATURES = {
     "hyteg_hip_cell_index": (_i64, [_i, _i, _i, _i]),
     "hyteg_hip_p1_apply_cell": (_i, [_vp, _vp, _i, _dp, _i, _vp]),
     "hyteg_hip_p1_apply_kernel_name": (_i, [_i, _i, C.c_char_p, _sz]),
+    "hyteg_hip_set_apply_shape": (_i, [_i, _i, _i]),
     "hyteg_hip_p1_apply_cell_f32": (_i, [_vp, _vp, _i, _dp, _i, _vp]),
     "hyteg_hip_p1_jacobi_cell_f32": (_i, [_vp, _vp, _vp, _vp, _i, _dp, _d, _vp]),
     "hyteg_hip_convert_f64_to_f32": (_i, [_vp, _vp, _sz, _vp]),
@@ -240,6 +241,11 @@ def stream_wait_event(stream, ev) -> None:
 def calib_copy(dst, src, n, nontemporal=True, stream=0) -> None:
     """streaming copy of n doubles (calibration of the practical bandwidth floor; bench.py roofline.copy_us)"""
     check(lib().hyteg_hip_calib_copy(dst, src, n, 1 if nontemporal else 0, stream), "calib_copy")
+
+
+def set_apply_shape(ny=0, lz=0, pfd=0) -> None:
+    """tuning knob: brick shape of the z-march kernels (0, 0, 0 = per-level defaults)"""
+    check(lib().hyteg_hip_set_apply_shape(ny, lz, pfd), "set_apply_shape")
 
 
 def p1_apply_kernel_name(level, update=REPLACE) -> str:

@@ -6,7 +6,6 @@ F="--offload-arch=gfx950 -O3 -std=c++20 -DHYTEG_HIP_BUILDING"
 /opt/rocm/bin/hipcc $F -o "$D/apply_trace_time" "$D/apply_trace.hip" "$D/../runtime.hip"
 /opt/rocm/bin/hipcc $F -DZM_DO_TRACE -o "$D/apply_trace" "$D/apply_trace.hip" "$D/../runtime.hip"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -o "$D/icache_probe" "$D/icache_probe.hip"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -o "$D/copy_calib" "$D/copy_calib.hip"
 /opt/rocm/bin/hipcc $F -o "$D/sor_trace" "$D/sor_trace.hip" "$D/../runtime.hip" "$D/../p1_sor_dataflow.hip"
 /opt/rocm/bin/hipcc $F -DSOR_LOOKAHEAD -o "$D/sor_trace_lookahead" "$D/sor_trace.hip" "$D/../runtime.hip" "$D/../p1_sor_dataflow.hip"
 /opt/rocm/bin/hipcc $F -DSOR_LOOKAHEAD -DSOR_STEPS -o "$D/sor_trace_lookahead_steps" "$D/sor_trace.hip" "$D/../runtime.hip" "$D/../p1_sor_dataflow.hip"

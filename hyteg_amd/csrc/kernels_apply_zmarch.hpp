@@ -203,7 +203,7 @@ __device__ inline BrickTask zm_decode_task( const ZMarchArgs& A, int task )
 // boundary of 8 entries of dst (doubles: 64 bytes) inside lanes 1..7 (at a boundary of 4 entries in lane 4 where it would fall
 // on lane 8) and is 56 entries long (doubles: 448 bytes), so that no 64-byte line of dst is written by two waves except the
 // first and the last line of a row (round 3: the PMC write traffic of the 62-wide form is 1.11 x the bytes of dst).
-template < int MODE, int NY, int LZ, int EX_AUX, bool DEC, int PFD, typename T, int XS = 62 >
+template < int MODE, int NY, int LZ, int EX_AUX, bool DEC, int PFD, typename T, int XS = 62, int ST_AUX = 2 >
 __device__ inline void zmarch_body( const ZMarchArgs& A, const BrickTask* tasks, int ntasks, int xcd_chunk )
 {
    static_assert( XS == 62 || ( XS == 56 && !DEC ), "x-stride: 62 (plain) or 56 (aligned store windows, table mode)" );
@@ -223,7 +223,7 @@ __device__ inline void zmarch_body( const ZMarchArgs& A, const BrickTask* tasks,
    const int lane = threadIdx.x & 63;
    ZM_TRACE( 1 );
 
-   constexpr int kStAux = 2; // nontemporal
+   constexpr int kStAux = ST_AUX; // 2 = nontemporal (the default; 1 = sc0, 16 = sc1: measured variants)
    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc( const_cast< void* >( A.src ), 0, A.bytes, 0x00020000 );
    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc( A.dst, 0, A.bytes, 0x00020000 );
    const __amdgpu_buffer_rsrc_t rr =
@@ -260,14 +260,15 @@ __device__ inline void zmarch_body( const ZMarchArgs& A, const BrickTask* tasks,
    };
 
    // wave-uniform element index of (xb, ym, z0-1+q) and row-0 length of that slice
-   static_assert( LZ + 2 <= kBrickMaxSlices || DEC, "brick taller than the table's base array" );
+   // (bricks taller than the table's base array -- experimental shapes -- compute their slice bases here)
+   constexpr bool kBasesFromTable = !DEC && LZ + 2 <= kBrickMaxSlices;
    int baseq[LZ + 2], Wqs[LZ + 2];
    {
       int base = t.i0, Wq = t.W0;
 #pragma unroll
       for ( int q = 0; q < LZ + 2; ++q )
       {
-         baseq[q] = DEC ? base : t.base[q < kBrickMaxSlices ? q : 0];
+         baseq[q] = !kBasesFromTable ? base : t.base[q < kBrickMaxSlices ? q : 0];
          Wqs[q]   = Wq;
          base += tri( Wq ) - ym; // (x, ym, z) -> (x, ym, z+1)
          Wq -= 1;
@@ -408,11 +409,11 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_k
 // as leading scalar arguments: built with -mllvm -amdgpu-kernarg-preload-count=4 the command processor places them in SGPRs
 // at wave launch, so the task load does not wait for a kernel-argument load first (one scalar round trip less in the start-up
 // chain of DESIGN 3.1).  The rest of the arguments stay in the struct.
-template < int MODE, int NY, int LZ, int EX_AUX = 0, bool DEC = false, int PFD = 1, typename T = double, int XS = 62 >
+template < int MODE, int NY, int LZ, int EX_AUX = 0, bool DEC = false, int PFD = 1, typename T = double, int XS = 62, int ST_AUX = 2 >
 __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_preload_kernel( const BrickTask* tasks, int ntasks, int xcd_chunk,
                                                                                               const ZMarchArgs A )
 {
-   zmarch_body< MODE, NY, LZ, EX_AUX, DEC, PFD, T, XS >( A, tasks, ntasks, xcd_chunk );
+   zmarch_body< MODE, NY, LZ, EX_AUX, DEC, PFD, T, XS, ST_AUX >( A, tasks, ntasks, xcd_chunk );
 }
 
 // host: bricks of NY rows x XS outputs x LZ slices, ordered z-chunk, y-chunk, x-chunk (memory order); zs (optional)

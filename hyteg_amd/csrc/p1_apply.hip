@@ -1,5 +1,6 @@
 // C-ABI entry points: constant-stencil apply and fused weighted Jacobi on one macro-cell.
 #include <cstdlib>
+#include <string>
 #include <type_traits>
 
 #include "kernels_apply.hpp"
@@ -11,61 +12,41 @@ namespace {
 
 constexpr int kTile = 1024;
 
-// Brick shape of the z-march kernel: rows x slices per wave.  Level 8 has only ~64k wave-rows for 1024 SIMDs, so the
-// shape trades reuse (taller bricks re-read fewer halo slices) against the number of waves: 4 x 8 is best from
-// level 8 on, 4 x 4 below (MI355X: level 7 4.3 vs 5.9 us, level 8 9.9 vs 9.7 us, level 9 equal).
-constexpr int kBrickNY = 4;
-inline int   brick_lz( int level ) { return level >= 8 ? 8 : 4; }
+// Brick shape of the z-march kernel: rows x slices per wave, and how many slices the loads run ahead of the arithmetic.
+// Level 8 has only ~64k wave-rows for 1024 SIMDs, so the shape trades reuse (taller / wider bricks re-read fewer halo rows
+// and slices) against the number of waves and against the share of a wave's loads that precede its first store (the
+// prologue: (2 + PFD) of LZ + 2 slices).  Round 3 swept the shapes with bench.py (profiles/r03_apply_shape_sweep.txt):
+// at level 8 more, shorter waves with a short prologue win -- 2 x 8, one slice ahead: 9.17-9.26 us against 9.53-9.57 us for
+// round 2's 4 x 8, two slices ahead; everything taller or wider is slower (4 x 16: 13.3, 6 x 8: 11.1, 4 x 12: 11.0 us).
+struct BrickShape
+{
+   int  ny, lz, pfd;
+   bool operator==( const BrickShape& o ) const { return ny == o.ny && lz == o.lz && pfd == o.pfd; }
+};
+BrickShape g_shape_override{ 0, 0, 0 }; // hyteg_hip_set_apply_shape (tuning knob; 0 = the defaults below)
 
-// developer switches (measurement only).  HYTEG_HIP_APPLY_DECODE=1: bricks decoded from the task index instead of read from
-// the table (measured SLOWER: 12.0 vs 10.0 us at level 8 -- ~200 scalar instructions per wave on the CU's one scalar
-// unit cost more than the table's round trip; profiles/r02_apply_wave_trace_table_vs_decode.txt).
-// HYTEG_HIP_APPLY_PFD=1: loads run one slice ahead of the arithmetic instead of two (default 2: 9.45 vs 9.6-9.7 us at level 8
-// in three A/B pairs of bench.py on one box, gpurun_out r02e; round 1 had measured no difference).
-inline bool apply_decode_enabled()
+// defaults read off the sweep of every compiled shape x mode x level (tools/apply_shape_sweep.py,
+// profiles/r03_apply_shape_sweep.txt): levels <= 7 (few hundred bricks, cache-resident) want many short waves; level 8
+// (one generation of waves, HBM-bound) wants 8 slices and a short prologue, two rows for the two-stream kernels and four for
+// the three-stream ones; from level 9 on (several generations) 4 x 4, two slices ahead
+inline BrickShape default_shape( int mode, int level, bool f32 )
 {
-   static const bool on = [] {
-      const char* e = getenv( "HYTEG_HIP_APPLY_DECODE" );
-      return e && e[0] == '1';
-   }();
-   return on;
-}
-inline int apply_prefetch_distance()
-{
-   static const int pfd = [] {
-      const char* e = getenv( "HYTEG_HIP_APPLY_PFD" );
-      return ( e && e[0] == '1' ) ? 1 : 2;
-   }();
-   return pfd;
-}
-
-// HYTEG_HIP_APPLY_PRELOAD=0: the variant whose arguments all travel in the struct instead of the one whose first three are
-// preloaded into SGPRs (default on: 9.90-10.18 -> 9.60-9.74 us in four A/B pairs of bench.py on one box)
-inline bool apply_preload_enabled()
-{
-   static const bool v = [] {
-      const char* e = getenv( "HYTEG_HIP_APPLY_PRELOAD" );
-      return !( e && e[0] == '0' );
-   }();
-   return v;
+   if ( level <= 7 )
+      return ( mode == APPLY_REPLACE || f32 ) ? BrickShape{ 2, 4, 1 } : BrickShape{ 4, 4, 1 };
+   if ( level == 8 )
+   {
+      if ( mode == APPLY_REPLACE || f32 )
+         return BrickShape{ 2, 8, 1 };
+      return mode == APPLY_JACOBI ? BrickShape{ 4, 8, 2 } : BrickShape{ 4, 8, 1 };
+   }
+   return BrickShape{ 4, 4, 2 };
 }
 
-// HYTEG_HIP_APPLY_ALIGNED=1: bricks 56 outputs wide whose store windows begin on 64-byte boundaries of dst (XS = 56 of
-// kernels_apply_zmarch.hpp) instead of 62 outputs wide at x = 1 + 62 k
-inline bool apply_aligned_enabled()
-{
-   static const bool v = [] {
-      const char* e = getenv( "HYTEG_HIP_APPLY_ALIGNED" );
-      return e && e[0] == '1';
-   }();
-   return v;
-}
-
-template < int MODE, int LZ, typename T = double, int XS = 62 >
-int launch_zmarch_lz( T* dst, const T* src, const T* rhs, const T* invdiag, int level, const double* w, double relax, hipStream_t stream )
+template < int MODE, int NY, int LZ, int PFD, typename T >
+int launch_zmarch_shape( T* dst, const T* src, const T* rhs, const T* invdiag, int level, const double* w, double relax, hipStream_t stream )
 {
    BrickTable bt;
-   int        rc = get_bricks( level, kBrickNY, LZ, &bt, XS );
+   int        rc = get_bricks( level, NY, LZ, &bt );
    if ( rc != HYTEG_HIP_OK )
       return rc;
    if ( bt.count == 0 )
@@ -82,9 +63,6 @@ int launch_zmarch_lz( T* dst, const T* src, const T* rhs, const T* invdiag, int 
    A.relax   = relax;
    for ( int k = 0; k < 15; ++k )
       A.st.w[k] = w[k];
-   static_assert( sizeof( bt.zs ) == sizeof( A.zs ), "z-chunk table sizes" );
-   for ( int k = 0; k < kZMarchMaxZChunks; ++k )
-      A.zs[k] = bt.zs[k];
    int nblocks = ( bt.count + kZMarchWavesPerBlock - 1 ) / kZMarchWavesPerBlock;
    nblocks     = ( nblocks + 7 ) & ~7;
    A.xcd_chunk = nblocks / 8;
@@ -92,40 +70,55 @@ int launch_zmarch_lz( T* dst, const T* src, const T* rhs, const T* invdiag, int 
    // inverse diagonal of Jacobi are re-read by the next sweep of the smoother and stay plain (nontemporal: 12.4 -> 17.6 us
    // when they are still in the Infinity Cache, -2% when they are not).
    constexpr int kExAux = MODE == APPLY_ADD ? 2 : 0; // (the right-hand side of the residual mode is re-read by the cycle: plain)
-   const dim3 grid( nblocks ), block( 64 * kZMarchWavesPerBlock );
-   if constexpr ( XS != 62 )
-      hipLaunchKernelGGL( ( p1_apply_zmarch_preload_kernel< MODE, kBrickNY, LZ, kExAux, false, 2, T, XS > ), grid, block, 0, stream, A.tasks,
-                          A.ntasks, A.xcd_chunk, A );
-   else if constexpr ( !std::is_same< T, double >::value )
-   {
-      if ( apply_preload_enabled() )
-         hipLaunchKernelGGL( ( p1_apply_zmarch_preload_kernel< MODE, kBrickNY, LZ, kExAux, false, 2, T > ), grid, block, 0, stream, A.tasks,
-                             A.ntasks, A.xcd_chunk, A );
-      else
-         hipLaunchKernelGGL( ( p1_apply_zmarch_kernel< MODE, kBrickNY, LZ, kExAux, false, 2, T > ), grid, block, 0, stream, A );
-   }
-   else if ( bt.decodable && apply_decode_enabled() )
-      hipLaunchKernelGGL( ( p1_apply_zmarch_kernel< MODE, kBrickNY, LZ, kExAux, true > ), grid, block, 0, stream, A );
-   else if ( apply_prefetch_distance() == 1 )
-      hipLaunchKernelGGL( ( p1_apply_zmarch_kernel< MODE, kBrickNY, LZ, kExAux, false, 1 > ), grid, block, 0, stream, A );
-   else if ( apply_preload_enabled() )
-      hipLaunchKernelGGL( ( p1_apply_zmarch_preload_kernel< MODE, kBrickNY, LZ, kExAux, false, 2 > ), grid, block, 0, stream, A.tasks, A.ntasks,
-                          A.xcd_chunk, A );
-   else
-      hipLaunchKernelGGL( ( p1_apply_zmarch_kernel< MODE, kBrickNY, LZ, kExAux, false, 2 > ), grid, block, 0, stream, A );
+   // the first three arguments are preloaded into SGPRs (-mllvm -amdgpu-kernarg-preload-count=4): the task load does not wait
+   // for a kernel-argument load (round 2: 9.90-10.18 -> 9.60-9.74 us)
+   hipLaunchKernelGGL( ( p1_apply_zmarch_preload_kernel< MODE, NY, LZ, kExAux, false, PFD, T > ), dim3( nblocks ), dim3( 64 * kZMarchWavesPerBlock ), 0,
+                       stream, A.tasks, A.ntasks, A.xcd_chunk, A );
    HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;
+}
+
+// the shapes compiled in: the defaults and the runners-up of the sweep (so that the sweep can be repeated on another box)
+#define HYTEG_ZM_SHAPES( X ) X( 2, 8, 1 ) X( 4, 8, 2 ) X( 4, 8, 1 ) X( 4, 4, 2 ) X( 4, 4, 1 ) X( 2, 4, 1 )
+
+inline bool shape_compiled( const BrickShape& s )
+{
+#define HH_X( NY_, LZ_, PFD_ ) \
+   if ( s == BrickShape{ NY_, LZ_, PFD_ } ) \
+      return true;
+   HYTEG_ZM_SHAPES( HH_X )
+#undef HH_X
+   return false;
+}
+
+// the shape of a launch: hyteg_hip_set_apply_shape, else HYTEG_HIP_APPLY_SHAPE=NYxLZxPFD from the environment (read once;
+// lets tools/gpu/r03_shapes.sh A/B whole bench.py runs), else the default of the mode and level
+inline BrickShape current_shape( int mode, int level, bool f32 )
+{
+   static const BrickShape env = [] {
+      BrickShape  e{ 0, 0, 0 };
+      const char* v = getenv( "HYTEG_HIP_APPLY_SHAPE" );
+      if ( v && sscanf( v, "%dx%dx%d", &e.ny, &e.lz, &e.pfd ) != 3 )
+         e = BrickShape{ -1, -1, -1 }; // unparsable: every launch fails with "not compiled in"
+      return e;
+   }();
+   if ( g_shape_override.ny )
+      return g_shape_override;
+   if ( env.ny )
+      return env;
+   return default_shape( mode, level, f32 );
 }
 
 template < int MODE, typename T = double >
 int launch_zmarch( T* dst, const T* src, const T* rhs, const T* invdiag, int level, const double* w, double relax, hipStream_t stream )
 {
-   if constexpr ( MODE == APPLY_REPLACE && std::is_same< T, double >::value )
-      if ( brick_lz( level ) == 8 && apply_aligned_enabled() )
-         return launch_zmarch_lz< MODE, 8, T, 56 >( dst, src, rhs, invdiag, level, w, relax, stream );
-   if ( brick_lz( level ) == 8 )
-      return launch_zmarch_lz< MODE, 8, T >( dst, src, rhs, invdiag, level, w, relax, stream );
-   return launch_zmarch_lz< MODE, 4, T >( dst, src, rhs, invdiag, level, w, relax, stream );
+   const BrickShape s = current_shape( MODE, level, !std::is_same< T, double >::value );
+#define HH_X( NY_, LZ_, PFD_ ) \
+   if ( s == BrickShape{ NY_, LZ_, PFD_ } ) \
+      return launch_zmarch_shape< MODE, NY_, LZ_, PFD_, T >( dst, src, rhs, invdiag, level, w, relax, stream );
+   HYTEG_ZM_SHAPES( HH_X )
+#undef HH_X
+   return fail( HYTEG_HIP_EINVAL, "apply: brick shape not compiled in" );
 }
 
 template < int MODE >
@@ -244,21 +237,20 @@ HYTEG_HIP_API int hyteg_hip_p1_apply_kernel_name( int level, int update, char* b
       snprintf( buf, buflen, "p1_apply_tiled_kernel<MODE=%d>", mode );
       return HYTEG_HIP_OK;
    }
-   const int  lz = brick_lz( level );
-   BrickTable bt;
-   int        rc = lz == 8 ? get_bricks( level, kBrickNY, 8, &bt ) : get_bricks( level, kBrickNY, 4, &bt );
-   if ( rc != HYTEG_HIP_OK )
-      return rc;
-   const bool dec = bt.decodable && apply_decode_enabled();
-   const int  pfd = dec ? 1 : apply_prefetch_distance();
-   const bool pre = !dec && pfd == 2 && apply_preload_enabled(); // as in launch_zmarch_lz
-   if ( mode == APPLY_REPLACE && lz == 8 && apply_aligned_enabled() )
+   const BrickShape s = current_shape( mode, level, false );
+   snprintf( buf, buflen, "p1_apply_zmarch_preload_kernel<MODE=%d,NY=%d,LZ=%d,EX_AUX=%d,DEC=0,PFD=%d>", mode, s.ny, s.lz, mode == APPLY_ADD ? 2 : 0, s.pfd );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_set_apply_shape( int ny, int lz, int pfd )
+{
+   if ( ny == 0 && lz == 0 && pfd == 0 )
    {
-      snprintf( buf, buflen, "p1_apply_zmarch_preload_kernel<MODE=%d,NY=%d,LZ=%d,EX_AUX=0,DEC=0,PFD=2,XS=56>", mode, kBrickNY, lz );
+      g_shape_override = BrickShape{ 0, 0, 0 };
       return HYTEG_HIP_OK;
    }
-   snprintf( buf, buflen, "%s<MODE=%d,NY=%d,LZ=%d,EX_AUX=%d,DEC=%d,PFD=%d>", pre ? "p1_apply_zmarch_preload_kernel" : "p1_apply_zmarch_kernel", mode,
-             kBrickNY, lz, mode == APPLY_ADD ? 2 : 0, dec ? 1 : 0, pfd );
+   HH_REQUIRE( shape_compiled( BrickShape{ ny, lz, pfd } ), "set_apply_shape: this brick shape is not compiled in (p1_apply.hip: HYTEG_ZM_SHAPES)" );
+   g_shape_override = BrickShape{ ny, lz, pfd };
    return HYTEG_HIP_OK;
 }
 

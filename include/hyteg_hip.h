@@ -153,9 +153,14 @@ HYTEG_HIP_API int hyteg_hip_convert_f32_to_f64( double* dst, const float* src, s
 HYTEG_HIP_API int hyteg_hip_axpy_f32_into_f64( double* y, const float* x, double alpha, size_t n, hyteg_hip_stream_t stream );
 
 /* Name of the kernel instantiation hyteg_hip_p1_apply_cell( ..., level, ..., update, ... ) launches on the current device,
- * with its template arguments, e.g. "p1_apply_zmarch_kernel<MODE=0,NY=4,LZ=8,EX_AUX=0,DEC=1,PFD=1>" — what profiler
+ * with its template arguments, e.g. "p1_apply_zmarch_preload_kernel<MODE=0,NY=2,LZ=8,EX_AUX=0,DEC=0,PFD=1>" — what profiler
  * output and recorded counter files are matched against (no reference counterpart: measurement support). */
 HYTEG_HIP_API int hyteg_hip_p1_apply_kernel_name( int level, int update, char* buf, size_t buflen );
+/* Tuning knob (measurement support, like hyteg_hip_set_sor_algorithm): brick shape of the z-march apply / Jacobi / residual
+ * kernels for all later launches of this process -- ny rows x lz slices per wave, loads pfd slices ahead of the arithmetic.
+ * Only shapes compiled into the library are accepted (EINVAL otherwise); ( 0, 0, 0 ) restores the per-level defaults.
+ * Results do not depend on the shape (same terms in the same order at every point). */
+HYTEG_HIP_API int hyteg_hip_set_apply_shape( int ny, int lz, int pfd );
 
 /* ---- a4: weighted Jacobi sweep, fused ------------------------------------------------------------------
  * replaces the 1 apply + 3 vector passes of P1Operator::smooth_jac

@@ -57,6 +57,52 @@ def test_apply_replace_and_add(env, level, tet):
         assert _rel(got[m], ref[m]) < TOL
 
 
+COMPILED_SHAPES = [(2, 8, 1), (4, 8, 2), (4, 8, 1), (4, 4, 2), (4, 4, 1), (2, 4, 1)]  # HYTEG_ZM_SHAPES of p1_apply.hip
+
+
+@pytest.mark.parametrize("level", [3, 6, 8])
+def test_every_compiled_brick_shape_gives_the_same_bits(env, level):
+    """hyteg_hip_set_apply_shape changes the work split between waves, not the arithmetic of a point: apply (Replace, Add),
+    fused Jacobi and the residual are bit-identical for every shape compiled in (and equal to the oracle: the tests above
+    run the default shapes)"""
+    torch, capi, po = env
+    rng = np.random.default_rng(7 + level)
+    w = po.assemble_cell_stencil(SKEW_TET, level)
+    n = po.cell_size(level)
+    src, rhs, dst0 = (_dev(torch, rng.random(n)) for _ in range(3))
+    st = _stream(torch)
+
+    def run_all():
+        out = []
+        for update in (capi.REPLACE, capi.ADD):
+            d = dst0.clone()
+            capi.p1_apply_cell(d.data_ptr(), src.data_ptr(), level, w, update, st)
+            out.append(d)
+        d = dst0.clone()
+        capi.p1_jacobi_cell(d.data_ptr(), rhs.data_ptr(), src.data_ptr(), level, w, 0.7, None, st)
+        out.append(d)
+        d = dst0.clone()
+        capi.p1_residual_cell(d.data_ptr(), rhs.data_ptr(), src.data_ptr(), level, w, st)
+        out.append(d)
+        sf, rf, df = src.float(), rhs.float(), dst0.float()
+        capi.p1_jacobi_cell_f32(df.data_ptr(), rf.data_ptr(), sf.data_ptr(), level, w, 0.7, None, st)
+        out.append(df)
+        torch.cuda.synchronize()
+        return [o.cpu().numpy() for o in out]
+
+    try:
+        ref = run_all()
+        for shape in COMPILED_SHAPES:
+            capi.set_apply_shape(*shape)
+            got = run_all()
+            for a, b in zip(got, ref):
+                assert np.array_equal(a, b), f"shape {shape} differs from the default shape at level {level}"
+        with pytest.raises(capi.HytegHipError, match="not compiled in"):
+            capi.set_apply_shape(3, 7, 1)
+    finally:
+        capi.set_apply_shape()
+
+
 def test_apply_random_weights_and_unaligned_source(env):
     """Non-symmetric random weights catch swapped stencil slots; a source pointer that is only 8-byte
     aligned exercises the scalar staging path."""

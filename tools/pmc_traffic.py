@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Post-process the PMC passes of hyteg_amd/csrc/exp/pmc_bench.sh (gpurun_out/pmc_bench/) into profiles/pmc_traffic.json:
-HBM bytes per launch of the apply kernel, FETCH_SIZE corrected with the factor calibrated in the same session on a copy
-kernel of known size and the same access width (MI355X_MICROARCH.md, HBM / rocprofv3 section).
+"""Post-process the PMC passes of tools/profile_bench.sh (gpurun_out/pmc_bench/) into profiles/pmc_traffic.json:
+HBM bytes per launch of the apply kernel, FETCH_SIZE corrected with the factor calibrated in the SAME passes on bench.py's
+copy-floor kernel (known size, same access width; MI355X_MICROARCH.md, HBM / rocprofv3 section).
 Usage: python tools/pmc_traffic.py [gpurun_out/pmc_bench] [round tag]"""
 import csv
 import glob
@@ -11,7 +11,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 src = Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "gpurun_out" / "pmc_bench"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
 COPY_BYTES = 2862209 * 8  # one level-8 cell array, read once and written once by the calibration copy kernel
 
 
@@ -37,8 +37,8 @@ def mean_counter(prefix, kernel_substr, counter):
 KERNEL = "p1_apply_zmarch_"  # p1_apply_zmarch_kernel or p1_apply_zmarch_preload_kernel (first arguments preloaded into SGPRs)
 fetch, nf = mean_counter("bench", KERNEL, "FETCH_SIZE")
 write, nw = mean_counter("bench", KERNEL, "WRITE_SIZE")
-cfetch, _ = mean_counter("calib", "calib_copy_kernel<false>", "FETCH_SIZE")
-cwrite, _ = mean_counter("calib", "calib_copy_kernel<false>", "WRITE_SIZE")
+cfetch, _ = mean_counter("bench", "calib_copy_kernel<true>", "FETCH_SIZE")
+cwrite, _ = mean_counter("bench", "calib_copy_kernel<true>", "WRITE_SIZE")
 kname = None
 for f in newest_per_pass("bench"):
     for r in csv.DictReader(open(f)):
@@ -82,11 +82,11 @@ out = {
     "read_bytes": int(round(read_b)),
     "write_bytes": int(round(write_b)),
     "kernel_as_rocprof_names_it": kname,
-    "method": "rocprofv3 --kernel-trace --pmc, separate passes for FETCH_SIZE and WRITE_SIZE over `python3 bench.py --steps 200 "
-              f"--warmup 20 --no-cpu-baseline` ({nf} / {nw} dispatches, level 8, rotating buffers); counters are in KiB "
-              "(hyteg_amd/csrc/exp/pmc_bench.sh, tools/pmc_traffic.py)",
+    "method": "rocprofv3 --kernel-trace --pmc, separate passes for FETCH_SIZE and WRITE_SIZE over `python3 bench.py --steps 100 "
+              f"--warmup 20 --regions 2 --no-cpu-baseline` ({nf} / {nw} dispatches, level 8, rotating buffers); counters are in KiB "
+              "(tools/profile_bench.sh, tools/pmc_traffic.py)",
     "raw": {"FETCH_SIZE_avg_KiB": fetch, "WRITE_SIZE_avg_KiB": write, "calib_FETCH_SIZE_avg_KiB": cfetch, "calib_WRITE_SIZE_avg_KiB": cwrite},
-    "gfx950_correction": f"calibration copy kernel (8 B per lane, {COPY_BYTES} B known each way): FETCH_SIZE*1024*{kf:.3f} = known bytes, "
+    "gfx950_correction": f"bench.py's copy-floor kernel in the same passes (8 B per lane, {COPY_BYTES} B known each way): FETCH_SIZE*1024*{kf:.3f} = known bytes, "
                          f"WRITE_SIZE*1024*{kw:.3f} = known bytes; the apply's figures use these factors "
                          "(FETCH_SIZE reports half of a coalesced stream on gfx950, MI355X_MICROARCH.md)",
     "algorithmic_bytes_per_launch": alg,
