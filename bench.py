@@ -246,10 +246,9 @@ def main():
                                 f"{ctx.inner_transport}")
         p2p["used_before"] = ctx.transport == "p2p"
 
-    def apply_steps(first, count):
-        # `count` applies, step k on ring pair (first + k) % nbuf, issued by the C++ host layer's own loop (what a C++
-        # application writes around apply(); one ctypes call for the whole region)
-        laplace.apply_cycle(srcs, dsts, level, host.Inner, host.Replace, first=first, steps=count)
+    # `count` applies, step k on ring pair (first + k) % nbuf, issued by the C++ host layer's own loop (what a C++
+    # application writes around apply(); one ctypes call for the whole region, its handle arrays built here)
+    apply_steps = laplace.prepared_cycle(srcs, dsts, level, host.Inner, host.Replace)
 
     copy_ptrs = [[(dsts[k].cell_pointer(c, level), srcs[k].cell_pointer(c, level)) for c in range(storage.n_local_cells)]
                  for k in range(nbuf)]

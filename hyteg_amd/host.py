@@ -420,9 +420,18 @@ class P1ConstantOperator:
 
     def apply_cycle(self, srcs, dsts, level, flag, update=Replace, first=0, steps=1):
         """`steps` applies, step k on pair (first + k) % len(srcs): the loop a C++ application writes around apply()"""
+        self.prepared_cycle(srcs, dsts, level, flag, update)(first, steps)
+
+    def prepared_cycle(self, srcs, dsts, level, flag, update=Replace):
+        """apply_cycle with the handle arrays built once: returns call(first, steps)"""
         n = len(srcs)
         hs, hd = (_vp * n)(*[f.h for f in srcs]), (_vp * n)(*[f.h for f in dsts])
-        _ck(lib().hyteg_host_operator_apply_cycle(self.h, n, hs, hd, level, flag, update, first, steps), "apply_cycle")
+        fn, h = lib().hyteg_host_operator_apply_cycle, self.h
+
+        def call(first, steps):
+            _ck(fn(h, n, hs, hd, level, flag, update, first, steps), "apply_cycle")
+
+        return call
 
     def smooth_jac(self, dst, rhs, src, relax, level, flag):
         _ck(lib().hyteg_host_operator_smooth_jac(self.h, dst.h, rhs.h, src.h, float(relax), level, flag), "smooth_jac")
