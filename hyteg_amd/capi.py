@@ -119,6 +119,14 @@ SIGNATURES = {
     "hyteg_hip_p1_sor_face3d_workspace": (C.c_size_t, [_i]),
     "hyteg_hip_p1_sor_face3d": (_i, [_vp, _vp, _vp, _i, _i, C.POINTER(_i), _dp, C.c_double, _i, _vp]),
     "hyteg_hip_gather_entries": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "hyteg_hip_p1_elementwise_diffusion_apply_macro_3d": (_i, [_vp, _vp, _dp, _i64, _d, _vp]),
+    "hyteg_hip_p1_elementwise_diffusion_apply_macro_3d_masked": (_i, [_vp, _vp, _dp, _i64, C.c_uint, _i, _vp]),
+    "hyteg_hip_p1_elementwise_diffusion_apply_macro_3d_f32": (_i, [_vp, _vp, C.POINTER(C.c_float), _i64, C.c_float, _vp]),
+    "hyteg_hip_p1_elementwise_diffusion_diagonal_macro_3d": (_i, [_vp, _dp, _i64, _d, _vp]),
+    "hyteg_hip_p1_elementwise_diffusion_stencils": (_i, [_dp, _i64, _dp, _dp]),
+    "hyteg_hip_p1_apply_cell_boundary_f32": (_i, [_vp, _vp, _i, _dp, C.c_uint, _i, _vp]),
+    "hyteg_hip_p2_elementwise_diffusion_apply_macro_3d": (_i, [_vp, _vp, _vp, _vp, _dp, _i64, _d, _vp]),
+    "hyteg_hip_p2_elementwise_diffusion_element_matrices": (_i, [_dp, _i64, _dp]),
 }
 MASK_INNER, MASK_SHELL, MASK_ALL = 1 << 14, 0x3FFF, 0x7FFF
 
@@ -513,3 +521,62 @@ def p1_apply_face3d(dst, src, level, vmaps, ws, update=REPLACE, stream=0):
     n = len(flat_v) // 3
     check(lib().hyteg_hip_p1_apply_face3d(dst, src, level, n, (C.c_int * len(flat_v))(*flat_v), (C.c_double * len(flat_w))(*flat_w),
                                           update, stream), "p1_apply_face3d")
+
+
+# ---- the hyteg_operators seam (generated elementwise operators: apply_macro_3D) ----
+def _c12(coords):
+    flat = [float(x) for v in coords for x in (v if hasattr(v, "__len__") else [v])]
+    if len(flat) != 12:
+        raise HytegHipError("macro_vertex_coords: 4 vertices x 3 components expected")
+    return flat
+
+
+def p1_elementwise_diffusion_apply_macro_3d(dst, src, coords, micro_edges, stream=0):
+    a = (C.c_double * 12)(*_c12(coords))
+    check(lib().hyteg_hip_p1_elementwise_diffusion_apply_macro_3d(dst, src, a, int(micro_edges), float(micro_edges), stream),
+          "p1_elementwise_diffusion_apply_macro_3d")
+
+
+def p1_elementwise_diffusion_apply_macro_3d_masked(dst, src, coords, micro_edges, mask=MASK_ALL, update=ADD, stream=0):
+    a = (C.c_double * 12)(*_c12(coords))
+    check(lib().hyteg_hip_p1_elementwise_diffusion_apply_macro_3d_masked(dst, src, a, int(micro_edges), mask, update, stream),
+          "p1_elementwise_diffusion_apply_macro_3d_masked")
+
+
+def p1_elementwise_diffusion_apply_macro_3d_f32(dst, src, coords, micro_edges, stream=0):
+    a = (C.c_float * 12)(*_c12(coords))
+    check(lib().hyteg_hip_p1_elementwise_diffusion_apply_macro_3d_f32(dst, src, a, int(micro_edges), float(micro_edges), stream),
+          "p1_elementwise_diffusion_apply_macro_3d_f32")
+
+
+def p1_elementwise_diffusion_diagonal_macro_3d(diag, coords, micro_edges, stream=0):
+    a = (C.c_double * 12)(*_c12(coords))
+    check(lib().hyteg_hip_p1_elementwise_diffusion_diagonal_macro_3d(diag, a, int(micro_edges), float(micro_edges), stream),
+          "p1_elementwise_diffusion_diagonal_macro_3d")
+
+
+def p1_elementwise_diffusion_stencils(coords, micro_edges):
+    """(w_inner[15], w_slots[14][15]) as Python lists: host-only, no GPU needed"""
+    a = (C.c_double * 12)(*_c12(coords))
+    wi, ws = (C.c_double * 15)(), (C.c_double * 210)()
+    check(lib().hyteg_hip_p1_elementwise_diffusion_stencils(a, int(micro_edges), wi, ws), "p1_elementwise_diffusion_stencils")
+    return list(wi), [list(ws[15 * s:15 * s + 15]) for s in range(14)]
+
+
+def p1_apply_cell_boundary_f32(dst, src, level, w_slots, mask=MASK_SHELL, update=REPLACE, stream=0):
+    flat = [float(x) for row in w_slots for x in row]
+    a = (C.c_double * 210)(*flat)
+    check(lib().hyteg_hip_p1_apply_cell_boundary_f32(dst, src, level, a, mask, update, stream), "p1_apply_cell_boundary_f32")
+
+
+def p2_elementwise_diffusion_apply_macro_3d(dst_v, dst_e, src_v, src_e, coords, micro_edges, stream=0):
+    a = (C.c_double * 12)(*_c12(coords))
+    check(lib().hyteg_hip_p2_elementwise_diffusion_apply_macro_3d(dst_v, dst_e, src_v, src_e, a, int(micro_edges), float(micro_edges), stream),
+          "p2_elementwise_diffusion_apply_macro_3d")
+
+
+def p2_elementwise_diffusion_element_matrices(coords, micro_edges):
+    a = (C.c_double * 12)(*_c12(coords))
+    out = (C.c_double * 600)()
+    check(lib().hyteg_hip_p2_elementwise_diffusion_element_matrices(a, int(micro_edges), out), "p2_elementwise_diffusion_element_matrices")
+    return list(out)

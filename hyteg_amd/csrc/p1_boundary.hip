@@ -13,8 +13,9 @@ constexpr int kThreads = 256;
 
 using namespace hyteg_hip::shell;
 
-__global__ __launch_bounds__( kThreads ) void p1_apply_shell_kernel( double* __restrict__ dst,
-                                                                      const double* __restrict__ src,
+template < typename T >
+__global__ __launch_bounds__( kThreads ) void p1_apply_shell_kernel( T* __restrict__ dst,
+                                                                      const T* __restrict__ src,
                                                                       int              N,
                                                                       unsigned         mask,
                                                                       int              update,
@@ -24,9 +25,9 @@ __global__ __launch_bounds__( kThreads ) void p1_apply_shell_kernel( double* __r
    int       x, y, z, slot;
    if ( !shell_point( N, q, x, y, z, slot ) || !( ( mask >> slot ) & 1u ) )
       return;
-   const double acc = share( S, src, N, x, y, z, slot );
-   const int    i   = cell_index( N, x, y, z );
-   dst[i]           = update == HYTEG_HIP_ADD ? acc + dst[i] : acc;
+   const T   acc = share< T >( S, src, N, x, y, z, slot );
+   const int i   = cell_index( N, x, y, z );
+   dst[i]        = update == HYTEG_HIP_ADD ? acc + dst[i] : acc;
 }
 
 // The shares of a rank's ONE macro-cell, delivered as they are computed: a point whose share other ranks need (send_first /
@@ -468,7 +469,34 @@ HYTEG_HIP_API int hyteg_hip_p1_apply_cell_boundary( double*            dst,
       for ( int k = 0; k < 15; ++k )
          S.w[s][k] = w_slots[15 * s + k];
    const int N = ( 1 << level ) + 1;
-   hipLaunchKernelGGL( p1_apply_shell_kernel, dim3( shell_blocks( N ) ), dim3( kThreads ), 0, as_stream( stream ), dst, src, N,
+   hipLaunchKernelGGL( p1_apply_shell_kernel< double >, dim3( shell_blocks( N ) ), dim3( kThreads ), 0, as_stream( stream ), dst, src, N,
+                       mask & HYTEG_HIP_MASK_SHELL, update, S );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
+// float instantiation (the generated elementwise operators exist for float32 as well:
+// apps/2023-zikeli-mt/MT-apps/operators-used/P1ElementwiseDiffusion_cubes_const_float32.hpp); weights arrive as doubles
+HYTEG_HIP_API int hyteg_hip_p1_apply_cell_boundary_f32( float*             dst,
+                                                        const float*       src,
+                                                        int                level,
+                                                        const double*      w_slots,
+                                                        unsigned           mask,
+                                                        int                update,
+                                                        hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( dst && src && w_slots, "p1_apply_cell_boundary_f32: null pointer" );
+   HH_REQUIRE( shell_level_ok( level ), "p1_apply_cell_boundary_f32: level out of range [0,11]" );
+   HH_REQUIRE( dst != src, "p1_apply_cell_boundary_f32: src and dst must not alias" );
+   HH_REQUIRE( update == HYTEG_HIP_REPLACE || update == HYTEG_HIP_ADD, "p1_apply_cell_boundary_f32: bad update type" );
+   if ( ( mask & HYTEG_HIP_MASK_SHELL ) == 0 )
+      return HYTEG_HIP_OK;
+   Slots14x15 S;
+   for ( int s = 0; s < 14; ++s )
+      for ( int k = 0; k < 15; ++k )
+         S.w[s][k] = w_slots[15 * s + k];
+   const int N = ( 1 << level ) + 1;
+   hipLaunchKernelGGL( p1_apply_shell_kernel< float >, dim3( shell_blocks( N ) ), dim3( kThreads ), 0, as_stream( stream ), dst, src, N,
                        mask & HYTEG_HIP_MASK_SHELL, update, S );
    HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;

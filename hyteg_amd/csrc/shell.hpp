@@ -81,11 +81,13 @@ __device__ inline bool shell_point( int N, int q, int& x, int& y, int& z, int& s
 // outside the cell reads the point itself and is skipped by a select, so the sum is the same FMA chain as before.
 // Neighbour indices by layout algebra from the point's own index (w = length of row 0 of slice z):
 //   same slice: row y -> y + 1: + ( w - y ), y -> y - 1: - ( w - y + 1 );  slice z - 1: - tri( w + 1 ) + y';  z + 1: + tri( w ) - y'
-__device__ inline double share( const Slots14x15& S, const double* __restrict__ src, int N, int x, int y, int z, int slot )
+// T: value type of the arrays and of the arithmetic (double; float for the float instantiations of the elementwise seam)
+template < typename T = double >
+__device__ inline T share( const Slots14x15& S, const T* __restrict__ src, int N, int x, int y, int z, int slot )
 {
    const int w  = N - z;
    const int i0 = cell_index( N, x, y, z );
-   double    v[15], c[15];
+   T         v[15], c[15];
    bool      ok[15];
 #pragma unroll
    for ( int k = 0; k < 15; ++k )
@@ -96,9 +98,9 @@ __device__ inline double share( const Slots14x15& S, const double* __restrict__ 
       const int rowDelta   = dy == 0 ? 0 : ( dy > 0 ? ( w - y ) : -( w - y + 1 ) );
       const int sliceDelta = dz == 0 ? 0 : ( dz > 0 ? tri( w ) - ny : ny - tri( w + 1 ) );
       v[k]                 = src[ok[k] ? i0 + sliceDelta + rowDelta + dx : i0];
-      c[k]                 = S.w[slot][k];
+      c[k]                 = (T) S.w[slot][k];
    }
-   double acc = 0.0;
+   T acc = (T) 0;
 #pragma unroll
    for ( int k = 0; k < 15; ++k )
       acc = ok[k] ? fma( c[k], v[k], acc ) : acc;

@@ -82,6 +82,12 @@ SIGNATURES = {
     "hyteg_host_operator_smooth_sor": (_i, [_vp, _vp, _vp, _d, _i, _i, _i]),
     "hyteg_host_operator_compute_inverse_diagonal": (_i, [_vp]),
     "hyteg_host_operator_inverse_diagonal": (_i, [_vp, C.POINTER(_vp)]),
+    "hyteg_host_elementwise_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "hyteg_host_elementwise_destroy": (_i, [_vp]),
+    "hyteg_host_elementwise_apply": (_i, [_vp, _vp, _vp, _i, _i, _i]),
+    "hyteg_host_elementwise_compute_inverse_diagonal": (_i, [_vp]),
+    "hyteg_host_elementwise_inverse_diagonal": (_i, [_vp, C.POINTER(_vp)]),
+    "hyteg_host_elementwise_smooth_jac": (_i, [_vp, _vp, _vp, _vp, _d, _i, _i]),
     "hyteg_host_restrict": (_i, [_vp, _i, _i]),
     "hyteg_host_prolongate": (_i, [_vp, _i, _i]),
     "hyteg_host_prolongate_and_add": (_i, [_vp, _i, _i]),
@@ -453,6 +459,37 @@ class P1ConstantOperator:
     def close(self):
         if self.h:
             lib().hyteg_host_operator_destroy(self.h)
+            self.h = None
+
+
+class P1ElementwiseDiffusion:
+    """hyteg::operatorgeneration::P1ElementwiseDiffusion (the class the hyteg_operators generator emits): every apply goes
+    through the C-ABI seam hyteg_hip_p1_elementwise_diffusion_apply_macro_3d_masked with the cell's coordinates"""
+
+    def __init__(self, storage: Storage, min_level: int, max_level: int):
+        self.storage = storage
+        self.min_level, self.max_level = min_level, max_level
+        h = _vp()
+        _ck(lib().hyteg_host_elementwise_create(storage.h, min_level, max_level, C.byref(h)), "elementwise_create")
+        self.h = h
+
+    def apply(self, src, dst, level, flag, update=Replace):
+        _ck(lib().hyteg_host_elementwise_apply(self.h, src.h, dst.h, level, flag, update), "elementwise apply")
+
+    def compute_inverse_diagonal(self):
+        _ck(lib().hyteg_host_elementwise_compute_inverse_diagonal(self.h), "computeInverseDiagonalOperatorValues")
+
+    def inverse_diagonal(self):
+        h = _vp()
+        _ck(lib().hyteg_host_elementwise_inverse_diagonal(self.h, C.byref(h)), "getInverseDiagonalValues")
+        return P1Function(self.storage, "invdiag", self.min_level, self.max_level, _borrowed=h)
+
+    def smooth_jac(self, dst, rhs, src, relax, level, flag):
+        _ck(lib().hyteg_host_elementwise_smooth_jac(self.h, dst.h, rhs.h, src.h, float(relax), level, flag), "elementwise smooth_jac")
+
+    def close(self):
+        if self.h:
+            lib().hyteg_host_elementwise_destroy(self.h)
             self.h = None
 
 

@@ -26,6 +26,7 @@
 #include "p2function.hpp"
 #include "forms.hpp"
 #include "p1operator.hpp"
+#include "p1elementwise.hpp"
 #include "p2operator.hpp"
 #include "p2gridtransfer.hpp"
 #include "gridtransfer.hpp"

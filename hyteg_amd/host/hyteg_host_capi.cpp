@@ -429,6 +429,46 @@ HYTEG_HOST_API int hyteg_host_operator_inverse_diagonal( hh_operator_t op, hh_fu
    } );
 }
 
+// ---- the generated elementwise operator class (module hyteg_operators): P1ElementwiseDiffusion ----
+struct ElementwiseH
+{
+   std::shared_ptr< operatorgeneration::P1ElementwiseDiffusion > p;
+   FunctionH                                                     invDiag; // borrowed view
+};
+HYTEG_HOST_API int hyteg_host_elementwise_create( hh_storage_t s, int minL, int maxL, hh_elementwise_t* out )
+{
+   return guarded( [&] {
+      auto* h = new ElementwiseH{};
+      h->p    = std::make_shared< operatorgeneration::P1ElementwiseDiffusion >( static_cast< StorageH* >( s )->p, (uint_t) minL, (uint_t) maxL );
+      *out    = h;
+   } );
+}
+HYTEG_HOST_API int hyteg_host_elementwise_destroy( hh_elementwise_t op )
+{
+   return guarded( [&] { delete static_cast< ElementwiseH* >( op ); } );
+}
+HYTEG_HOST_API int hyteg_host_elementwise_apply( hh_elementwise_t op, hh_function_t src, hh_function_t dst, int level, int flag, int update )
+{
+   return guarded( [&] { static_cast< ElementwiseH* >( op )->p->apply( F( src ), F( dst ), (uint_t) level, DoFType( flag ), update ? Add : Replace ); } );
+}
+HYTEG_HOST_API int hyteg_host_elementwise_compute_inverse_diagonal( hh_elementwise_t op )
+{
+   return guarded( [&] { static_cast< ElementwiseH* >( op )->p->computeInverseDiagonalOperatorValues(); } );
+}
+HYTEG_HOST_API int hyteg_host_elementwise_inverse_diagonal( hh_elementwise_t op, hh_function_t* out )
+{
+   return guarded( [&] {
+      auto* h      = static_cast< ElementwiseH* >( op );
+      h->invDiag.p = h->p->getInverseDiagonalValues();
+      *out         = &h->invDiag;
+   } );
+}
+HYTEG_HOST_API int hyteg_host_elementwise_smooth_jac( hh_elementwise_t op, hh_function_t dst, hh_function_t rhs, hh_function_t src, double relax,
+                                                      int level, int flag )
+{
+   return guarded( [&] { static_cast< ElementwiseH* >( op )->p->smooth_jac( F( dst ), F( rhs ), F( src ), relax, (uint_t) level, DoFType( flag ) ); } );
+}
+
 HYTEG_HOST_API int hyteg_host_restrict( hh_function_t f, int sourceLevel, int flag )
 {
    return guarded( [&] { P1toP1LinearRestriction().restrict( F( f ), (uint_t) sourceLevel, DoFType( flag ) ); } );

@@ -866,6 +866,81 @@ HYTEG_HIP_API int hyteg_hip_p2p_wait( const unsigned long long* flags,
                                       unsigned                  timeout_ms,
                                       hyteg_hip_stream_t        stream );
 
+/* ---- b-3: the seam of the generated elementwise operators (module hyteg_operators) ---------------------------------------
+ * The generated operators call, per macro-cell,
+ *    apply_macro_3D( dst*, src*, macro_vertex_coord_id_{0..3}comp{0..2} (12 scalars), int64 micro_edges_per_macro_edge,
+ *                    (value type) micro_edges_per_macro_edge_float )
+ * (apps/2023-zikeli-mt/MT-apps/operators-used/P1ElementwiseDiffusion_cubes_const_float64.hpp:95-130, kernel .cpp:782-;
+ * call site .cpp:76-165: halo synchronised and dst zeroed before, additive communication afterwards).  The entry points
+ * below have that argument list (the twelve coordinates as one array [vertex][component]) and that effect:
+ *    dst += ( operator of THIS macro-cell ) src   at ALL points of the cell array,
+ * i.e. the full stencil at inner points and this cell's share at points on its macro-faces / -edges / -vertices.
+ * The element matrices are computed on the host from the coordinates (constant per micro-cell type on an affine cell) and
+ * summed into the constant stencils of the 15 point classes; results agree with the reference's element-by-element
+ * scatter to rounding (the reference's own criterion for constant-stencil vs elementwise: < 1e-13,
+ * tests/hyteg/convergence/P1JacobiConvergenceTest.cpp:117).  micro_edges_per_macro_edge = 2^level, levels 0..11
+ * (float: 0..10). */
+HYTEG_HIP_API int hyteg_hip_p1_elementwise_diffusion_apply_macro_3d( double*            dst,
+                                                                     const double*      src,
+                                                                     const double*      macro_vertex_coords /* 12: [vertex][component] */,
+                                                                     int64_t            micro_edges_per_macro_edge,
+                                                                     double             micro_edges_per_macro_edge_float,
+                                                                     hyteg_hip_stream_t stream );
+/* The same kernel restricted to the point classes of `mask` (as hyteg_hip_p1_apply_cell_boundary: bit k < 14 = points on slot k,
+ * HYTEG_HIP_MASK_INNER = inner points) with REPLACE or ADD: for callers whose cell arrays hold the shared DoFs themselves (the
+ * host layer here) instead of a halo that may be zeroed.  ( HYTEG_HIP_MASK_ALL, HYTEG_HIP_ADD ) is the call above. */
+HYTEG_HIP_API int hyteg_hip_p1_elementwise_diffusion_apply_macro_3d_masked( double*            dst,
+                                                                            const double*      src,
+                                                                            const double*      macro_vertex_coords,
+                                                                            int64_t            micro_edges_per_macro_edge,
+                                                                            unsigned           mask,
+                                                                            int                update,
+                                                                            hyteg_hip_stream_t stream );
+/* float32 sibling (P1ElementwiseDiffusion_cubes_const_float32.hpp); stencils are summed in double and rounded to float */
+HYTEG_HIP_API int hyteg_hip_p1_elementwise_diffusion_apply_macro_3d_f32( float*             dst,
+                                                                         const float*       src,
+                                                                         const float*       macro_vertex_coords,
+                                                                         int64_t            micro_edges_per_macro_edge,
+                                                                         float              micro_edges_per_macro_edge_float,
+                                                                         hyteg_hip_stream_t stream );
+/* computeInverseDiagonalOperatorValues_macro_3D of the same operators: diag += the diagonal entries of the element matrices
+ * of the adjacent micro-cells at all points of the cell array (levels 0..10) */
+HYTEG_HIP_API int hyteg_hip_p1_elementwise_diffusion_diagonal_macro_3d( double*            diag,
+                                                                        const double*      macro_vertex_coords,
+                                                                        int64_t            micro_edges_per_macro_edge,
+                                                                        double             micro_edges_per_macro_edge_float,
+                                                                        hyteg_hip_stream_t stream );
+/* host helper: the stencils the calls above use -- w_inner[15] and w_slots[14][15] in the conventions of
+ * hyteg_hip_p1_apply_cell / hyteg_hip_p1_apply_cell_boundary */
+HYTEG_HIP_API int hyteg_hip_p1_elementwise_diffusion_stencils( const double* macro_vertex_coords,
+                                                               int64_t       micro_edges_per_macro_edge,
+                                                               double*       w_inner,
+                                                               double*       w_slots );
+/* float instantiation of hyteg_hip_p1_apply_cell_boundary (used by the float seam above) */
+HYTEG_HIP_API int hyteg_hip_p1_apply_cell_boundary_f32( float*             dst,
+                                                        const float*       src,
+                                                        int                level,
+                                                        const double*      w_slots,
+                                                        unsigned           mask,
+                                                        int                update,
+                                                        hyteg_hip_stream_t stream );
+/* P2 form of the seam (generated P2ElementwiseDiffusion; its source is absent from the snapshot -- call sites
+ * src/hyteg_operators_composites/viscousblock/P2ViscousBlockLaplaceOperator.hpp:29,66 -- so the ORDER of the four array
+ * arguments is this header's convention, vertex before edge: parity unpinned for the argument order).
+ * dst += A_cell src on all vertex and edge DoFs of the macro-cell; levels 0..9.  The six 10 x 10 element matrices
+ * (FEniCS ordering, micro-cell types in the order of celldof::allCellTypes) are available through the second call. */
+HYTEG_HIP_API int hyteg_hip_p2_elementwise_diffusion_apply_macro_3d( double*            dst_vertex,
+                                                                     double*            dst_edge,
+                                                                     const double*      src_vertex,
+                                                                     const double*      src_edge,
+                                                                     const double*      macro_vertex_coords,
+                                                                     int64_t            micro_edges_per_macro_edge,
+                                                                     double             micro_edges_per_macro_edge_float,
+                                                                     hyteg_hip_stream_t stream );
+HYTEG_HIP_API int hyteg_hip_p2_elementwise_diffusion_element_matrices( const double* macro_vertex_coords,
+                                                                       int64_t       micro_edges_per_macro_edge,
+                                                                       double*       elmat /* 600 */ );
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,7 @@ typedef void* hh_operator_t;
 typedef void* hh_solver_t;
 typedef void* hh_p2function_t;
 typedef void* hh_p2operator_t;
+typedef void* hh_elementwise_t;
 typedef void* hh_stokes_function_t;
 typedef void* hh_stokes_operator_t;
 typedef void* hh_stokes_solver_t;
@@ -126,6 +127,19 @@ HYTEG_HOST_API int hyteg_host_operator_smooth_jac( hh_operator_t op, hh_function
 HYTEG_HOST_API int hyteg_host_operator_smooth_sor( hh_operator_t op, hh_function_t dst, hh_function_t rhs, double relax, int level, int flag, int backwards );
 HYTEG_HOST_API int hyteg_host_operator_compute_inverse_diagonal( hh_operator_t op );
 HYTEG_HOST_API int hyteg_host_operator_inverse_diagonal( hh_operator_t op, hh_function_t* out /* borrowed */ );
+
+/* hyteg::operatorgeneration::P1ElementwiseDiffusion (module hyteg_operators; sample class
+ * apps/2023-zikeli-mt/MT-apps/operators-used/P1ElementwiseDiffusion_cubes_const_float64.hpp:64-93): apply() hands every
+ * macro-cell's arrays, vertex coordinates and micro_edges_per_macro_edge to the C-ABI seam
+ * hyteg_hip_p1_elementwise_diffusion_apply_macro_3d_masked; computeInverseDiagonalOperatorValues / getInverseDiagonalValues;
+ * smooth_jac as P1ElementwiseOperator.cpp:288-331 */
+HYTEG_HOST_API int hyteg_host_elementwise_create( hh_storage_t s, int min_level, int max_level, hh_elementwise_t* out );
+HYTEG_HOST_API int hyteg_host_elementwise_destroy( hh_elementwise_t op );
+HYTEG_HOST_API int hyteg_host_elementwise_apply( hh_elementwise_t op, hh_function_t src, hh_function_t dst, int level, int flag, int update );
+HYTEG_HOST_API int hyteg_host_elementwise_compute_inverse_diagonal( hh_elementwise_t op );
+HYTEG_HOST_API int hyteg_host_elementwise_inverse_diagonal( hh_elementwise_t op, hh_function_t* out /* borrowed */ );
+HYTEG_HOST_API int hyteg_host_elementwise_smooth_jac( hh_elementwise_t op, hh_function_t dst, hh_function_t rhs, hh_function_t src, double relax,
+                                                      int level, int flag );
 
 /* ---- grid transfer ---- */
 HYTEG_HOST_API int hyteg_host_restrict( hh_function_t f, int source_level, int flag );

@@ -1247,6 +1247,75 @@ HO_API void ho_p2_cell_element_matrices( double* elmat, const double* cell_coord
    }
 }
 
+/* The generated elementwise P1 diffusion operator's macro-cell kernel,
+ * apps/2023-zikeli-mt/MT-apps/operators-used/P1ElementwiseDiffusion_cubes_const_float64.cpp:782- (apply_macro_3D: per
+ * micro-cell type the element matrix of the affine micro-cell from the twelve macro-vertex coordinates, then for every
+ * micro-cell of that type dst[v_i] += sum_j elMat_ij src[v_j]), which is the loop of the in-tree
+ * P1ElementwiseOperator::apply (src/hyteg/elementwiseoperators/P1ElementwiseOperator.cpp:158-178 with
+ * localMatrixVectorMultiply3D, P1LocalOperations.hpp:85-114) with the element matrix hoisted out of the micro-cell loop.
+ * Literal restatement: micro-cell types in the order of celldof::allCellTypes, micro-cells in iterator order, the element
+ * matrix from ho_p1_tet_diffusion (pinned to the reference's p1_tet_diffusion.h through oracle/_ref); dst is ADDED to at every
+ * point of the cell array, boundary points included. */
+HO_API void ho_p1_elementwise_apply_macro_3d( double* dst, const double* src, const double* cell_coords12, int64_t micro_edges )
+{
+   int level = 0;
+   while ( ( (int64_t) 1 << level ) < micro_edges )
+      ++level;
+   const int64_t N = ho_width( level ), n = N - 1;
+   for ( int t = 0; t < 6; ++t )
+   {
+      double c[12], M[16];
+      for ( int k = 0; k < 4; ++k )
+         ho_coordinate_from_index( c + 3 * k, cell_coords12, level, MICRO_CELL_VERTS[t][k][0], MICRO_CELL_VERTS[t][k][1],
+                                   MICRO_CELL_VERTS[t][k][2] );
+      ho_p1_tet_diffusion( M, c );
+      const int64_t rows = n - MICRO_CELL_ROW_DEFICIT[t];
+      for ( int64_t z = 0; z < rows; ++z )
+         for ( int64_t y = 0; y < rows - z; ++y )
+            for ( int64_t x = 0; x < rows - z - y; ++x )
+            {
+               int64_t idx[4];
+               double  old[4];
+               for ( int k = 0; k < 4; ++k )
+               {
+                  idx[k] = cell_index_w( N, x + MICRO_CELL_VERTS[t][k][0], y + MICRO_CELL_VERTS[t][k][1], z + MICRO_CELL_VERTS[t][k][2] );
+                  old[k] = src[idx[k]];
+               }
+               for ( int k = 0; k < 4; ++k )
+               {
+                  double sum = 0.0;
+                  for ( int j = 0; j < 4; ++j )
+                     sum = sum + M[4 * k + j] * old[j];
+                  dst[idx[k]] += sum;
+               }
+            }
+   }
+}
+
+/* computeInverseDiagonalOperatorValues_macro_3D of the same operator: diag[v_i] += elMat_ii over all micro-cells */
+HO_API void ho_p1_elementwise_diagonal_macro_3d( double* diag, const double* cell_coords12, int64_t micro_edges )
+{
+   int level = 0;
+   while ( ( (int64_t) 1 << level ) < micro_edges )
+      ++level;
+   const int64_t N = ho_width( level ), n = N - 1;
+   for ( int t = 0; t < 6; ++t )
+   {
+      double c[12], M[16];
+      for ( int k = 0; k < 4; ++k )
+         ho_coordinate_from_index( c + 3 * k, cell_coords12, level, MICRO_CELL_VERTS[t][k][0], MICRO_CELL_VERTS[t][k][1],
+                                   MICRO_CELL_VERTS[t][k][2] );
+      ho_p1_tet_diffusion( M, c );
+      const int64_t rows = n - MICRO_CELL_ROW_DEFICIT[t];
+      for ( int64_t z = 0; z < rows; ++z )
+         for ( int64_t y = 0; y < rows - z; ++y )
+            for ( int64_t x = 0; x < rows - z - y; ++x )
+               for ( int k = 0; k < 4; ++k )
+                  diag[cell_index_w( N, x + MICRO_CELL_VERTS[t][k][0], y + MICRO_CELL_VERTS[t][k][1], z + MICRO_CELL_VERTS[t][k][2] )] +=
+                      M[4 * k + k];
+   }
+}
+
 /* point class (slot 0..13, 14 inner) of the edge DoF with logical index (x,y,z) and orientation o: the macro-primitive that
  * contains both end points */
 static const int EDGE_END_OFFSETS[7][2][3] = { { { 0, 0, 0 }, { 1, 0, 0 } }, { { 0, 0, 0 }, { 0, 1, 0 } }, { { 0, 0, 0 }, { 0, 0, 1 } },

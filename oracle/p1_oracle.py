@@ -87,6 +87,8 @@ def _bind(lib):
         "ho_edge_dof_class": (i, [i, ll, ll, ll, i]),
         "ho_p2_elementwise_apply_cell": (None, [_P, _P, _P, _P, i, _P, d, i, C.c_uint]),
         "ho_sor_shell_cell": (None, [_P, _P, _P, i, C.POINTER(C.c_int), _P, C.POINTER(C.c_int), _P, _P, d, C.c_uint, i]),
+        "ho_p1_elementwise_apply_macro_3d": (None, [_P, _P, _P, ll]),
+        "ho_p1_elementwise_diagonal_macro_3d": (None, [_P, _P, ll]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)
@@ -434,6 +436,19 @@ def p2_elementwise_apply_cell(dst_v, dst_e, src_v, src_e, level, elmat, alpha=1.
     em = np.ascontiguousarray(elmat, dtype=np.float64).reshape(600)
     lib().ho_p2_elementwise_apply_cell(_p(dst_v), _p(dst_e), _p(src_v), _p(src_e), level, _p(em), float(alpha), update, mask)
     return dst_v, dst_e
+
+
+def p1_elementwise_apply_macro_3d(dst, src, cell_vertex_coords, micro_edges):
+    """dst += (operator of the macro-cell) src at all points: the generated elementwise kernel's micro-cell loop"""
+    c = np.ascontiguousarray(cell_vertex_coords, dtype=np.float64).reshape(12)
+    lib().ho_p1_elementwise_apply_macro_3d(_p(dst), _p(src), _p(c), int(micro_edges))
+    return dst
+
+
+def p1_elementwise_diagonal_macro_3d(diag, cell_vertex_coords, micro_edges):
+    c = np.ascontiguousarray(cell_vertex_coords, dtype=np.float64).reshape(12)
+    lib().ho_p1_elementwise_diagonal_macro_3d(_p(diag), _p(c), int(micro_edges))
+    return diag
 
 
 def edge_midpoints(cell_vertex_coords, level):
