@@ -121,9 +121,8 @@ def test_p2_apply_macro_3d_equals_the_micro_cell_loop(env, level, tet):
     rng = np.random.default_rng(77 + level)
     nv, ne = po.cell_size(level), po.edge_array_size(level)
     sv, se, dv0, de0 = rng.random(nv), rng.random(ne), rng.random(nv), rng.random(ne)
-    dv, de = _dev(torch, dv0), _dev(torch, de0)
-    capi.p2_elementwise_diffusion_apply_macro_3d(dv.data_ptr(), de.data_ptr(), _dev(torch, sv).data_ptr(), _dev(torch, se).data_ptr(), tet,
-                                                 1 << level)
+    dv, de, dsv, dse = _dev(torch, dv0), _dev(torch, de0), _dev(torch, sv), _dev(torch, se)
+    capi.p2_elementwise_diffusion_apply_macro_3d(dv.data_ptr(), de.data_ptr(), dsv.data_ptr(), dse.data_ptr(), tet, 1 << level)
     torch.cuda.synchronize()
     rv, re_ = dv0.copy(), de0.copy()
     po.p2_elementwise_apply_cell(rv, re_, sv, se, level, po.p2_cell_element_matrices(tet, level), 1.0, po.ADD, 0x7FFF)
