@@ -119,6 +119,11 @@ SIGNATURES = {
     "hyteg_hip_p1_sor_face3d_workspace": (C.c_size_t, [_i]),
     "hyteg_hip_p1_sor_face3d": (_i, [_vp, _vp, _vp, _i, _i, C.POINTER(_i), _dp, C.c_double, _i, _vp]),
     "hyteg_hip_gather_entries": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "hyteg_hip_p2_constant_stencil_layout": (_i, [C.POINTER(_i), C.POINTER(_i)]),
+    "hyteg_hip_p2_build_operator_table_from_stencils": (_i, [_dp, _dp, _dp]),
+    "hyteg_hip_p2_apply_cell_edgedof_to_vertexdof": (_i, [_vp] * 7 + [_vp, _dp, _i, _i, _vp]),
+    "hyteg_hip_p2_apply_cell_vertexdof_to_edgedof": (_i, [_vp] * 7 + [_vp, _i, _dp, _i, _vp]),
+    "hyteg_hip_p2_apply_cell_edgedof_to_edgedof": (_i, [_vp] * 14 + [_dp, _i, _i, _vp]),
     "hyteg_hip_p1_elementwise_diffusion_apply_macro_3d": (_i, [_vp, _vp, _dp, _i64, _d, _vp]),
     "hyteg_hip_p1_elementwise_diffusion_apply_macro_3d_masked": (_i, [_vp, _vp, _dp, _i64, C.c_uint, _i, _vp]),
     "hyteg_hip_p1_elementwise_diffusion_apply_macro_3d_f32": (_i, [_vp, _vp, C.POINTER(C.c_float), _i64, C.c_float, _vp]),
@@ -580,3 +585,49 @@ def p2_elementwise_diffusion_element_matrices(coords, micro_edges):
     out = (C.c_double * 600)()
     check(lib().hyteg_hip_p2_elementwise_diffusion_element_matrices(a, int(micro_edges), out), "p2_elementwise_diffusion_element_matrices")
     return list(out)
+
+
+# ---- the constant-stencil P2 operator's kernel seam (P2ConstantOperator's four sub-operators) ----
+def p2_constant_stencil_layout():
+    """(counts [v2v, e2v, v2e, e2e], keys [(dst kind, src kind, dx, dy, dz), ...] in the order a binding flattens its maps)"""
+    counts = (C.c_int * 4)()
+    check(lib().hyteg_hip_p2_constant_stencil_layout(counts, None), "p2_constant_stencil_layout")
+    total = sum(counts)
+    keys = (C.c_int * (5 * total))()
+    check(lib().hyteg_hip_p2_constant_stencil_layout(counts, keys), "p2_constant_stencil_layout")
+    return list(counts), [tuple(keys[5 * i:5 * i + 5]) for i in range(total)]
+
+
+def p2_build_operator_table_from_stencils(inner, classes=None):
+    n = int(lib().hyteg_hip_p2_operator_table_size())
+    a = (C.c_double * len(inner))(*[float(x) for x in inner])
+    b = None if classes is None else (C.c_double * len(classes))(*[float(x) for x in classes])
+    out = (C.c_double * n)()
+    check(lib().hyteg_hip_p2_build_operator_table_from_stencils(a, b, out), "p2_build_operator_table_from_stencils")
+    return list(out)
+
+
+def _edge_blocks(base, level):
+    """the seven block pointers in the reference kernels' (alphabetical) order X, XY, XYZ, XZ, Y, YZ, Z"""
+    n = 1 << level
+    b = 8 * (n * (n + 1) * (n + 2) // 6)
+    x, y, z, xy, xz, yz, xyz = (base + k * b for k in range(7))
+    return [x, xy, xyz, xz, y, yz, z]
+
+
+def p2_apply_cell_edgedof_to_vertexdof(src_edge, dst_vertex, e2v, level, update=REPLACE, stream=0):
+    w = (C.c_double * len(e2v))(*[float(x) for x in e2v])
+    check(lib().hyteg_hip_p2_apply_cell_edgedof_to_vertexdof(*_edge_blocks(src_edge, level), dst_vertex, w, level, update, stream),
+          "p2_apply_cell_edgedof_to_vertexdof")
+
+
+def p2_apply_cell_vertexdof_to_edgedof(dst_edge, src_vertex, v2e, level, update=REPLACE, stream=0):
+    w = (C.c_double * len(v2e))(*[float(x) for x in v2e])
+    check(lib().hyteg_hip_p2_apply_cell_vertexdof_to_edgedof(*_edge_blocks(dst_edge, level), src_vertex, level, w, update, stream),
+          "p2_apply_cell_vertexdof_to_edgedof")
+
+
+def p2_apply_cell_edgedof_to_edgedof(dst_edge, src_edge, e2e, level, update=REPLACE, stream=0):
+    w = (C.c_double * len(e2e))(*[float(x) for x in e2e])
+    check(lib().hyteg_hip_p2_apply_cell_edgedof_to_edgedof(*_edge_blocks(dst_edge, level), *_edge_blocks(src_edge, level), w, level, update, stream),
+          "p2_apply_cell_edgedof_to_edgedof")

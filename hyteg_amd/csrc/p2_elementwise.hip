@@ -10,8 +10,11 @@
 // (edgedofspace/EdgeDoFIndexing.hpp:89-165); they are built once on the host.
 // First version: table-driven, one thread per destination DoF, direct loads.  Parity first; the roofline work
 // (row-wise register reuse as in the P1 z-march kernel) is the next step for this row.
+#include <algorithm>
+#include <map>
 #include <mutex>
 #include <utility>
+#include <vector>
 
 #include <cstdlib>
 
@@ -1274,6 +1277,215 @@ HYTEG_HIP_API int hyteg_hip_p2_build_operator_table( const double* elmat_host, d
       }
    }
    return HYTEG_HIP_OK;
+}
+
+// ---- f4: the constant-stencil operator's kernel seam ----------------------------------------------------------------
+// P2ConstantOperator::apply = four sub-operators (P2ConstantOperator.cpp:100-112) whose macro-cell kernels take stencil maps:
+//   vertex->vertex  std::map< Index, real_t >                                                    (P1ConstantOperator)
+//   edge->vertex    std::map< EdgeDoFOrientation, std::map< Index, real_t > >                    e2vStencilMap[ leaf orientation ][ offset ]
+//   vertex->edge    std::map< EdgeDoFOrientation, std::map< Index, real_t > >                    v2eStencilMap[ centre orientation ][ offset ]
+//   edge->edge      std::map< EdgeDoFOrientation, std::map< EdgeDoFOrientation, std::map< Index, real_t > > >   [ centre ][ leaf ][ offset ]
+// (mixedoperators/EdgeDoFToVertexDoFOperator/generatedKernels/apply_3D_macrocell_edgedof_to_vertexdof_replace.hpp:36,
+//  mixedoperators/VertexDoFToEdgeDoFOperator/generatedKernels/apply_3D_macrocell_vertexdof_to_edgedof_replace.hpp:36,
+//  constant_stencil_operator/EdgeDoFGeneratedKernels/apply_3D_macrocell_edgedof_to_edgedof_replace.hpp:37).
+// The key sets of those maps are a geometric fact -- the (source kind, offset) lists of KindStencil above -- so a binding passes
+// only the VALUES, flattened in the maps' own iteration order (orientations in enum order X, Y, Z, XY, XZ, YZ, XYZ; offsets in
+// indexing::Index order z, y, x), the four maps one after the other.  hyteg_hip_p2_constant_stencil_layout returns the keys in
+// that order so that a binding can check its maps against them.
+} // extern "C"
+namespace {
+struct CanonKey
+{
+   int c, s, dx, dy, dz; // destination kind (0 vertex, 1..7 edge X..XYZ), source kind, offset source index - destination index
+};
+inline int canon_group( const CanonKey& k ) { return k.c == 0 ? ( k.s == 0 ? 0 : 1 ) : ( k.s == 0 ? 2 : 3 ); }
+const std::vector< CanonKey >& canonical_keys()
+{
+   static const std::vector< CanonKey > keys = [] {
+      std::vector< CanonKey > v;
+      for ( int c = 0; c < 8; ++c )
+      {
+         const KindStencil S = build_kind_stencil( c );
+         for ( int q = 0; q < S.n; ++q )
+            v.push_back( CanonKey{ c, S.kind[q], S.dx[q], S.dy[q], S.dz[q] } );
+      }
+      std::sort( v.begin(), v.end(), []( const CanonKey& a, const CanonKey& b ) {
+         const int ga = canon_group( a ), gb = canon_group( b );
+         if ( ga != gb )
+            return ga < gb;
+         if ( a.c != b.c )
+            return a.c < b.c;
+         if ( a.s != b.s )
+            return a.s < b.s;
+         if ( a.dz != b.dz )
+            return a.dz < b.dz;
+         if ( a.dy != b.dy )
+            return a.dy < b.dy;
+         return a.dx < b.dx;
+      } );
+      return v;
+   }();
+   return keys;
+}
+// position of table entry (c, q) in the canonical list
+int canonical_position( int c, int q )
+{
+   static const std::vector< std::vector< int > > pos = [] {
+      const auto&                       keys = canonical_keys();
+      std::vector< std::vector< int > > p( 8 );
+      for ( int c2 = 0; c2 < 8; ++c2 )
+      {
+         const KindStencil S = build_kind_stencil( c2 );
+         p[c2].assign( S.n, -1 );
+         for ( int q2 = 0; q2 < S.n; ++q2 )
+            for ( size_t i = 0; i < keys.size(); ++i )
+               if ( keys[i].c == c2 && keys[i].s == S.kind[q2] && keys[i].dx == S.dx[q2] && keys[i].dy == S.dy[q2] && keys[i].dz == S.dz[q2] )
+                  p[c2][q2] = (int) i;
+      }
+      return p;
+   }();
+   return pos[c][q];
+}
+// device copies of operator tables built inside this file (the sub-operator entry points), by content
+int cached_table( const std::vector< double >& host, const double** dev_out )
+{
+   static std::mutex                                                   mtx;
+   static std::map< std::pair< int, std::vector< double > >, double* > cache;
+   int                                                                 dev = 0;
+   HH_CHECK_HIP( hipGetDevice( &dev ) );
+   std::lock_guard< std::mutex > lock( mtx );
+   auto                          it = cache.find( { dev, host } );
+   if ( it == cache.end() )
+   {
+      void* p = nullptr;
+      HH_CHECK_HIP( hipMalloc( &p, host.size() * sizeof( double ) ) );
+      HH_CHECK_HIP( hipMemcpy( p, host.data(), host.size() * sizeof( double ), hipMemcpyHostToDevice ) );
+      it = cache.emplace( std::make_pair( dev, host ), static_cast< double* >( p ) ).first;
+   }
+   *dev_out = it->second;
+   return HYTEG_HIP_OK;
+}
+// the seven edge-DoF block pointers of the reference's kernels (alphabetical: X, XY, XYZ, XZ, Y, YZ, Z) must be the blocks of ONE
+// edge-DoF array (EdgeDoFIndexing.hpp:920-985: X, Y, Z, XY, XZ, YZ blocks of tet(2^level) entries, then XYZ)
+template < typename P >
+bool blocks_of_one_array( P x, P xy, P xyz, P xz, P y, P yz, P z, int level )
+{
+   const int64_t b = tet64( (int64_t) 1 << level );
+   return y == x + b && z == x + 2 * b && xy == x + 3 * b && xz == x + 4 * b && yz == x + 5 * b && xyz == x + 6 * b;
+}
+} // namespace
+extern "C" {
+
+HYTEG_HIP_API int hyteg_hip_p2_constant_stencil_layout( int* counts, int* keys )
+{
+   HH_REQUIRE( counts, "p2_constant_stencil_layout: null pointer" );
+   const auto& K = canonical_keys();
+   counts[0] = counts[1] = counts[2] = counts[3] = 0;
+   for ( size_t i = 0; i < K.size(); ++i )
+   {
+      ++counts[canon_group( K[i] )];
+      if ( keys )
+         keys[5 * i] = K[i].c, keys[5 * i + 1] = K[i].s, keys[5 * i + 2] = K[i].dx, keys[5 * i + 3] = K[i].dy, keys[5 * i + 4] = K[i].dz;
+   }
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_p2_build_operator_table_from_stencils( const double* inner, const double* classes, double* table_host )
+{
+   HH_REQUIRE( inner && table_host, "p2_build_operator_table_from_stencils: null pointer" );
+   const int total = (int) canonical_keys().size();
+   for ( int k = 0; k < kOperatorTableSize; ++k )
+      table_host[k] = 0.0; // no element matrices: such a table serves levels >= 2 (levels 0, 1 gather micro-cell by micro-cell)
+   for ( int c = 0; c < 8; ++c )
+   {
+      const int n = stencil_count( c );
+      for ( int q = 0; q < n; ++q )
+      {
+         const int pos                       = canonical_position( c, q );
+         table_host[stencil_offset( c ) + q] = inner[pos];
+         if ( classes )
+            for ( int cls = 0; cls < 14; ++cls )
+               table_host[class_offset( c ) + cls * n + q] = classes[(size_t) cls * total + pos];
+      }
+   }
+   return HYTEG_HIP_OK;
+}
+
+// one sub-operator on the INNER DoFs of a macro-cell (what the reference's macro-cell kernels update): a table that carries only
+// that sub-operator's weights, the destination kinds it writes
+static int apply_sub_operator( double* dst_vertex, double* dst_edge, const double* src_vertex, const double* src_edge, int level, int group,
+                               const double* values, int update, hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( level >= 2 && level <= HYTEG_HIP_P2_MAX_LEVEL, "p2 constant sub-operator: level out of range [2,9]" );
+   const auto&           K = canonical_keys();
+   std::vector< double > inner( K.size(), 0.0 );
+   int                   first = 0;
+   for ( size_t i = 0; i < K.size() && canon_group( K[i] ) < group; ++i )
+      ++first;
+   for ( size_t i = first; i < K.size() && canon_group( K[i] ) == group; ++i )
+      inner[i] = values[i - first];
+   std::vector< double > table( kOperatorTableSize );
+   hyteg_hip_p2_build_operator_table_from_stencils( inner.data(), nullptr, table.data() );
+   const double* table_dev = nullptr;
+   const int     rc        = cached_table( table, &table_dev );
+   if ( rc != HYTEG_HIP_OK )
+      return rc;
+   return hyteg_hip_p2_elementwise_apply_cell_kinds( dst_vertex, dst_edge, src_vertex, src_edge, level, table_dev, 1.0, update, HYTEG_HIP_MASK_INNER,
+                                                     group <= 1 ? 0x01u : 0xFEu, stream );
+}
+
+HYTEG_HIP_API int hyteg_hip_p2_apply_cell_edgedof_to_vertexdof( const double* src_x, const double* src_xy, const double* src_xyz, const double* src_xz,
+                                                                const double* src_y, const double* src_yz, const double* src_z, double* dst_vertex,
+                                                                const double* e2v_stencil, int level, int update, hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( src_x && dst_vertex && e2v_stencil, "p2_apply_cell_edgedof_to_vertexdof: null pointer" );
+   HH_REQUIRE( blocks_of_one_array( src_x, src_xy, src_xyz, src_xz, src_y, src_yz, src_z, level ),
+               "p2_apply_cell_edgedof_to_vertexdof: the seven source pointers are not the blocks of one edge-DoF array" );
+   // the vertex source of the fused kernel carries zero weights here and its edge destination is masked: the edge source (a
+   // genuine, finite source, at least as long as a vertex array) stands in for the former, an unwritten pointer for the latter
+   return apply_sub_operator( dst_vertex, const_cast< double* >( src_x ) + 1, src_x, src_x, level, 1, e2v_stencil, update, stream );
+}
+
+HYTEG_HIP_API int hyteg_hip_p2_apply_cell_vertexdof_to_edgedof( double* dst_x, double* dst_xy, double* dst_xyz, double* dst_xz, double* dst_y,
+                                                                double* dst_yz, double* dst_z, const double* src_vertex, int level,
+                                                                const double* v2e_stencil, int update, hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( dst_x && src_vertex && v2e_stencil, "p2_apply_cell_vertexdof_to_edgedof: null pointer" );
+   HH_REQUIRE( blocks_of_one_array( dst_x, dst_xy, dst_xyz, dst_xz, dst_y, dst_yz, dst_z, level ),
+               "p2_apply_cell_vertexdof_to_edgedof: the seven destination pointers are not the blocks of one edge-DoF array" );
+   // edge source: zero weights, but 0 * x is only 0 for finite x -- a zero-filled array of the level's edge-DoF size stands in
+   // (kept per device and level); vertex destination: masked, never written
+   static std::mutex                              mtx;
+   static std::map< std::pair< int, int >, double* > zeros;
+   int                                            dev = 0;
+   HH_CHECK_HIP( hipGetDevice( &dev ) );
+   double* zero_edges = nullptr;
+   {
+      std::lock_guard< std::mutex > lock( mtx );
+      auto                          it = zeros.find( { dev, level } );
+      if ( it == zeros.end() )
+      {
+         void*        p     = nullptr;
+         const size_t bytes = ( hyteg_hip_p2_edge_array_size( level ) + 1 ) * sizeof( double );
+         HH_CHECK_HIP( hipMalloc( &p, bytes ) );
+         HH_CHECK_HIP( hipMemset( p, 0, bytes ) );
+         it = zeros.emplace( std::make_pair( dev, level ), static_cast< double* >( p ) ).first;
+      }
+      zero_edges = it->second;
+   }
+   return apply_sub_operator( const_cast< double* >( src_vertex ) + 1, dst_x, src_vertex, zero_edges, level, 2, v2e_stencil, update, stream );
+}
+
+HYTEG_HIP_API int hyteg_hip_p2_apply_cell_edgedof_to_edgedof( double* dst_x, double* dst_xy, double* dst_xyz, double* dst_xz, double* dst_y, double* dst_yz,
+                                                              double* dst_z, const double* src_x, const double* src_xy, const double* src_xyz,
+                                                              const double* src_xz, const double* src_y, const double* src_yz, const double* src_z,
+                                                              const double* e2e_stencil, int level, int update, hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( dst_x && src_x && e2e_stencil, "p2_apply_cell_edgedof_to_edgedof: null pointer" );
+   HH_REQUIRE( blocks_of_one_array( dst_x, dst_xy, dst_xyz, dst_xz, dst_y, dst_yz, dst_z, level ) &&
+                   blocks_of_one_array( src_x, src_xy, src_xyz, src_xz, src_y, src_yz, src_z, level ),
+               "p2_apply_cell_edgedof_to_edgedof: the seven pointers are not the blocks of one edge-DoF array" );
+   return apply_sub_operator( dst_x + 1, dst_x, src_x, src_x, level, 3, e2e_stencil, update, stream );
 }
 
 HYTEG_HIP_API int hyteg_hip_p2_edge_vector_cell_masked( int                  op,

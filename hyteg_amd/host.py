@@ -113,6 +113,7 @@ SIGNATURES = {
     "hyteg_host_p2_restrict": (_i, [_vp, _i, _i]),
     "hyteg_host_p2operator_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
     "hyteg_host_p2operator_destroy": (_i, [_vp]),
+    "hyteg_host_p2operator_constant_stencils": (_i, [_vp, _i, _i, _dp, _i, C.POINTER(_i)]),
     "hyteg_host_p2operator_element_matrices": (_i, [_vp, _i, _i, _vp]),
     "hyteg_host_p2operator_apply": (_i, [_vp, _vp, _vp, _i, _i, _i]),
     "hyteg_host_p2_cg_solve": (_i, [_vp, _vp, _vp, _vp, _i, _i, _d, C.POINTER(_i)]),
@@ -763,5 +764,12 @@ class P2Solver:
 
 
 class P2ConstantLaplaceOperator(P2ElementwiseLaplaceOperator):
-    """hyteg::P2ConstantLaplaceOperator: the four constant-stencil sub-operators in one kernel pass"""
+    """hyteg::P2ConstantLaplaceOperator: assembles the stencils of its four sub-operators itself (P2Elements3D) and hands them to
+    the C-ABI's kernel seam; one kernel pass for all four"""
     _create = "hyteg_host_p2operator_create_constant"
+
+    def inner_stencils(self, level, cell=0):
+        """values of the v2v | e2v | v2e | e2e maps of a local cell (order: hyteg_hip_p2_constant_stencil_layout)"""
+        out, n = np.empty(512), C.c_int(0)
+        _ck(lib().hyteg_host_p2operator_constant_stencils(self.h, cell, level, out.ctypes.data_as(_dp), 512, C.byref(n)), "constant_stencils")
+        return out[:n.value].copy()

@@ -765,6 +765,19 @@ HYTEG_HOST_API int hyteg_host_p2operator_create_constant( hh_storage_t s, int mi
       *out = new P2OperatorH{ std::make_shared< P2ConstantLaplaceOperator >( static_cast< StorageH* >( s )->p, (uint_t) minL, (uint_t) maxL ) };
    } );
 }
+HYTEG_HOST_API int hyteg_host_p2operator_constant_stencils( hh_p2operator_t op, int local_cell, int level, double* out, int capacity, int* count )
+{
+   return guarded( [&] {
+      auto* c = dynamic_cast< P2ConstantLaplaceOperator* >( static_cast< P2OperatorH* >( op )->p.get() );
+      if ( !c )
+         throw std::runtime_error( "p2operator_constant_stencils: not a P2ConstantLaplaceOperator" );
+      const auto& v = c->getInnerStencils( (uint_t) level, (uint_t) local_cell );
+      *count        = (int) v.size();
+      if ( capacity < (int) v.size() )
+         throw std::runtime_error( "p2operator_constant_stencils: buffer too small" );
+      std::copy( v.begin(), v.end(), out );
+   } );
+}
 HYTEG_HOST_API int hyteg_host_p2operator_destroy( hh_p2operator_t op )
 {
    return guarded( [&] { delete static_cast< P2OperatorH* >( op ); } );

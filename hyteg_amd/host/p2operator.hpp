@@ -2,6 +2,7 @@
 // P2 forms and P2ElementwiseOperator (src/hyteg/elementwiseoperators/P2ElementwiseOperator.cpp)
 #pragma once
 
+#include "p2elements.hpp"
 #include "p2function.hpp"
 #include "forms.hpp"
 #include "p1operator.hpp"
@@ -98,38 +99,70 @@ class P2ElementwiseOperator
  public:
    using srcType = P2Function< double >;
    using dstType = P2Function< double >;
+   virtual ~P2ElementwiseOperator() = default;
+
+ protected:
+   // for derived operators that bring their own operator tables (P2ConstantOperator: from stencils it assembles itself)
+   struct NoTables
+   {};
+   P2ElementwiseOperator( const std::shared_ptr< PrimitiveStorage >& storage, uint_t minLevel, uint_t maxLevel, NoTables )
+   : storage_( storage )
+   , minLevel_( minLevel )
+   , maxLevel_( maxLevel )
+   {}
+   // the operator table whose apply to the function 1 gives the operator's diagonal (computeInverseDiagonalOperatorValues)
+   virtual std::vector< double > diagonalTable( uint_t level, uint_t localCell ) const
+   {
+      std::vector< double > h( 600, 0.0 );
+      const auto&           full = hostMatrices_.at( level ).at( localCell );
+      for ( int t = 0; t < 6; ++t )
+         for ( int k = 0; k < 10; ++k )
+            h[100 * t + 11 * k] = full[100 * t + 11 * k];
+      std::vector< double > table( hyteg_hip_p2_operator_table_size() );
+      hipCheck( hyteg_hip_p2_build_operator_table( h.data(), table.data() ), "P2ElementwiseOperator: diagonal table" );
+      return table;
+   }
+
+ public:
    P2ElementwiseOperator( const std::shared_ptr< PrimitiveStorage >& storage, uint_t minLevel, uint_t maxLevel )
    : storage_( storage )
    , minLevel_( minLevel )
    , maxLevel_( maxLevel )
+   {
+      for ( uint_t l = minLevel; l <= maxLevel; ++l )
+         for ( uint_t lc = 0; lc < storage->getNumberOfLocalCells(); ++lc )
+            addElementMatrixTable( l, lc );
+   }
+
+ protected:
+   // the six element matrices of local cell lc at level l and the operator table built from them, uploaded
+   void addElementMatrixTable( uint_t l, uint_t lc )
    {
       // micro-cell vertex offsets of the six cell types, celldof::macrocell::getMicroVerticesFromMicroCell (CellDoFIndexing.hpp:155-198)
       static const int verts[6][4][3] = {
           { { 0, 0, 0 }, { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } }, { { 1, 0, 0 }, { 1, 1, 0 }, { 0, 1, 0 }, { 1, 0, 1 } },
           { { 1, 0, 0 }, { 0, 1, 0 }, { 1, 0, 1 }, { 0, 0, 1 } }, { { 1, 1, 0 }, { 1, 1, 1 }, { 0, 1, 1 }, { 1, 0, 1 } },
           { { 1, 0, 1 }, { 0, 1, 1 }, { 0, 0, 1 }, { 0, 1, 0 } }, { { 0, 1, 0 }, { 1, 1, 0 }, { 1, 0, 1 }, { 0, 1, 1 } } };
-      for ( uint_t l = minLevel; l <= maxLevel; ++l )
-         for ( uint_t lc = 0; lc < storage->getNumberOfLocalCells(); ++lc )
-         {
-            const MacroCell&      cell = storage->getLocalCell( lc );
-            const double          step = 1.0 / double( int64_t( 1 ) << l );
-            std::vector< double > h( 600 );
-            for ( int t = 0; t < 6; ++t )
-            {
-               std::array< Point3D, 4 > c;
-               for ( int k = 0; k < 4; ++k )
-                  for ( int r = 0; r < 3; ++r )
-                     c[k][r] = cell.coords[0][r] + ( cell.coords[1][r] - cell.coords[0][r] ) * step * verts[t][k][0] +
-                               ( cell.coords[2][r] - cell.coords[0][r] ) * step * verts[t][k][1] +
-                               ( cell.coords[3][r] - cell.coords[0][r] ) * step * verts[t][k][2];
-               P2Form::integrateAll( c, h.data() + 100 * t );
-            }
-            std::vector< double > table( hyteg_hip_p2_operator_table_size() );
-            hipCheck( hyteg_hip_p2_build_operator_table( h.data(), table.data() ), "P2ElementwiseOperator: operator table" );
-            elementMatrices_[l].push_back( storage->uploadTable( table ) );
-            hostMatrices_[l].push_back( h );
-         }
+      const MacroCell&      cell = storage_->getLocalCell( lc );
+      const double          step = 1.0 / double( int64_t( 1 ) << l );
+      std::vector< double > h( 600 );
+      for ( int t = 0; t < 6; ++t )
+      {
+         std::array< Point3D, 4 > c;
+         for ( int k = 0; k < 4; ++k )
+            for ( int r = 0; r < 3; ++r )
+               c[k][r] = cell.coords[0][r] + ( cell.coords[1][r] - cell.coords[0][r] ) * step * verts[t][k][0] +
+                         ( cell.coords[2][r] - cell.coords[0][r] ) * step * verts[t][k][1] +
+                         ( cell.coords[3][r] - cell.coords[0][r] ) * step * verts[t][k][2];
+         P2Form::integrateAll( c, h.data() + 100 * t );
+      }
+      std::vector< double > table( hyteg_hip_p2_operator_table_size() );
+      hipCheck( hyteg_hip_p2_build_operator_table( h.data(), table.data() ), "P2ElementwiseOperator: operator table" );
+      elementMatrices_[l].push_back( storage_->uploadTable( table ) );
+      hostMatrices_[l].push_back( h );
    }
+
+ public:
    uint64_t uid() const { return uid_; }
 
    // P2ElementwiseOperator::computeInverseDiagonalOperatorValues (P2ElementwiseOperator.hpp:110, computeDiagonalOperatorValues .cpp:420-520:
@@ -146,16 +179,7 @@ class P2ElementwiseOperator
          ones.interpolate( 1.0, l, All );
          std::vector< const double* > diagTables;
          for ( uint_t c = 0; c < storage_->getNumberOfLocalCells(); ++c )
-         {
-            std::vector< double > h( 600, 0.0 );
-            const auto&           full = hostMatrices_.at( l ).at( c );
-            for ( int t = 0; t < 6; ++t )
-               for ( int k = 0; k < 10; ++k )
-                  h[100 * t + 11 * k] = full[100 * t + 11 * k];
-            std::vector< double > table( hyteg_hip_p2_operator_table_size() );
-            hipCheck( hyteg_hip_p2_build_operator_table( h.data(), table.data() ), "P2ElementwiseOperator: diagonal table" );
-            diagTables.push_back( storage_->uploadTable( table ) );
-         }
+            diagTables.push_back( storage_->uploadTable( diagonalTable( l, c ) ) );
          const P2Function< double >& d = *inverseDiagonalValues_;
          launchWith( diagTables, 1.0, ones, d, l, All, HYTEG_HIP_MASK_ALL, HYTEG_HIP_REPLACE );
          if ( storage_->getCells().size() > 1 )
@@ -332,7 +356,7 @@ class P2ElementwiseOperator
       dst.assign( { beta, 1.0 }, { dst, tmp }, level, flag );
    }
 
- private:
+ protected:
    void launch( double alpha, const P2Function< double >& src, const P2Function< double >& dst, uint_t level, DoFType flag, unsigned keep,
                 int update ) const
    {
@@ -366,18 +390,110 @@ using P2ElementwiseLaplaceOperator = P2ElementwiseOperator< forms::P2LaplaceForm
 
 // P2ConstantOperator< P2Form > (src/constant_stencil_operator/P2ConstantOperator.hpp; apply = the four sub-operators
 // VertexToVertex, EdgeToVertex, VertexToEdge, EdgeToEdge, P2ConstantOperator.cpp:100-112, each a constant stencil per
-// macro-primitive assembled from the element matrices of the adjacent micro-cells).  On the affine macro-cells of this
-// path those stencils are exactly what hyteg_hip_p2_build_operator_table sums for the gather kernel -- one constant stencil
-// per destination kind (vertex DoF, edge DoF of each of the 7 orientations) and point class, covering all four
-// sub-operators in one pass over the DoFs -- so the constant-stencil operator launches the same kernel as the elementwise
-// one and gives the same numbers (the reference pins that equivalence in tests/hyteg/convergence/P2JacobiConvergenceTest.cpp
-// and operators/ElementwiseOperatorAdditiveApplyTest.cpp).  A separate type so that code written against
-// P2ConstantLaplaceOperator compiles unchanged.
+// macro-primitive).  This class ASSEMBLES those stencils itself, the reference's way -- P2Elements3D::calculate*StencilInMacroCell
+// (p2elements.hpp), for an inner DoF of every kind and for a DoF of each of the 14 boundary point classes (there the maps hold
+// this cell's share, as the reference's functions do "for indices on the boundary of a macro-cell") -- and hands the VALUES,
+// flattened in the iteration order of the reference's std::map types, to the C-ABI's kernel seam
+// (hyteg_hip_p2_build_operator_table_from_stencils; the layout of the keys comes from hyteg_hip_p2_constant_stencil_layout and
+// is checked against the assembled maps).  From level 2 on no element matrix reaches the kernels.  apply / gemv / smoothers
+// are the base class's: all four sub-operators in one pass over the DoFs.
 template < class P2Form >
 class P2ConstantOperator : public P2ElementwiseOperator< P2Form >
 {
+   using Base = P2ElementwiseOperator< P2Form >;
+
  public:
-   using P2ElementwiseOperator< P2Form >::P2ElementwiseOperator;
+   P2ConstantOperator( const std::shared_ptr< PrimitiveStorage >& storage, uint_t minLevel, uint_t maxLevel )
+   : Base( storage, minLevel, maxLevel, typename Base::NoTables{} )
+   {
+      int counts[4];
+      hipCheck( hyteg_hip_p2_constant_stencil_layout( counts, nullptr ), "P2ConstantOperator: layout" );
+      total_ = counts[0] + counts[1] + counts[2] + counts[3];
+      keys_.resize( 5 * (size_t) total_ );
+      hipCheck( hyteg_hip_p2_constant_stencil_layout( counts, keys_.data() ), "P2ConstantOperator: layout" );
+      for ( uint_t l = minLevel; l <= maxLevel; ++l )
+         for ( uint_t lc = 0; lc < storage->getNumberOfLocalCells(); ++lc )
+         {
+            if ( l < 2 )
+            {
+               // levels 0 and 1: a DoF can lie on several macro-faces at once, there is no stencil per point class; the kernels
+               // gather micro-cell by micro-cell from the element matrices there (a handful of DoFs)
+               this->addElementMatrixTable( l, lc );
+               stencils_[l].push_back( CellStencils{} );
+               continue;
+            }
+            const MacroCell& cell = storage->getLocalCell( lc );
+            CellStencils     S;
+            // inner DoFs: the stencil maps must have exactly the keys of the layout; boundary classes: a subset of them
+            S.inner = flatten( P2Elements::P2Elements3D::assembleAtClass< P2Form >( cell, l, 14 ), true );
+            S.classes.assign( 14 * (size_t) total_, 0.0 );
+            for ( int cls = 0; cls < 14; ++cls )
+            {
+               const auto v = flatten( P2Elements::P2Elements3D::assembleAtClass< P2Form >( cell, l, cls ), false );
+               std::copy( v.begin(), v.end(), S.classes.begin() + (size_t) cls * total_ );
+            }
+            std::vector< double > table( hyteg_hip_p2_operator_table_size() );
+            hipCheck( hyteg_hip_p2_build_operator_table_from_stencils( S.inner.data(), S.classes.data(), table.data() ),
+                      "P2ConstantOperator: operator table" );
+            this->elementMatrices_[l].push_back( storage->uploadTable( table ) );
+            stencils_[l].push_back( std::move( S ) );
+         }
+   }
+   // the flattened inner stencils of a local cell (v2v | e2v | v2e | e2e in the reference's map order) and their keys
+   const std::vector< double >& getInnerStencils( uint_t level, uint_t localCell = 0 ) const { return stencils_.at( level ).at( localCell ).inner; }
+   const std::vector< int >&    getStencilKeys() const { return keys_; }
+
+ protected:
+   // diagonal: the weights with source kind = destination kind and offset 0
+   std::vector< double > diagonalTable( uint_t level, uint_t localCell ) const override
+   {
+      if ( level < 2 )
+         return Base::diagonalTable( level, localCell );
+      const auto&           S = stencils_.at( level ).at( localCell );
+      std::vector< double > inner( (size_t) total_, 0.0 ), classes( 14 * (size_t) total_, 0.0 );
+      for ( int i = 0; i < total_; ++i )
+      {
+         const int* k = &keys_[5 * (size_t) i];
+         if ( k[0] != k[1] || k[2] != 0 || k[3] != 0 || k[4] != 0 )
+            continue;
+         inner[i] = S.inner[i];
+         for ( int cls = 0; cls < 14; ++cls )
+            classes[(size_t) cls * total_ + i] = S.classes[(size_t) cls * total_ + i];
+      }
+      std::vector< double > table( hyteg_hip_p2_operator_table_size() );
+      hipCheck( hyteg_hip_p2_build_operator_table_from_stencils( inner.data(), classes.data(), table.data() ), "P2ConstantOperator: diagonal table" );
+      return table;
+   }
+
+ private:
+   struct CellStencils
+   {
+      std::vector< double > inner, classes;
+   };
+   // values of the assembled maps in the order of the layout's keys; `complete`: every key of the layout must be present
+   std::vector< double > flatten( const P2Elements::P2Elements3D::KindStencils& maps, bool complete ) const
+   {
+      std::vector< double > v( (size_t) total_, 0.0 );
+      size_t                found = 0;
+      for ( int i = 0; i < total_; ++i )
+      {
+         const int* k  = &keys_[5 * (size_t) i];
+         auto       it = maps[k[0]].find( P2Elements::P2Elements3D::Key{ k[1], { k[2], k[3], k[4] } } );
+         if ( it != maps[k[0]].end() )
+            v[i] = it->second, ++found;
+         else if ( complete )
+            throw std::runtime_error( "P2ConstantOperator: the assembled stencil lacks a key of hyteg_hip_p2_constant_stencil_layout" );
+      }
+      size_t have = 0;
+      for ( const auto& m : maps )
+         have += m.size();
+      if ( found != have )
+         throw std::runtime_error( "P2ConstantOperator: the assembled stencil has keys hyteg_hip_p2_constant_stencil_layout does not list" );
+      return v;
+   }
+   int                                            total_ = 0;
+   std::vector< int >                             keys_;
+   std::map< uint_t, std::vector< CellStencils > > stencils_;
 };
 using P2ConstantLaplaceOperator = P2ConstantOperator< forms::P2LaplaceForm >; // P2ConstantOperator.hpp
 

@@ -866,6 +866,42 @@ HYTEG_HIP_API int hyteg_hip_p2p_wait( const unsigned long long* flags,
                                       unsigned                  timeout_ms,
                                       hyteg_hip_stream_t        stream );
 
+/* ---- f4: the constant-stencil P2 operator at its kernel seam -------------------------------------------------------------
+ * P2ConstantOperator::apply (src/constant_stencil_operator/P2ConstantOperator.cpp:100-112) = four sub-operators whose
+ * macro-cell kernels take stencil MAPS and update the macro-cell's INNER DoFs:
+ *   vertex->vertex  hyteg_hip_p1_apply_cell (above)
+ *   edge->vertex    apply_3D_macrocell_edgedof_to_vertexdof_{replace,add}( src X, XY, XYZ, XZ, Y, YZ, Z, dst vertex, e2vStencilMap, level )
+ *                   src/hyteg/mixedoperators/EdgeDoFToVertexDoFOperator/generatedKernels/apply_3D_macrocell_edgedof_to_vertexdof_replace.hpp:36
+ *   vertex->edge    apply_3D_macrocell_vertexdof_to_edgedof_{replace,add}( dst X, ..., Z, src vertex, level, v2eStencilMap )
+ *                   src/hyteg/mixedoperators/VertexDoFToEdgeDoFOperator/generatedKernels/apply_3D_macrocell_vertexdof_to_edgedof_replace.hpp:36
+ *   edge->edge      apply_3D_macrocell_edgedof_to_edgedof_{replace,add}( dst X, ..., Z, src X, ..., Z, e2eStencilMap, level )
+ *                   src/constant_stencil_operator/EdgeDoFGeneratedKernels/apply_3D_macrocell_edgedof_to_edgedof_replace.hpp:37
+ * The entry points keep the reference's pointer lists (the seven pointers must be the blocks of ONE edge-DoF array, which is
+ * what the reference passes: &data[ index( level, 0, 0, 0, orientation ) ]) and take the stencil map's VALUES flattened in the
+ * map's own iteration order -- orientations in the order of the enum (X, Y, Z, XY, XZ, YZ, XYZ), offsets in indexing::Index
+ * order (z, y, x):
+ *     for ( auto& a : e2eStencilMap ) for ( auto& b : a.second ) for ( auto& c : b.second ) w[k++] = c.second;
+ * hyteg_hip_p2_constant_stencil_layout gives the number of values of the four maps (counts[4]: v2v, e2v, v2e, e2e) and, if
+ * keys != NULL, for every value of the concatenation v2v | e2v | v2e | e2e the five integers { destination kind, source kind,
+ * dx, dy, dz } (kind 0 = vertex DoFs, 1..7 = edge DoFs X, Y, Z, XY, XZ, YZ, XYZ; offset = source index - destination index),
+ * so that a binding can check its maps' keys.  Levels 2..9.  These three calls run the fused kernel with all other weights
+ * zero; the fast path is ONE pass for all four sub-operators: hyteg_hip_p2_build_operator_table_from_stencils turns the
+ * concatenated values (inner DoFs) and, optionally, the cell's share stencils of the 14 boundary point classes
+ * (classes[14][total], zero where a neighbour lies outside the cell) into the table hyteg_hip_p2_elementwise_apply_cell takes. */
+HYTEG_HIP_API int hyteg_hip_p2_constant_stencil_layout( int* counts /* 4 */, int* keys /* NULL or 5 * total */ );
+HYTEG_HIP_API int hyteg_hip_p2_build_operator_table_from_stencils( const double* inner /* total */, const double* classes /* NULL or 14 * total */,
+                                                                   double* table_host );
+HYTEG_HIP_API int hyteg_hip_p2_apply_cell_edgedof_to_vertexdof( const double* src_x, const double* src_xy, const double* src_xyz, const double* src_xz,
+                                                                const double* src_y, const double* src_yz, const double* src_z, double* dst_vertex,
+                                                                const double* e2v_stencil, int level, int update, hyteg_hip_stream_t stream );
+HYTEG_HIP_API int hyteg_hip_p2_apply_cell_vertexdof_to_edgedof( double* dst_x, double* dst_xy, double* dst_xyz, double* dst_xz, double* dst_y,
+                                                                double* dst_yz, double* dst_z, const double* src_vertex, int level,
+                                                                const double* v2e_stencil, int update, hyteg_hip_stream_t stream );
+HYTEG_HIP_API int hyteg_hip_p2_apply_cell_edgedof_to_edgedof( double* dst_x, double* dst_xy, double* dst_xyz, double* dst_xz, double* dst_y, double* dst_yz,
+                                                              double* dst_z, const double* src_x, const double* src_xy, const double* src_xyz,
+                                                              const double* src_xz, const double* src_y, const double* src_yz, const double* src_z,
+                                                              const double* e2e_stencil, int level, int update, hyteg_hip_stream_t stream );
+
 /* ---- b-3: the seam of the generated elementwise operators (module hyteg_operators) ---------------------------------------
  * The generated operators call, per macro-cell,
  *    apply_macro_3D( dst*, src*, macro_vertex_coord_id_{0..3}comp{0..2} (12 scalars), int64 micro_edges_per_macro_edge,

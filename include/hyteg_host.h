@@ -206,6 +206,9 @@ HYTEG_HOST_API int hyteg_host_p2_restrict( hh_p2function_t f, int source_level, 
 /* P2ConstantLaplaceOperator (src/constant_stencil_operator/P2ConstantOperator.hpp): same handle type and calls as the
  * elementwise operator; on affine macro-cells the assembled constant stencils ARE what the kernel's operator table holds */
 HYTEG_HOST_API int hyteg_host_p2operator_create_constant( hh_storage_t s, int min_level, int max_level, hh_p2operator_t* out );
+/* the inner-DoF stencils a P2ConstantLaplaceOperator assembled for a local cell (levels >= 2): the values of the four maps
+ * v2v | e2v | v2e | e2e in the order of hyteg_hip_p2_constant_stencil_layout */
+HYTEG_HOST_API int hyteg_host_p2operator_constant_stencils( hh_p2operator_t op, int local_cell, int level, double* out, int capacity, int* count );
 HYTEG_HOST_API int hyteg_host_p2operator_destroy( hh_p2operator_t op );
 /* the six 10 x 10 element matrices (FEniCS ordering) of a local cell at `level` */
 HYTEG_HOST_API int hyteg_host_p2operator_element_matrices( hh_p2operator_t op, int local_cell, int level, double* out600 );

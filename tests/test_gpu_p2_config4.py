@@ -4,7 +4,7 @@
    residual at every inner DoF, u^T A u = int |grad u|^2);
  * two ranks (sharing this box's one GPU, gloo transport through the hooks): the vertex- AND edge-DoF shares travel through the
    exchange and every rank reproduces the single-rank result;
- * P2ConstantLaplaceOperator gives the numbers of the elementwise operator."""
+ * P2ConstantLaplaceOperator (own stencil assembly, tests/test_gpu_p2_constant.py) agrees with the elementwise operator."""
 import os
 import socket
 import sys
@@ -103,7 +103,7 @@ def test_p2_constant_operator_gives_the_elementwise_numbers():
     inner_v, inner_e = po.slot_of_points(level) == 14, po.edge_classes(level) == 14
     for c in range(st.n_local_cells):
         (cv, ce), (ev, ee) = rc.download(level, c), re_.download(level, c)
-        assert np.array_equal(cv, ev) and np.array_equal(ce, ee)
+        assert np.abs(cv - ev).max() < 1e-13 * np.abs(ev).max() and np.abs(ce - ee).max() < 1e-13 * np.abs(ee).max()  # two assemblies of one operator
         gid, co, nnc = st.local_cell(c)
         em = po.p2_cell_element_matrices(np.asarray(co).reshape(12), level)
         ov, oe = po.p2_elementwise_apply_cell(np.zeros(po.cell_size(level)), np.zeros(po.edge_array_size(level)), fields[c][1], fields[c][2],
