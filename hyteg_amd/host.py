@@ -71,6 +71,10 @@ SIGNATURES = {
     "hyteg_host_stokes_operator_apply": (_i, [_vp, _vp, _vp, _i, _i]),
     "hyteg_host_stokes_uzawa_create": (_i, [_vp, _i, _i, _d, _i, _i, _d, C.POINTER(_vp)]),
     "hyteg_host_stokes_gmg_create": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "hyteg_host_stokes_gmg_create_with_coarse": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _d, C.POINTER(_vp)]),
+    "hyteg_host_stokes_minres_create": (_i, [_vp, _i, _i, _i, _d, _i, _i, C.POINTER(_vp)]),
+    "hyteg_host_stokes_minres_iterations": (_i, [_vp, C.POINTER(_i)]),
+    "hyteg_host_solver_create_minres": (_i, [_vp, _i, _i, _i, _d, _i, C.POINTER(_vp)]),
     "hyteg_host_stokes_solver_solve": (_i, [_vp, _vp, _vp, _vp, _i]),
     "hyteg_host_stokes_solver_destroy": (_i, [_vp]),
     "hyteg_host_operator_create": (_i, [_vp, _i, _i, _i, C.POINTER(_vp)]),
@@ -524,6 +528,14 @@ class Solver:
         _ck(lib().hyteg_host_cg_create(storage.h, min_level, max_level, max_iter, float(tol), C.byref(h)), "cg_create")
         return cls(h)
 
+    @classmethod
+    def minres(cls, storage, min_level, max_level, max_iter=1000, rel_tol=1e-16, jacobi_iterations=0):
+        """hyteg::MinResSolver< P1ConstantLaplaceOperator >, optionally with JacobiPreconditioner( jacobi_iterations )"""
+        h = _vp()
+        _ck(lib().hyteg_host_solver_create_minres(storage.h, min_level, max_level, int(max_iter), float(rel_tol), jacobi_iterations, C.byref(h)),
+            "solver_create_minres")
+        return cls(h)
+
     def solve(self, laplace: P1ConstantOperator, x: P1Function, b: P1Function, level: int):
         _ck(lib().hyteg_host_solver_solve(self.h, laplace.h, x.h, b.h, level), "solve")
 
@@ -623,12 +635,32 @@ class StokesSolver:
         return cls(h)
 
     @classmethod
-    def gmg(cls, storage, smoother, min_level, max_level, pre=3, post=3, increment=0, project_mean_after_restriction=True):
-        """hyteg::GeometricMultigridSolver< P1P1StokesOperator > with a dense direct solve on min_level"""
+    def gmg(cls, storage, smoother, min_level, max_level, pre=3, post=3, increment=0, project_mean_after_restriction=True,
+            coarse="lu", coarse_max_iter=1000, coarse_rel_tol=1e-16):
+        """hyteg::GeometricMultigridSolver< P1P1StokesOperator >; coarse-grid solver on min_level: "lu" = dense direct solve on
+        the host (single rank), "minres" = MinResSolver with the pressure-block preconditioner as apps/stokesSphere composes it
+        (any number of ranks)"""
         h = _vp()
-        _ck(lib().hyteg_host_stokes_gmg_create(storage.h, smoother.h, min_level, max_level, pre, post, increment,
-                                               int(project_mean_after_restriction), C.byref(h)), "stokes_gmg_create")
+        _ck(lib().hyteg_host_stokes_gmg_create_with_coarse(storage.h, smoother.h, min_level, max_level, pre, post, increment,
+                                                           int(project_mean_after_restriction), {"lu": 0, "minres": 1}[coarse],
+                                                           int(coarse_max_iter), float(coarse_rel_tol), C.byref(h)), "stokes_gmg_create")
         return cls(h, keep=(smoother,))
+
+    @classmethod
+    def minres(cls, storage, min_level, max_level, max_iter=1000, rel_tol=1e-16, preconditioner="pressure", velocity_steps=2):
+        """hyteg::MinResSolver< P1P1StokesOperator >; preconditioner "identity", "pressure" (StokesPressureBlockPreconditioner with the
+        lumped inverse mass operator) or "block" (StokesBlockDiagonalPreconditioner: V(2,2) Laplace cycles on the velocity)"""
+        h = _vp()
+        _ck(lib().hyteg_host_stokes_minres_create(storage.h, min_level, max_level, int(max_iter), float(rel_tol),
+                                                  {"identity": 0, "pressure": 1, "block": 2}[preconditioner], velocity_steps, C.byref(h)),
+            "stokes_minres_create")
+        return cls(h)
+
+    @property
+    def minres_iterations(self) -> int:
+        n = _i(0)
+        _ck(lib().hyteg_host_stokes_minres_iterations(self.h, C.byref(n)), "stokes_minres_iterations")
+        return n.value
 
     def solve(self, op: P1P1StokesOperator, x: P1StokesFunction, b: P1StokesFunction, level: int):
         _ck(lib().hyteg_host_stokes_solver_solve(self.h, op.h, x.h, b.h, level), "stokes_solver_solve")

@@ -645,19 +645,91 @@ HYTEG_HOST_API int hyteg_host_stokes_uzawa_create( hh_storage_t s, int minL, int
                                                                                   (uint_t) velocity_iterations ) };
    } );
 }
-HYTEG_HOST_API int hyteg_host_stokes_gmg_create( hh_storage_t s, hh_stokes_solver_t smoother, int minL, int maxL, int pre, int post, int increment,
-                                                 int project_mean_after_restriction, hh_stokes_solver_t* out )
+// coarse: 0 = dense LU on the host (stand-in for PETScLUSolver, single rank), 1 = MinResSolver preconditioned with
+// StokesPressureBlockPreconditioner< P1P1StokesOperator, P1LumpedInvMassOperator > as apps/stokesSphere/StokesSphere.cpp:227-237
+// composes it (any number of ranks)
+HYTEG_HOST_API int hyteg_host_stokes_gmg_create_with_coarse( hh_storage_t s, hh_stokes_solver_t smoother, int minL, int maxL, int pre, int post,
+                                                             int increment, int project_mean_after_restriction, int coarse, int coarse_max_iter,
+                                                             double coarse_rel_tol, hh_stokes_solver_t* out )
 {
    return guarded( [&] {
       using Op     = P1P1StokesOperator;
       auto storage = static_cast< StorageH* >( s )->p;
-      auto coarse  = std::make_shared< DenseCoarseGridSolver< Op > >( storage, (uint_t) minL );
-      *out         = new StokesSolverH{
+      std::shared_ptr< Solver< Op > > coarseSolver;
+      if ( coarse == 0 )
+         coarseSolver = std::make_shared< DenseCoarseGridSolver< Op > >( storage, (uint_t) minL );
+      else if ( coarse == 1 )
+      {
+         auto prec    = std::make_shared< StokesPressureBlockPreconditioner< Op, P1LumpedInvMassOperator > >( storage, (uint_t) minL, (uint_t) minL );
+         coarseSolver = std::make_shared< MinResSolver< Op > >( storage, (uint_t) minL, (uint_t) minL, (uint_t) coarse_max_iter, coarse_rel_tol, 1e-16, prec );
+      }
+      else
+         throw std::runtime_error( "stokes_gmg_create: unknown coarse-grid solver" );
+      *out = new StokesSolverH{
           std::make_shared< GeometricMultigridSolver< Op, P1P1StokesToP1P1StokesRestriction, P1P1StokesToP1P1StokesProlongation > >(
-              storage, static_cast< StokesSolverH* >( smoother )->p, coarse,
+              storage, static_cast< StokesSolverH* >( smoother )->p, coarseSolver,
               std::make_shared< P1P1StokesToP1P1StokesRestriction >( project_mean_after_restriction != 0 ),
               std::make_shared< P1P1StokesToP1P1StokesProlongation >(), (uint_t) minL, (uint_t) maxL, (uint_t) pre, (uint_t) post,
               (uint_t) increment ) };
+   } );
+}
+HYTEG_HOST_API int hyteg_host_stokes_gmg_create( hh_storage_t s, hh_stokes_solver_t smoother, int minL, int maxL, int pre, int post, int increment,
+                                                 int project_mean_after_restriction, hh_stokes_solver_t* out )
+{
+   return hyteg_host_stokes_gmg_create_with_coarse( s, smoother, minL, maxL, pre, post, increment, project_mean_after_restriction, 0, 0, 0.0, out );
+}
+// MinResSolver< P1P1StokesOperator > on its own: preconditioner 0 identity, 1 pressure block (lumped inverse mass),
+// 2 StokesBlockDiagonalPreconditioner with `velocity_steps` V(2,2) cycles of the scalar Laplace operator per velocity component
+// (apps/stokesSphere/StokesSphere.cpp:198-222, tests/hyteg/convergence/P1Stokes3DMinResConvergenceTest.cpp:166-183)
+HYTEG_HOST_API int hyteg_host_stokes_minres_create( hh_storage_t s, int minL, int maxL, int max_iter, double rel_tol, int preconditioner,
+                                                    int velocity_steps, hh_stokes_solver_t* out )
+{
+   return guarded( [&] {
+      using Op     = P1P1StokesOperator;
+      auto storage = static_cast< StorageH* >( s )->p;
+      std::shared_ptr< Solver< Op > > prec;
+      if ( preconditioner == 0 )
+         prec = std::make_shared< IdentityPreconditioner< Op > >();
+      else if ( preconditioner == 1 )
+         prec = std::make_shared< StokesPressureBlockPreconditioner< Op, P1LumpedInvMassOperator > >( storage, (uint_t) minL, (uint_t) maxL );
+      else if ( preconditioner == 2 )
+      {
+         using L       = P1ConstantLaplaceOperator;
+         auto smoother = std::make_shared< GaussSeidelSmoother< L > >();
+         auto coarse   = std::make_shared< CGSolver< L > >( storage, (uint_t) minL, (uint_t) maxL );
+         auto gmg      = std::make_shared< GeometricMultigridSolver< L > >( storage, smoother, coarse, std::make_shared< P1toP1LinearRestriction >(),
+                                                                       std::make_shared< P1toP1LinearProlongation >(), (uint_t) minL, (uint_t) maxL, 2, 2 );
+         prec = std::make_shared< StokesBlockDiagonalPreconditioner< Op, P1LumpedInvMassOperator > >( storage, (uint_t) minL, (uint_t) maxL,
+                                                                                                       (uint_t) velocity_steps, gmg );
+      }
+      else
+         throw std::runtime_error( "stokes_minres_create: unknown preconditioner" );
+      auto solver = std::make_shared< MinResSolver< Op > >( storage, (uint_t) minL, (uint_t) maxL, (uint_t) max_iter, rel_tol, 1e-16, prec );
+      *out        = new StokesSolverH{ solver };
+   } );
+}
+HYTEG_HOST_API int hyteg_host_stokes_minres_iterations( hh_stokes_solver_t solver, int* iterations )
+{
+   return guarded( [&] {
+      auto* m = dynamic_cast< MinResSolver< P1P1StokesOperator >* >( static_cast< StokesSolverH* >( solver )->p.get() );
+      if ( !m )
+         throw std::runtime_error( "stokes_minres_iterations: not a MinResSolver" );
+      *iterations = (int) m->getIterations();
+   } );
+}
+// MinResSolver< P1ConstantLaplaceOperator > with JacobiPreconditioner( jacobi_iterations ) (0: identity), as
+// tests/hyteg/convergence/P1MinResConvergenceTest.cpp:68-72
+HYTEG_HOST_API int hyteg_host_solver_create_minres( hh_storage_t s, int minL, int maxL, int max_iter, double rel_tol, int jacobi_iterations, hh_solver_t* out )
+{
+   return guarded( [&] {
+      using L      = P1ConstantLaplaceOperator;
+      auto storage = static_cast< StorageH* >( s )->p;
+      std::shared_ptr< Solver< L > > prec;
+      if ( jacobi_iterations > 0 )
+         prec = std::make_shared< JacobiPreconditioner< L > >( storage, (uint_t) minL, (uint_t) maxL, (uint_t) jacobi_iterations );
+      else
+         prec = std::make_shared< IdentityPreconditioner< L > >();
+      *out = new SolverH{ std::make_shared< MinResSolver< L > >( storage, (uint_t) minL, (uint_t) maxL, (uint_t) max_iter, rel_tol, 1e-16, prec ) };
    } );
 }
 HYTEG_HOST_API int hyteg_host_stokes_solver_solve( hh_stokes_solver_t solver, hh_stokes_operator_t op, hh_stokes_function_t x, hh_stokes_function_t b, int level )

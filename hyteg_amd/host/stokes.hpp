@@ -8,6 +8,7 @@
 // stencil kernels as for the Laplace operator, with other weights.
 #pragma once
 
+#include "minres.hpp"
 #include "solvers.hpp"
 
 namespace hyteg {

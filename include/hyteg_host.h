@@ -184,6 +184,20 @@ HYTEG_HOST_API int hyteg_host_stokes_uzawa_create( hh_storage_t s, int min_level
                                                    int velocity_smoother, double velocity_relax, hh_stokes_solver_t* out );
 HYTEG_HOST_API int hyteg_host_stokes_gmg_create( hh_storage_t s, hh_stokes_solver_t smoother, int min_level, int max_level, int pre, int post,
                                                  int increment, int project_mean_after_restriction, hh_stokes_solver_t* out );
+/* GeometricMultigridSolver< P1P1StokesOperator > with a choice of coarse-grid solver: 0 = dense LU on the host (stand-in for
+ * PETScLUSolver, single rank), 1 = MinResSolver preconditioned with StokesPressureBlockPreconditioner< P1P1StokesOperator,
+ * P1LumpedInvMassOperator > (apps/stokesSphere/StokesSphere.cpp:227-237; any number of ranks) */
+HYTEG_HOST_API int hyteg_host_stokes_gmg_create_with_coarse( hh_storage_t s, hh_stokes_solver_t smoother, int min_level, int max_level, int pre, int post,
+                                                             int increment, int project_mean_after_restriction, int coarse, int coarse_max_iter,
+                                                             double coarse_rel_tol, hh_stokes_solver_t* out );
+/* MinResSolver< P1P1StokesOperator > (src/hyteg/solvers/MinresSolver.hpp): preconditioner 0 identity, 1 pressure block (lumped
+ * inverse mass), 2 StokesBlockDiagonalPreconditioner with `velocity_steps` V(2,2) Laplace cycles per velocity component */
+HYTEG_HOST_API int hyteg_host_stokes_minres_create( hh_storage_t s, int min_level, int max_level, int max_iter, double rel_tol, int preconditioner,
+                                                    int velocity_steps, hh_stokes_solver_t* out );
+HYTEG_HOST_API int hyteg_host_stokes_minres_iterations( hh_stokes_solver_t solver, int* iterations );
+/* MinResSolver< P1ConstantLaplaceOperator > with JacobiPreconditioner( jacobi_iterations ) (0: identity) */
+HYTEG_HOST_API int hyteg_host_solver_create_minres( hh_storage_t s, int min_level, int max_level, int max_iter, double rel_tol, int jacobi_iterations,
+                                                    hh_solver_t* out );
 HYTEG_HOST_API int hyteg_host_stokes_solver_solve( hh_stokes_solver_t solver, hh_stokes_operator_t op, hh_stokes_function_t x, hh_stokes_function_t b, int level );
 HYTEG_HOST_API int hyteg_host_stokes_solver_destroy( hh_stokes_solver_t solver );
 

@@ -1,0 +1,153 @@
+"""MinResSolver (src/hyteg/solvers/MinresSolver.hpp) and the preconditioners apps/stokesSphere composes around it
+(BASELINE config 5's coarse-grid solver): single rank here, two ranks in tests/test_gpu_stokes_distributed.py.
+Known answers of the reference: tests/hyteg/convergence/P1MinResConvergenceTest.cpp (its 2-D mesh has no 3-D counterpart in
+the tree: the same set-up -- harmonic x^2 - y^2, Jacobi( 10 )-preconditioned MINRES to 1e-8 -- on the unit cube) and the Uzawa
+multigrid test with the MINRES coarse-grid solver in place of PETSc's LU."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+MESHES = ROOT / "hyteg_amd" / "data" / "meshes"
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    from hyteg_amd import capi, host
+    from oracle import p1_oracle as po
+
+    assert torch.cuda.is_available()
+    capi.lib()
+    host.lib()
+    return torch, capi, host, po
+
+
+@pytest.mark.parametrize("jacobi", [0, 10])
+def test_minres_laplace_recovers_a_harmonic_quadratic(env, jacobi):
+    """P1MinResConvergenceTest.cpp:57-85: u = x^2 - y^2 on the boundary, zero right-hand side, MINRES( 1000, 1e-8 ) preconditioned
+    with 10 Jacobi iterations: discrete L2 error < 6e-9 (there: level 5 of a 2-D mesh; here: level 4 of cube_6el, whose uniform
+    refinement reproduces harmonic quadratics exactly as well)"""
+    torch, capi, host, po = env
+    from hostutil import MultiCellOracle, download, upload
+
+    min_level, max_level = 2, 4
+    st = host.Storage.from_gmsh(MESHES / "cube_6el.msh")
+    mo = MultiCellOracle(st)
+    L = host.P1ConstantOperator(st, min_level, max_level)
+    L.compute_inverse_diagonal()
+    u, f, ex, err, tmp = (host.P1Function(st, n, min_level, max_level) for n in ("u", "f", "u_exact", "err", "tmp"))
+    for fn in (u, f, ex, err):
+        fn.interpolate(0.0, max_level, host.All)
+    upload(ex, mo.interpolate(lambda x, y, z: x * x - y * y, max_level), max_level)
+    u.assign([1.0], [ex], max_level, host.DirichletBoundary)
+    solver = host.Solver.minres(st, min_level, max_level, 1000, 1e-8, jacobi)
+    solver.solve(L, u, f, max_level)
+    err.assign([1.0, -1.0], [u, ex], max_level, host.All)
+    tmp.interpolate(1.0, max_level, host.All)
+    npoints = tmp.dot(tmp, max_level, host.All)
+    l2 = np.sqrt(err.dot(err, max_level, host.All) / npoints)
+    assert l2 < 6e-9, l2
+    for o in (solver, u, f, ex, err, tmp, L, st):
+        o.close()
+
+
+def _stokes_problem(host, st, min_level, max_level):
+    from hostutil import MultiCellOracle, upload
+
+    mo = MultiCellOracle(st)
+    L = host.P1P1StokesOperator(st, min_level, max_level)
+    u, f, r, exact = (host.P1StokesFunction(st, n, min_level, max_level) for n in ("u", "f", "r", "uExact"))
+    cf = [lambda x, y, z: 20.0 * x * y ** 3, lambda x, y, z: 5.0 * x ** 4 - 5.0 * y ** 4, lambda x, y, z: 0.0 * x,
+          lambda x, y, z: 60.0 * x ** 2 * y - 20.0 * y ** 3]
+    for fn in (u, f, r, exact):
+        for lvl in range(min_level, max_level + 1):
+            for k in range(4):
+                fn.components[k].interpolate(0.0, lvl, host.All)
+    for k in range(4):
+        upload(exact.components[k], mo.interpolate(cf[k], max_level), max_level)
+    for k in range(3):
+        u.components[k].assign([1.0], [exact.components[k]], max_level, host.DirichletBoundary)
+    return L, u, f, r, exact
+
+
+def test_pressure_preconditioned_minres_solves_the_coarse_stokes_system(env):
+    """the coarse-grid solver of apps/stokesSphere (StokesSphere.cpp:227-237) on level 2 of cube_24el: the residual of the
+    saddle-point system drops by ten orders of magnitude, and the solution agrees with the dense direct solve up to the
+    pressure's constant"""
+    torch, capi, host, po = env
+    level = 2
+    st = host.Storage.from_gmsh(MESHES / "cube_24el.msh")
+    L, u, f, r, exact = _stokes_problem(host, st, level, level)
+    flag = host.Inner | host.NeumannBoundary
+
+    def residual():
+        L.apply(u, r, level, flag)
+        r.assign([1.0, -1.0], [f, r], level, flag)
+        return np.sqrt(r.dot(r, level, flag))
+
+    r0 = residual()
+    mr = host.StokesSolver.minres(st, level, level, 2000, 1e-13, "pressure")
+    mr.solve(L, u, f, level)
+    its = mr.minres_iterations
+    assert 0 < its < 2000
+    assert residual() < 1e-10 * r0
+    # identity-preconditioned MINRES converges as well, more slowly
+    u2 = host.P1StokesFunction(st, "u2", level, level)
+    for k in range(4):
+        u2.components[k].interpolate(0.0, level, host.All)
+    for k in range(3):
+        u2.components[k].assign([1.0], [exact.components[k]], level, host.DirichletBoundary)
+    mi = host.StokesSolver.minres(st, level, level, 5000, 1e-13, "identity")
+    mi.solve(L, u2, f, level)
+    assert mi.minres_iterations < 5000
+    host.project_mean(u.p, level)
+    host.project_mean(u2.p, level)
+    u2.assign([1.0, -1.0], [u2, u], level, host.All)
+    assert np.sqrt(u2.dot(u2, level, host.All)) < 1e-7 * np.sqrt(u.dot(u, level, host.All))
+    for o in (mr, mi, u, u2, f, r, exact, L, st):
+        o.close()
+
+
+def test_uzawa_multigrid_with_the_minres_coarse_grid_solver(env):
+    """tests/hyteg/convergence/P1P1Stokes3DUzawaConvergenceTest.cpp (cube_24el, levels 2..5, V(3,3) increment 2, Uzawa( 0.3 ) over
+    Gauss-Seidel) with stokesSphere's coarse-grid solver -- pressure-preconditioned MINRES -- instead of the exact solve: the
+    reference's bounds still hold (residual reduction < 0.14 per cycle, errors u+v+w < 2.8e-3, p < 0.13, residual < 4e-6)"""
+    torch, capi, host, po = env
+    min_level, max_level = 2, 5
+    st = host.Storage.from_gmsh(MESHES / "cube_24el.msh")
+    L, u, f, r, exact = _stokes_problem(host, st, min_level, max_level)
+    err = host.P1StokesFunction(st, "err", min_level, max_level)
+    one = host.P1Function(st, "one", max_level, max_level)
+    one.interpolate(1.0, max_level, host.All)
+    ndofs = one.dot(one, max_level, host.All)
+    flag = host.Inner | host.NeumannBoundary
+
+    def residual():
+        L.apply(u, r, max_level, flag)
+        return np.sqrt(r.dot(r, max_level, host.All) / (4.0 * ndofs))
+
+    smoother = host.StokesSolver.uzawa(st, min_level, max_level, 0.3, velocity_iterations=2, velocity_smoother=host.GAUSS_SEIDEL)
+    gmg = host.StokesSolver.gmg(st, smoother, min_level, max_level, pre=3, post=3, increment=2, project_mean_after_restriction=True,
+                                coarse="minres", coarse_max_iter=1000, coarse_rel_tol=1e-12)
+    last = residual()
+    for _ in range(3):
+        gmg.solve(L, u, f, max_level)
+        host.project_mean(u.p, max_level)
+        host.project_mean(exact.p, max_level)
+        res = residual()
+        assert res / last < 0.14, (res, last)
+        last = res
+    for k in range(4):
+        err.components[k].assign([1.0, -1.0], [u.components[k], exact.components[k]], max_level, host.All)
+    e_uvw = sum(np.sqrt(err.components[k].dot(err.components[k], max_level, host.All) / ndofs) for k in range(3))
+    e_p = np.sqrt(err.p.dot(err.p, max_level, host.All) / ndofs)
+    assert e_uvw < 2.8e-3 and e_p < 0.13 and last < 4e-6, (e_uvw, e_p, last)
+    for o in (gmg, smoother, u, f, r, exact, err, one, L, st):
+        o.close()
