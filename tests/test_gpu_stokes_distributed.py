@@ -83,7 +83,7 @@ def _run_cycle(host, st, min_level, max_level):
 
     uz = host.StokesSolver.uzawa(st, min_level, max_level, 0.3, velocity_iterations=2, velocity_smoother=host.GAUSS_SEIDEL)
     gmg = host.StokesSolver.gmg(st, uz, min_level, max_level, pre=2, post=2, increment=2, project_mean_after_restriction=True,
-                                coarse="minres", coarse_max_iter=400, coarse_rel_tol=1e-13)
+                                coarse="minres", coarse_max_iter=40, coarse_rel_tol=1e-16)
     res = [residual()]
     for _ in range(2):
         gmg.solve(L, x, b, max_level)
