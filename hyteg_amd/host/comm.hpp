@@ -4,6 +4,8 @@
 // pack, non-blocking send/receive per neighbour rank, wait, unpack) for one process per GPU.
 #pragma once
 
+#include <set>
+
 #include "types.hpp"
 
 namespace hyteg {
@@ -250,9 +252,20 @@ class P2PTransport : public Transport
          timeoutMs_ = (unsigned) std::atoi( e );
       if ( const char* e = std::getenv( "HYTEG_HIP_P2P_FUSED_WAIT" ) ) // 0: a wait kernel of its own in front of the reduce kernel
          fusedWait_ = std::atoi( e ) != 0;
+      live().insert( this );
+   }
+   // An exception between the begin and the end of an exchange (a failed launch, a Python hook that raised) would leave the plan
+   // marked "in flight" and every later exchange of it would be refused: the host layer's C facade calls this from its catch
+   // block, for every live transport (the failed operation's results are invalid either way).
+   static void abortExchangesOfAllTransports()
+   {
+      for ( P2PTransport* t : live() )
+         for ( auto& s : t->plans_ )
+            s.second.inFlight = false;
    }
    ~P2PTransport() override
    {
+      live().erase( this );
       if ( lastCompute_ )
          hyteg_hip_stream_synchronize( lastCompute_ );
       hyteg_hip_stream_synchronize( nullptr );
@@ -439,7 +452,15 @@ class P2PTransport : public Transport
       }
       inner_->check( compute );
    }
-   void        allreduceSum( double* values, int n ) override { inner_->allreduceSum( values, n ); }
+   // A global sum is a point where the host waits for the device anyway (the local sums have just been read back): the status word
+   // of the arrival waits is read there as well, so that a solver that only ever calls dot products (CG, MINRES, the multigrid
+   // residual norms) cannot continue on values a timed-out wait let through.
+   void allreduceSum( double* values, int n ) override
+   {
+      if ( lastCompute_ )
+         check( lastCompute_ );
+      inner_->allreduceSum( values, n );
+   }
    bool        collective() const override { return inner_->collective(); }
    bool        anyStream( int level, int key ) const override { return connected( level, key ) || inner_->anyStream( level, key ); }
    const char* name() const override { return "p2p"; }
@@ -475,6 +496,11 @@ class P2PTransport : public Transport
    int                                          arenaKind_ = 0;
    bool                                         opened_    = false;
    unsigned*                                    dStatus_   = nullptr;
+   static std::set< P2PTransport* >& live()
+   {
+      static std::set< P2PTransport* > s;
+      return s;
+   }
    unsigned                                     timeoutMs_ = 0;
    bool                                         fusedWait_ = true;
    hyteg_hip_stream_t                           lastCompute_ = nullptr;

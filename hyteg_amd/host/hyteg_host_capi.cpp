@@ -59,10 +59,12 @@ int guarded( F&& fn )
    } catch ( const std::exception& e )
    {
       g_err = e.what();
+      P2PTransport::abortExchangesOfAllTransports(); // no plan stays "in flight" behind a failed operation
       return 1;
    } catch ( ... )
    {
       g_err = "unknown error";
+      P2PTransport::abortExchangesOfAllTransports();
       return 1;
    }
 }

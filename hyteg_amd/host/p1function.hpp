@@ -251,6 +251,8 @@ class P1Function
       hipCheck( hyteg_hip_download( host, getCellPointer( c, level ), (size_t) layout::cellSize( (int) level ) * sizeof( double ),
                                     storage_->stream() ),
                 "copyCellToHost" );
+      // the host is about to use values that may have come through a peer-to-peer exchange: a timed-out arrival wait fails here
+      storage_->checkTransportAtHostRead();
    }
    void copyCellFromHost( uint_t c, uint_t level, const double* host ) const
    {

@@ -417,6 +417,13 @@ class PrimitiveStorage
       if ( transport_ )
          transport_->check( stream_ );
    }
+   // at the points where the host reads device results anyway (downloads of cell arrays): only the peer-to-peer transport has
+   // something to check there (the status word of its device-side arrival waits)
+   void checkTransportAtHostRead() const
+   {
+      if ( transport_ && std::string( transport_->name() ) == "p2p" )
+         transport_->check( stream_ );
+   }
    Transport* transport() const { return transport_.get(); }
    Transport& requireTransport( const char* what ) const
    {

@@ -309,3 +309,71 @@ def test_p2p_canary_between_processes_on_one_gpu():
     procs = [p2p_canary.launch(r, 3, 0, tag) for r in range(3)]
     outs = [p2p_canary.finish(p) for p in procs]
     assert all(ok for ok, _ in outs), outs
+
+
+# ---- a peer that never sends: the arrival wait times out and the next host synchronisation point raises ------------------
+def _worker_withheld(rank, world, port, level, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HYTEG_HIP_P2P_TIMEOUT_MS="300")
+    import torch
+    import torch.distributed as dist
+
+    from hyteg_amd import host
+    from hyteg_amd.distributed import DistributedContext
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        st = host.Storage.from_gmsh(ROOT / "hyteg_amd" / "data" / "meshes" / "pyramid_2el.msh", rank, world)
+        st.set_boundary_type(host.NeumannBoundary)  # the shared face takes part in apply( ..., All )
+        st.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx = DistributedContext(st, [level], torch.device("cuda", 0), transport="p2p")
+        assert ctx.transport == "p2p" and st.transport == "p2p", ctx.transport_note
+        A = host.P1ConstantOperator(st, level, level)
+        u, r = host.P1Function(st, "u", level, level), host.P1Function(st, "r", level, level)
+        u.interpolate(1.0, level, host.All)
+        outcome = "withheld"
+        if rank == 0:
+            # rank 1 never runs this apply: the reduce kernel's wait for its values gives up after 300 ms and lets stale values
+            # through -- the dot product (a point where the host waits for the device anyway) must refuse to go on
+            A.apply(u, r, level, host.All)
+            try:
+                r.dot(r, level, host.All)
+                outcome = "no error"
+            except host.HytegHostError as e:
+                outcome = str(e)
+            # the plan is usable again afterwards (not stuck "in flight"), and a download checks the transport as well
+            try:
+                A.apply(u, r, level, host.All)
+                r.download_cell(0, level)
+                outcome += " | second: no error"
+            except host.HytegHostError as e:
+                outcome += " | second: " + str(e)
+        q.put((rank, outcome))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_p2p_timeout_fails_the_next_dot_product_or_download():
+    """a timed-out peer-to-peer arrival wait must not be silent -- P2PTransport checks its status word at the host
+    synchronisation points that exist anyway (global sums, downloads of cell arrays)"""
+    import torch
+    import torch.multiprocessing as mp
+
+    assert torch.cuda.is_available()
+    level, world = 3, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_withheld, args=(r, world, port, level, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[1] == "withheld"
+    first, second = results[0].split(" | second: ")
+    assert "timed out" in first, results[0]
+    assert "timed out" in second, results[0]  # not "second exchange of a plan begun before the first one has ended"
