@@ -198,7 +198,7 @@ def test_p2_apply_on_two_ranks_reproduces_the_single_rank_result(transport):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, level, q, transport)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, level, q, transport), daemon=True) for r in range(2)]
     for p in procs:
         p.start()
     results = []

@@ -139,7 +139,7 @@ def test_stokes_operator_and_uzawa_smoother_on_two_ranks(transport):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, level, q, transport)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, level, q, transport), daemon=True) for r in range(world)]
     for p in procs:
         p.start()
     results = []
@@ -180,7 +180,7 @@ def test_stokes_v_cycle_with_minres_coarse_solver_on_two_ranks(transport):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, levels, q, transport)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, levels, q, transport), daemon=True) for r in range(world)]
     for p in procs:
         p.start()
     results = []
