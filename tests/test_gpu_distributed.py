@@ -350,6 +350,11 @@ def _worker_late_peer(rank, world, port, level, q):
             r.download_cell(0, level)  # rank 0's values arrived long ago: nothing to report
         q.put((rank, outcome))
         dist.barrier()
+    except BaseException as e:  # report before the process group is torn down (which may block while the peer waits)
+        import traceback
+
+        q.put((rank, "worker failed: " + repr(e) + " " + traceback.format_exc()[-1500:]))
+        raise
     finally:
         dist.destroy_process_group()
 
