@@ -639,8 +639,12 @@ HYTEG_HOST_API int hyteg_host_stokes_uzawa_create( hh_storage_t s, int minL, int
          scalar = std::make_shared< WeightedJacobiSmoother< P1ConstantLaplaceOperator > >( storage, (uint_t) minL, (uint_t) maxL, velocity_relax );
       else if ( velocity_smoother == 1 )
          scalar = std::make_shared< GaussSeidelSmoother< P1ConstantLaplaceOperator > >();
-      else
+      else if ( velocity_smoother == 2 )
          scalar = std::make_shared< SORSmoother< P1ConstantLaplaceOperator > >( velocity_relax );
+      else if ( velocity_smoother == 3 ) // BASELINE config 5's "fp32 smoother": float Jacobi sweeps inside the Uzawa smoother
+         scalar = std::make_shared< MixedPrecisionJacobiSmoother< P1ConstantLaplaceOperator > >( storage, (uint_t) minL, (uint_t) maxL, velocity_relax );
+      else
+         throw std::runtime_error( "stokes_uzawa_create: unknown velocity smoother" );
       auto velocity = std::make_shared< StokesVelocityBlockBlockDiagonalPreconditioner< Op > >( storage, scalar );
       *out          = new StokesSolverH{ std::make_shared< UzawaSmoother< Op > >( storage, velocity, (uint_t) minL, (uint_t) maxL, relax,
                                                                                   Inner | NeumannBoundary | FreeslipBoundary,
