@@ -171,7 +171,9 @@ class P1ConstantVectorLaplaceOperator
    using dstType = P1VectorFunction< double >;
    P1ConstantVectorLaplaceOperator( const std::shared_ptr< PrimitiveStorage >& storage, uint_t minLevel, uint_t maxLevel )
    : lapl_( std::make_shared< P1ConstantLaplaceOperator >( storage, minLevel, maxLevel ) )
-   {}
+   {
+      lapl_->computeInverseDiagonalOperatorValues(); // Jacobi-type velocity smoothers ask the scalar operator for it
+   }
    void apply( const srcType& src, const dstType& dst, uint_t level, DoFType flag, UpdateType updateType = Replace ) const
    {
       for ( uint_t k = 0; k < 3; ++k )

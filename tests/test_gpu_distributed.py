@@ -315,7 +315,10 @@ def test_p2p_canary_between_processes_on_one_gpu():
 def _worker_late_peer(rank, world, port, level, q):
     sys.path.insert(0, str(ROOT))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HYTEG_HIP_P2P_TIMEOUT_MS="300")
+    import faulthandler
     import time
+
+    faulthandler.dump_traceback_later(60, exit=True)  # a rank that hangs says where, and ends
 
     import torch
     import torch.distributed as dist
@@ -333,6 +336,10 @@ def _worker_late_peer(rank, world, port, level, q):
         A = host.P1ConstantOperator(st, level, level)
         u, r = host.P1Function(st, "u", level, level), host.P1Function(st, "r", level, level)
         u.interpolate(1.0, level, host.All)
+        # one ordinary apply + dot first: nothing times out, and every kernel has been launched once (a first launch can take
+        # longer than the two seconds below)
+        A.apply(u, r, level, host.Inner)
+        r.dot(r, level, host.Inner)
         dist.barrier()
         # both ranks make the same calls (the plans without peers still go through the collective hooks), but rank 1 starts its
         # apply two seconds late: rank 0's reduce kernel gives up waiting for rank 1's values after 300 ms and lets stale values
