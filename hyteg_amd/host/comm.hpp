@@ -266,7 +266,7 @@ class P2PTransport : public Transport
    ~P2PTransport() override
    {
       live().erase( this );
-      if ( lastCompute_ )
+      if ( exchanged_ )
          hyteg_hip_stream_synchronize( lastCompute_ );
       hyteg_hip_stream_synchronize( nullptr );
       for ( auto& s : plans_ )
@@ -371,7 +371,7 @@ class P2PTransport : public Transport
       if ( S->inFlight )
          throw std::runtime_error( "P2PTransport: second exchange of a plan begun before the first one has ended" );
       S->inFlight  = true;
-      lastCompute_ = compute;
+      lastCompute_ = compute, exchanged_ = true;
       ++S->seq;
       hipCheck( hyteg_hip_p2p_pack( S->dPeers, (int) plan.peers.size(), bases, plan.dSendBuf, plan.dSendOff, plan.totalSend(), S->seq,
                                     S->dCounter, compute ),
@@ -386,7 +386,7 @@ class P2PTransport : public Transport
       if ( S->inFlight )
          throw std::runtime_error( "P2PTransport: second exchange of a plan begun before the first one has ended" );
       S->inFlight  = true;
-      lastCompute_ = compute;
+      lastCompute_ = compute, exchanged_ = true;
       ++S->seq;
       a.peers   = S->dPeers;
       a.npeers  = (int) plan.peers.size();
@@ -457,7 +457,7 @@ class P2PTransport : public Transport
    // residual norms) cannot continue on values a timed-out wait let through.
    void allreduceSum( double* values, int n ) override
    {
-      if ( lastCompute_ )
+      if ( exchanged_ ) // (the stream handle itself may be null: the default stream)
          check( lastCompute_ );
       inner_->allreduceSum( values, n );
    }
@@ -504,6 +504,7 @@ class P2PTransport : public Transport
    unsigned                                     timeoutMs_ = 0;
    bool                                         fusedWait_ = true;
    hyteg_hip_stream_t                           lastCompute_ = nullptr;
+   bool                                         exchanged_ = false; // an exchange has been packed on lastCompute_
    std::map< std::pair< int, int >, PlanState > plans_;
 };
 
