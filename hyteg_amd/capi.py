@@ -60,6 +60,8 @@ SIGNATURES = {
     "hyteg_hip_cell_index": (_i64, [_i, _i, _i, _i]),
     "hyteg_hip_p1_apply_cell": (_i, [_vp, _vp, _i, _dp, _i, _vp]),
     "hyteg_hip_p1_apply_kernel_name": (_i, [_i, _i, C.c_char_p, _sz]),
+    "hyteg_hip_p1_residual_jacobi_start_f32": (_i, [_vp, _vp, _vp, _vp, _i, _dp, _d, _vp]),
+    "hyteg_hip_p1_jacobi_accumulate_f32": (_i, [_vp, _vp, _vp, _i, _dp, _d, _vp]),
     "hyteg_hip_set_apply_shape": (_i, [_i, _i, _i]),
     "hyteg_hip_p1_apply_cell_f32": (_i, [_vp, _vp, _i, _dp, _i, _vp]),
     "hyteg_hip_p1_jacobi_cell_f32": (_i, [_vp, _vp, _vp, _vp, _i, _dp, _d, _vp]),
@@ -254,6 +256,14 @@ def stream_wait_event(stream, ev) -> None:
 def calib_copy(dst, src, n, nontemporal=True, stream=0) -> None:
     """streaming copy of n doubles (calibration of the practical bandwidth floor; bench.py roofline.copy_us)"""
     check(lib().hyteg_hip_calib_copy(dst, src, n, 1 if nontemporal else 0, stream), "calib_copy")
+
+
+def p1_residual_jacobi_start_f32(r_f32, e_f32, rhs, src, level, w, relax, stream=0):
+    check(lib().hyteg_hip_p1_residual_jacobi_start_f32(r_f32, e_f32, rhs, src, level, _w15(w), float(relax), stream), "p1_residual_jacobi_start_f32")
+
+
+def p1_jacobi_accumulate_f32(x, rhs_f32, e_f32, level, w, relax, stream=0):
+    check(lib().hyteg_hip_p1_jacobi_accumulate_f32(x, rhs_f32, e_f32, level, _w15(w), float(relax), stream), "p1_jacobi_accumulate_f32")
 
 
 def set_apply_shape(ny=0, lz=0, pfd=0) -> None:

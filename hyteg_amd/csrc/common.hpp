@@ -132,7 +132,11 @@ enum ApplyMode
    APPLY_REPLACE = 0,
    APPLY_ADD     = 1,
    APPLY_JACOBI  = 2,
-   APPLY_RESIDUAL = 3 // dst = rhs - A src
+   APPLY_RESIDUAL = 3, // dst = rhs - A src
+   // the two fused steps of the mixed-precision Jacobi smoother (double arrays in, float arrays out, and back):
+   APPLY_RESIDUAL_F32OUT = 4, // double arithmetic: r = rhs - A src; dst (float) = r, dst2 (float) = relax * r / centre  (= the first Jacobi
+                              //   sweep on A e = r from e = 0)
+   APPLY_JACOBI_ACCUM = 5     // float arithmetic: e = src + relax * ( rhs - A src ) / centre (src, rhs float); xacc (double) += e; e is not stored
 };
 
 struct Stencil15

@@ -54,8 +54,10 @@ struct ZMarchArgs
    // both, apply_3D_macrocell_vertexdof_to_vertexdof_replace.cpp:96-97)
    void*            dst;
    const void*      src;
-   const void*      rhs;     // JACOBI only
+   const void*      rhs;     // JACOBI / RESIDUAL modes
    const void*      invdiag; // JACOBI only, may be null
+   void*            dst2;    // RESIDUAL_F32OUT: second float output (the first Jacobi iterate of the error equation)
+   double*          xacc;    // JACOBI_ACCUM: the double array the last float sweep is added to
    const BrickTask* tasks;   // table mode (DEC == false)
    int              ntasks;
    unsigned         bytes;     // size of the cell array in bytes (buffer range): entries x sizeof( value type )
@@ -225,9 +227,14 @@ __device__ inline void zmarch_body( const ZMarchArgs& A, const BrickTask* tasks,
 
    constexpr int kStAux = ST_AUX; // 2 = nontemporal (the default; 1 = sc0, 16 = sc1: measured variants)
    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc( const_cast< void* >( A.src ), 0, A.bytes, 0x00020000 );
-   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc( A.dst, 0, A.bytes, 0x00020000 );
-   const __amdgpu_buffer_rsrc_t rr =
-       __builtin_amdgcn_make_buffer_rsrc( const_cast< void* >( ( MODE == APPLY_JACOBI || MODE == APPLY_RESIDUAL ) ? A.rhs : A.src ), 0, A.bytes, 0x00020000 );
+   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc( A.dst, 0, MODE == APPLY_RESIDUAL_F32OUT ? A.bytes / 2 : A.bytes, 0x00020000 );
+   constexpr bool kHasRhs = MODE == APPLY_JACOBI || MODE == APPLY_RESIDUAL || MODE == APPLY_RESIDUAL_F32OUT || MODE == APPLY_JACOBI_ACCUM;
+   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc( const_cast< void* >( kHasRhs ? A.rhs : A.src ), 0, A.bytes, 0x00020000 );
+   // mixed-precision modes: float outputs of a double kernel (half the bytes), the double accumulator of a float kernel (twice)
+   const __amdgpu_buffer_rsrc_t rd2 =
+       __builtin_amdgcn_make_buffer_rsrc( MODE == APPLY_RESIDUAL_F32OUT ? A.dst2 : A.dst, 0, MODE == APPLY_RESIDUAL_F32OUT ? A.bytes / 2 : A.bytes, 0x00020000 );
+   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+       MODE == APPLY_JACOBI_ACCUM ? (void*) A.xacc : A.dst, 0, MODE == APPLY_JACOBI_ACCUM ? A.bytes * 2 : A.bytes, 0x00020000 );
    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(
        const_cast< void* >( ( MODE == APPLY_JACOBI && A.invdiag ) ? A.invdiag : A.src ), 0, A.bytes, 0x00020000 );
 
@@ -293,6 +300,7 @@ __device__ inline void zmarch_body( const ZMarchArgs& A, const BrickTask* tasks,
    // whole memory round trip at its first store of every slice -- 16.9 us for the fused Jacobi against 9.7 us for the apply,
    // i.e. 7 us for 23 MB more).
    T          EX0[LZ][NY], EX1[LZ][NY];
+   double     EXD[LZ][NY]; // JACOBI_ACCUM: the accumulator's old values
    const bool hasInv = MODE == APPLY_JACOBI && A.invdiag != nullptr;
    auto       load_extra = [&]( auto sc ) {
       constexpr int s = decltype( sc )::value;
@@ -307,6 +315,8 @@ __device__ inline void zmarch_body( const ZMarchArgs& A, const BrickTask* tasks,
             const int last8 = ( W - ( t.y0 + j ) - 1 - t.xb ) * SZ;
             const int vo    = min( lane_off, last8 );
             EX0[s][j]       = MODE == APPLY_ADD ? zm_load2< T, EX_AUX >( rd, vo, ie * SZ ) : zm_load2< T, EX_AUX >( rr, vo, ie * SZ );
+            if constexpr ( MODE == APPLY_JACOBI_ACCUM )
+               EXD[s][j] = zm_load2< double, 2 >( rx, min( lane * 8, last8 * 2 ), ie * 8 ); // read once, rewritten right after: nontemporal
             if constexpr ( MODE == APPLY_JACOBI )
             {
                T v = invc; // scalar inverse diagonal unless a function was given (wave-uniform branch)
@@ -367,8 +377,10 @@ __device__ inline void zmarch_body( const ZMarchArgs& A, const BrickTask* tasks,
             out = acc;
          else if ( MODE == APPLY_ADD )
             out = acc + EX0[s][j];
-         else if ( MODE == APPLY_RESIDUAL )
+         else if ( MODE == APPLY_RESIDUAL || MODE == APPLY_RESIDUAL_F32OUT )
             out = EX0[s][j] - acc; // the bits of assign( { 1, -1 }, { rhs, A src } ): one rounding of rhs - acc either way
+         else if ( MODE == APPLY_JACOBI_ACCUM )
+            out = a0 + relax * ( invc * ( EX0[s][j] - acc ) );
          else
             out = a0 + relax * ( EX1[s][j] * ( EX0[s][j] - acc ) );
          if constexpr ( XS == 62 )
@@ -376,7 +388,18 @@ __device__ inline void zmarch_body( const ZMarchArgs& A, const BrickTask* tasks,
             // outputs are lanes 1 .. min( 62, R - 2 - xb ) of slices that exist: one unsigned compare of (lane - 1)
             const int      cnt = s < t.nz ? min( 62, R - 2 - t.xb ) : 0; // wave-uniform
             const unsigned lm1 = (unsigned) ( lane - 1 );
-            zm_store2< T, kStAux >( rd, lm1 < (unsigned) max( cnt, 0 ) ? lane_off : -8, io * SZ, out );
+            const bool     on  = lm1 < (unsigned) max( cnt, 0 );
+            if constexpr ( MODE == APPLY_RESIDUAL_F32OUT )
+            {
+               // r as float, and the first Jacobi iterate of A e = r from e = 0: relax * r / centre (float arithmetic)
+               const float rf = (float) out;
+               zm_store2< float, 0 >( rd, on ? lane * 4 : -8, io * 4, rf ); // re-read by the following float sweeps: not nontemporal
+               zm_store2< float, 0 >( rd2, on ? lane * 4 : -8, io * 4, (float) relax * ( (float) invc * rf ) );
+            }
+            else if constexpr ( MODE == APPLY_JACOBI_ACCUM )
+               zm_store2< double, kStAux >( rx, on ? lane * 8 : -8, io * 8, EXD[s][j] + (double) out );
+            else
+               zm_store2< T, kStAux >( rd, on ? lane_off : -8, io * SZ, out );
          }
          else
          {

@@ -42,8 +42,10 @@ inline BrickShape default_shape( int mode, int level, bool f32 )
    return BrickShape{ 4, 4, 2 };
 }
 
+// `extra`: the second float output of APPLY_RESIDUAL_F32OUT / the double accumulator of APPLY_JACOBI_ACCUM
 template < int MODE, int NY, int LZ, int PFD, typename T >
-int launch_zmarch_shape( T* dst, const T* src, const T* rhs, const T* invdiag, int level, const double* w, double relax, hipStream_t stream )
+int launch_zmarch_shape( void* dst, const T* src, const T* rhs, const T* invdiag, int level, const double* w, double relax, hipStream_t stream,
+                         void* extra = nullptr )
 {
    BrickTable bt;
    int        rc = get_bricks( level, NY, LZ, &bt );
@@ -56,6 +58,8 @@ int launch_zmarch_shape( T* dst, const T* src, const T* rhs, const T* invdiag, i
    A.src     = src;
    A.rhs     = rhs;
    A.invdiag = invdiag;
+   A.dst2    = extra;
+   A.xacc    = static_cast< double* >( extra );
    A.tasks   = bt.dev;
    A.ntasks  = bt.count;
    A.N       = ( 1 << level ) + 1;
@@ -110,12 +114,15 @@ inline BrickShape current_shape( int mode, int level, bool f32 )
 }
 
 template < int MODE, typename T = double >
-int launch_zmarch( T* dst, const T* src, const T* rhs, const T* invdiag, int level, const double* w, double relax, hipStream_t stream )
+int launch_zmarch( void* dst, const T* src, const T* rhs, const T* invdiag, int level, const double* w, double relax, hipStream_t stream,
+                   void* extra = nullptr )
 {
-   const BrickShape s = current_shape( MODE, level, !std::is_same< T, double >::value );
+   // the fused mixed-precision steps take the shapes of the kernels they replace (residual / float Jacobi)
+   const int        shapeMode = MODE == APPLY_RESIDUAL_F32OUT ? APPLY_RESIDUAL : ( MODE == APPLY_JACOBI_ACCUM ? APPLY_JACOBI : MODE );
+   const BrickShape s         = current_shape( shapeMode, level, !std::is_same< T, double >::value );
 #define HH_X( NY_, LZ_, PFD_ ) \
    if ( s == BrickShape{ NY_, LZ_, PFD_ } ) \
-      return launch_zmarch_shape< MODE, NY_, LZ_, PFD_, T >( dst, src, rhs, invdiag, level, w, relax, stream );
+      return launch_zmarch_shape< MODE, NY_, LZ_, PFD_, T >( dst, src, rhs, invdiag, level, w, relax, stream, extra );
    HYTEG_ZM_SHAPES( HH_X )
 #undef HH_X
    return fail( HYTEG_HIP_EINVAL, "apply: brick shape not compiled in" );
@@ -224,6 +231,37 @@ HYTEG_HIP_API int hyteg_hip_p1_residual_cell( double*            dst,
    HH_REQUIRE( level >= HYTEG_HIP_MIN_LEVEL && level <= 10, "p1_residual_cell: level out of range [2,10]" );
    HH_REQUIRE( dst != src, "p1_residual_cell: src and dst must not alias" );
    return launch_zmarch< APPLY_RESIDUAL >( dst, src, rhs, (const double*) nullptr, level, w, 0.0, as_stream( stream ) );
+}
+
+// ---- the two fused steps of the mixed-precision Jacobi smoother (host/solvers.hpp MixedPrecisionJacobiSmoother::solveSteps) ----
+HYTEG_HIP_API int hyteg_hip_p1_residual_jacobi_start_f32( float*             r_f32,
+                                                          float*             e_f32,
+                                                          const double*      rhs,
+                                                          const double*      src,
+                                                          int                level,
+                                                          const double*      w,
+                                                          double             relax,
+                                                          hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( r_f32 && e_f32 && rhs && src && w, "p1_residual_jacobi_start_f32: null pointer" );
+   HH_REQUIRE( level >= HYTEG_HIP_MIN_LEVEL && level <= 10, "p1_residual_jacobi_start_f32: level out of range [2,10]" );
+   HH_REQUIRE( r_f32 != e_f32, "p1_residual_jacobi_start_f32: the two outputs must differ" );
+   HH_REQUIRE( w[7] != 0.0, "p1_residual_jacobi_start_f32: zero centre weight" );
+   return launch_zmarch< APPLY_RESIDUAL_F32OUT >( r_f32, src, rhs, (const double*) nullptr, level, w, relax, as_stream( stream ), e_f32 );
+}
+
+HYTEG_HIP_API int hyteg_hip_p1_jacobi_accumulate_f32( double*            x,
+                                                      const float*       rhs_f32,
+                                                      const float*       e_f32,
+                                                      int                level,
+                                                      const double*      w,
+                                                      double             relax,
+                                                      hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( x && rhs_f32 && e_f32 && w, "p1_jacobi_accumulate_f32: null pointer" );
+   HH_REQUIRE( level >= HYTEG_HIP_MIN_LEVEL && level <= 10, "p1_jacobi_accumulate_f32: level out of range [2,10]" );
+   HH_REQUIRE( w[7] != 0.0, "p1_jacobi_accumulate_f32: zero centre weight" );
+   return launch_zmarch< APPLY_JACOBI_ACCUM, float >( nullptr, e_f32, rhs_f32, (const float*) nullptr, level, w, relax, as_stream( stream ), x );
 }
 
 HYTEG_HIP_API int hyteg_hip_p1_apply_kernel_name( int level, int update, char* buf, size_t buflen )

@@ -79,14 +79,16 @@ class WeightedJacobiSmoother : public Solver< OperatorType >
 
 // Mixed-precision weighted Jacobi: the "fp32 smoother" of BASELINE config 5.  The reference instantiates its generated apply
 // kernels for float (apply_3D_macrocell_vertexdof_to_vertexdof_replace.cpp:96-97) and converts between function
-// precisions with copyFrom (VertexDoFFunction.hpp:598-650); this smoother uses exactly those pieces in defect-correction
-// form, so that the iterate and the residual stay in double:
-//   r = b - A x                                                   double, every point `flag` selects
-//   per macro-cell:  e = fp32Sweeps Jacobi sweeps on A e = r     float arrays, cell interior only, e = 0 on the cell boundary
-//                    (block Jacobi over the macro-cells: the fused float kernel, half the bytes of the double one)
-//   x += e                                                        double
-//   one double smooth_jac over all selected points                (the points shared between cells are smoothed here)
-// On one macro-cell with Dirichlet boundary the float part IS fp32Sweeps Jacobi sweeps on the error equation.
+// precisions with copyFrom (VertexDoFFunction.hpp:598-650); this smoother uses those pieces in defect-correction form, so
+// that the iterate and the right-hand side stay in double.  n Jacobi sweeps on A x = b are, in exact arithmetic,
+//      r = b - A x;   e_1 = relax r / c;   e_{k+1} = e_k + relax ( r - A e_k ) / c;   x += e_n          (c: centre weight)
+// -- the sweeps on the error equation run in float (half the bytes), the first one fused with the residual and the last one
+// with the update of x (hyteg_hip_p1_residual_jacobi_start_f32 / hyteg_hip_p1_jacobi_accumulate_f32): n launches for n sweeps.
+//  * solveSteps( n ) on macro-cells whose shell is not selected by the flag (one macro-cell with fixed boundary values): exactly
+//    that -- n Jacobi sweeps, corrections rounded to float relative to the CORRECTION, not to the iterate (round 2 needed
+//    residual + conversion + sweeps + axpy + copy + a double sweep per step: 3-4 x slower than the double smoother);
+//  * otherwise (points shared between macro-cells are smoothed): per step fp32Sweeps float sweeps on the cell interiors with
+//    e = 0 on the cell boundary (block Jacobi over the macro-cells), then one double smooth_jac over all selected points.
 template < class OperatorType >
 class MixedPrecisionJacobiSmoother : public Solver< OperatorType >
 {
@@ -95,7 +97,6 @@ class MixedPrecisionJacobiSmoother : public Solver< OperatorType >
    : storage_( storage )
    , relax_( relax )
    , fp32Sweeps_( fp32Sweeps )
-   , r_( "mixed_jacobi_r", storage, minLevel, maxLevel )
    , tmp_( "mixed_jacobi_tmp", storage, minLevel, maxLevel )
    , flag_( Inner | NeumannBoundary )
    {}
@@ -107,42 +108,61 @@ class MixedPrecisionJacobiSmoother : public Solver< OperatorType >
    }
    void solve( const OperatorType& A, const P1Function< double >& x, const P1Function< double >& b, uint_t level ) override
    {
-      if ( level >= HYTEG_HIP_MIN_LEVEL && level <= 10 && fp32Sweeps_ > 0 )
-      {
-         A.residual( x, b, r_, level, flag_ ); // apply + assign( { 1, -1 } ), one launch where no shell point is selected
-         const size_t n = (size_t) layout::cellSize( (int) level );
-         for ( uint_t c = 0; c < storage_->getNumberOfLocalCells(); ++c )
-         {
-            float**     f  = buffersFor( c, level ); // rf, e0, e1, zero
-            const auto& st = A.getCellStencils( storage_->getLocalCell( c ).id, level );
-            auto        s  = storage_->stream();
-            hipCheck( hyteg_hip_convert_f64_to_f32( f[0], r_.getCellPointer( c, level ), n, s ), "mixed Jacobi: convert residual" );
-            // the first sweep reads e = 0 from a buffer that is never written (no memset per step); the sweeps then alternate
-            // between e0 and e1, whose boundary entries are zero since their allocation and whose interior is overwritten
-            float *src = f[3], *dst = f[1];
-            for ( uint_t k = 0; k < fp32Sweeps_; ++k )
-            {
-               hipCheck( hyteg_hip_p1_jacobi_cell_f32( dst, f[0], src, nullptr, (int) level, st.inner, relax_, s ), "mixed Jacobi: float sweep" );
-               src = dst;
-               dst = dst == f[1] ? f[2] : f[1];
-            }
-            hipCheck( hyteg_hip_axpy_f32_into_f64( x.getCellPointer( c, level ), src, 1.0, n, s ), "mixed Jacobi: correction" );
-         }
-      }
+      if ( floatLevel( level ) && fp32Sweeps_ >= 2 )
+         floatSweeps( A, x, b, level, fp32Sweeps_ );
       tmp_.assign( { 1.0 }, { x }, level, All );
       A.smooth_jac( x, b, tmp_, relax_, level, flag_ );
    }
+   void solveSteps( const OperatorType& A, const P1Function< double >& x, const P1Function< double >& b, uint_t level, uint_t steps ) override
+   {
+      bool anyShell = storage_->numRanks() > 1;
+      for ( uint_t c = 0; c < storage_->getNumberOfLocalCells(); ++c )
+         anyShell = anyShell || ( storage_->maskFor( storage_->getLocalCell( c ), x.effectiveFlag( flag_ ) ) & HYTEG_HIP_MASK_SHELL );
+      if ( anyShell || !floatLevel( level ) || steps < 2 )
+      {
+         for ( uint_t i = 0; i < steps; ++i )
+            solve( A, x, b, level );
+         return;
+      }
+      floatSweeps( A, x, b, level, steps ); // `steps` Jacobi sweeps: every selected point is an inner point of its macro-cell
+   }
 
  private:
+   static bool floatLevel( uint_t level ) { return level >= HYTEG_HIP_MIN_LEVEL && level <= 10; }
+   // x += e_n on the inner points of every local cell, e_n = n float Jacobi sweeps on A e = b - A x from e = 0
+   void floatSweeps( const OperatorType& A, const P1Function< double >& x, const P1Function< double >& b, uint_t level, uint_t n )
+   {
+      const DoFType flag = x.effectiveFlag( flag_ );
+      for ( uint_t c = 0; c < storage_->getNumberOfLocalCells(); ++c )
+      {
+         const MacroCell& cell = storage_->getLocalCell( c );
+         if ( !( storage_->maskFor( cell, flag ) & HYTEG_HIP_MASK_INNER ) )
+            continue;
+         float**     f  = buffersFor( c, level ); // r, e0, e1: boundary entries of e0 / e1 are zero since their allocation
+         const auto& st = A.getCellStencils( cell.id, level );
+         auto        s  = storage_->stream();
+         hipCheck( hyteg_hip_p1_residual_jacobi_start_f32( f[0], f[1], b.getCellPointer( c, level ), x.getCellPointer( c, level ), (int) level, st.inner,
+                                                           relax_, s ),
+                   "mixed Jacobi: residual + first sweep" );
+         float *src = f[1], *dst = f[2];
+         for ( uint_t k = 2; k < n; ++k )
+         {
+            hipCheck( hyteg_hip_p1_jacobi_cell_f32( dst, f[0], src, nullptr, (int) level, st.inner, relax_, s ), "mixed Jacobi: float sweep" );
+            std::swap( src, dst );
+         }
+         hipCheck( hyteg_hip_p1_jacobi_accumulate_f32( x.getCellPointer( c, level ), f[0], src, (int) level, st.inner, relax_, s ),
+                   "mixed Jacobi: last sweep + correction" );
+      }
+   }
    float** buffersFor( uint_t c, uint_t level )
    {
       auto key = std::make_pair( c, level );
       auto it  = buffers_.find( key );
       if ( it == buffers_.end() )
       {
-         const size_t         bytes = (size_t) layout::cellSize( (int) level ) * sizeof( float );
+         const size_t          bytes = (size_t) layout::cellSize( (int) level ) * sizeof( float );
          std::vector< float* > v;
-         for ( int k = 0; k < 4; ++k )
+         for ( int k = 0; k < 3; ++k )
          {
             void* q = nullptr;
             hipCheck( hyteg_hip_malloc( &q, bytes ), "mixed Jacobi: malloc" );
@@ -153,11 +173,11 @@ class MixedPrecisionJacobiSmoother : public Solver< OperatorType >
       }
       return it->second.data();
    }
-   std::shared_ptr< PrimitiveStorage >                         storage_;
-   double                                                      relax_;
-   uint_t                                                      fp32Sweeps_;
-   P1Function< double >                                        r_, tmp_;
-   DoFType                                                     flag_;
+   std::shared_ptr< PrimitiveStorage >                            storage_;
+   double                                                         relax_;
+   uint_t                                                         fp32Sweeps_;
+   P1Function< double >                                           tmp_;
+   DoFType                                                        flag_;
    std::map< std::pair< uint_t, uint_t >, std::vector< float* > > buffers_;
 };
 

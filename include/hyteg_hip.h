@@ -152,6 +152,20 @@ HYTEG_HIP_API int hyteg_hip_convert_f64_to_f32( float* dst, const double* src, s
 HYTEG_HIP_API int hyteg_hip_convert_f32_to_f64( double* dst, const float* src, size_t n, hyteg_hip_stream_t stream );
 HYTEG_HIP_API int hyteg_hip_axpy_f32_into_f64( double* y, const float* x, double alpha, size_t n, hyteg_hip_stream_t stream );
 
+/* The two fused steps of a mixed-precision Jacobi smoother that keeps iterate and right-hand side in double and sweeps the error
+ * equation in float (no reference counterpart as a kernel; the reference's pieces are the float instantiation of its apply kernel
+ * and VertexDoFFunction::copyFrom between precisions, see above).  n Jacobi sweeps on A x = b equal
+ *    r = b - A x;  e_1 = relax r / c;  e_{k+1} = e_k + relax ( r - A e_k ) / c  (k = 1 .. n-1);  x += e_n      (c = centre weight)
+ * on the inner points of a macro-cell whose boundary values are fixed (e = 0 there):
+ *   hyteg_hip_p1_residual_jacobi_start_f32: r (double arithmetic) rounded to float into r_f32, and e_1 into e_f32 -- one launch;
+ *   hyteg_hip_p1_jacobi_cell_f32 (above): the sweeps in between;
+ *   hyteg_hip_p1_jacobi_accumulate_f32: the last sweep, added to x (double) instead of being stored -- one launch.
+ * n launches for n sweeps, 60 instead of 72 bytes per DoF for n = 3.  Levels 2..10; only inner points are read-modified. */
+HYTEG_HIP_API int hyteg_hip_p1_residual_jacobi_start_f32( float* r_f32, float* e_f32, const double* rhs, const double* src, int level, const double* w,
+                                                          double relax, hyteg_hip_stream_t stream );
+HYTEG_HIP_API int hyteg_hip_p1_jacobi_accumulate_f32( double* x, const float* rhs_f32, const float* e_f32, int level, const double* w, double relax,
+                                                      hyteg_hip_stream_t stream );
+
 /* Name of the kernel instantiation hyteg_hip_p1_apply_cell( ..., level, ..., update, ... ) launches on the current device,
  * with its template arguments, e.g. "p1_apply_zmarch_preload_kernel<MODE=0,NY=2,LZ=8,EX_AUX=0,DEC=0,PFD=1>" — what profiler
  * output and recorded counter files are matched against (no reference counterpart: measurement support). */

@@ -140,3 +140,76 @@ def test_multigrid_with_the_fp32_smoother_converges_like_the_fp64_one(env, mesh)
     assert f32[-1] <= 3.0 * f64[-1], (f32, f64)
     for o in (A, st):
         o.close()
+
+
+@pytest.mark.parametrize("level", [2, 4, 7, 8])
+def test_fused_steps_of_the_mixed_precision_jacobi_smoother(env, level):
+    """hyteg_hip_p1_residual_jacobi_start_f32 and hyteg_hip_p1_jacobi_accumulate_f32 against the double oracle:
+    r = b - A x rounded to float (relative L2 <= 1e-7: one float rounding of a double number), e_1 = relax r / c (float product:
+    <= 3e-7), and x += e + relax ( r - A e ) / c with the sweep in float (the INCREMENT within 2e-6, as the other float kernels);
+    entries outside the cell interior are untouched"""
+    torch, capi, host, po = env
+    n = po.cell_size(level)
+    rng = np.random.default_rng(90 + level)
+    w = po.assemble_cell_stencil(SKEW_TET, level)
+    relax = 0.7
+    x_h, b_h = rng.random(n), rng.random(n)
+    x, b = torch.from_numpy(x_h).cuda(), torch.from_numpy(b_h).cuda()
+    rf = torch.full((n,), 3.0, dtype=torch.float32, device="cuda")
+    e1 = torch.full((n,), 5.0, dtype=torch.float32, device="cuda")
+    capi.p1_residual_jacobi_start_f32(rf.data_ptr(), e1.data_ptr(), b.data_ptr(), x.data_ptr(), level, w, relax)
+    torch.cuda.synchronize()
+    ax = np.zeros(n)
+    po.apply_cell(ax, x_h, level, w)
+    m = po.inner_mask(level)
+    r_ref = (b_h - ax)[m]
+    got_r, got_e = rf.cpu().numpy(), e1.cpu().numpy()
+    assert np.all(got_r[~m] == 3.0) and np.all(got_e[~m] == 5.0)
+    assert _rel(got_r[m], r_ref) < 1e-7
+    assert _rel(got_e[m], relax * r_ref / w[7]) < 3e-7
+    # last sweep + accumulation: e and r as the float arrays a smoother would hold (zero on the cell boundary)
+    e_h = np.where(m, rng.random(n) - 0.5, 0.0).astype(np.float32)
+    r_h = np.where(m, rng.random(n) - 0.5, 0.0).astype(np.float32)
+    e_d, r_d = torch.from_numpy(e_h).cuda(), torch.from_numpy(r_h).cuda()
+    x0 = x.clone()
+    capi.p1_jacobi_accumulate_f32(x.data_ptr(), r_d.data_ptr(), e_d.data_ptr(), level, w, relax)
+    torch.cuda.synchronize()
+    ae = np.zeros(n)
+    po.apply_cell(ae, e_h.astype(np.float64), level, w)
+    inc_ref = (e_h.astype(np.float64) + relax * (r_h.astype(np.float64) - ae) / w[7])[m]
+    got = x.cpu().numpy()
+    assert np.array_equal(got[~m], x_h[~m])
+    assert _rel((got - x0.cpu().numpy())[m], inc_ref) < F32_TOL
+
+
+def test_fp32_smoothing_phase_is_n_jacobi_sweeps_in_n_launches(env):
+    """MixedPrecisionJacobiSmoother::solveSteps( n ) on a macro-cell with fixed boundary values = n weighted Jacobi sweeps: a V(3,3)
+    cycle with it gives the residual history of the double smoother's cycle to float accuracy of the corrections"""
+    torch, capi, host, po = env
+    from hostutil import MultiCellOracle, upload
+
+    max_level = 6
+    st = host.Storage.from_gmsh(ROOT / "hyteg_amd" / "data" / "meshes" / "tet_1el.msh")
+    mo = MultiCellOracle(st)
+    A = host.P1ConstantOperator(st, 2, max_level)
+    A.compute_inverse_diagonal()
+    hist = {}
+    for smoother in (host.JACOBI, host.JACOBI_FP32):
+        u, b, r = (host.P1Function(st, n_, 2, max_level) for n_ in ("u", "b", "r"))
+        upload(u, mo.interpolate(lambda x, y, z: np.sin(9 * x) * np.cos(4 * y) + z * z, max_level), max_level)
+        u.interpolate(0.0, max_level, host.DirichletBoundary)
+        b.interpolate(0.0, max_level, host.All)
+        gmg = host.Solver.gmg(st, 2, max_level, smoother=smoother, relax=2.0 / 3.0, pre=3, post=3)
+        res = []
+        for _ in range(6):
+            gmg.solve(A, u, b, max_level)
+            A.apply(u, r, max_level, host.Inner)
+            res.append(np.sqrt(r.dot(r, max_level, host.Inner)))
+        hist[smoother] = res
+        for o in (gmg, u, b, r):
+            o.close()
+    f64, f32 = np.array(hist[host.JACOBI]), np.array(hist[host.JACOBI_FP32])
+    assert np.all(np.abs(f32 / f64 - 1.0) < 1e-3), (f32, f64)  # the same iteration, corrections rounded to float
+    assert f32[-1] < 1e-5 * f32[0]
+    for o in (A, st):
+        o.close()

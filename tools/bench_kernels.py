@@ -17,11 +17,54 @@ import torch  # noqa: E402
 from hyteg_amd import capi, host  # noqa: E402
 
 
+def cpu_rows(L, w, rows):
+    """CPU baseline beside the GPU rows: the oracle's restatement of the reference's generated kernels, built with the flags of a
+    HyTeG Release build (oracle/Makefile: -O3 -march=native), one thread as one MPI rank runs them; protocol of
+    apps/benchmarks/KernelBench/3DKernelBench.cpp:59-82 (double the sweeps until a block lasts 0.5 s), bounded to ~2 s per row."""
+    from oracle import p1_oracle as po
+
+    n, nc, inner = po.cell_size(L), po.cell_size(L - 1), po.cell_inner_size(L)
+    rng = np.random.default_rng(1)
+    a, b, c, co = rng.random(n), rng.random(n), rng.random(n), rng.random(nc)
+    ones = np.ones(14)
+    fast = po.lib(fast=True)
+
+    def protocol(fn, budget=2.0):
+        fn()
+        sweeps, total = 1, 0.0
+        while True:
+            t0 = time.perf_counter()
+            for _ in range(sweeps):
+                fn()
+            dt = time.perf_counter() - t0
+            total += dt
+            if dt > 0.5 or total > budget:
+                return dt / sweeps
+            sweeps *= 2
+
+    table = [
+        ("apply Replace", lambda: po.apply_cell(b, a, L, w, fast=True), 16 * inner, inner),
+        ("SOR forward sweep", lambda: po.sor_cell(b, a, L, w, 1.0, False, fast=True), 24 * inner, inner),
+        ("Jacobi composition (apply + 3 vector passes)", lambda: po.jacobi_cell(b, c, a, L, w, 0.66, None, fast=True), 104 * inner, inner),
+        ("restrict (fine L -> coarse L-1)", lambda: fast.ho_restrict_cell(po._p(co), po._p(a), L - 1, po._p(ones)), 8 * (n + nc), nc),
+        ("prolongate (coarse L-1 -> fine L, incl. zeroing)",
+         lambda: (fast.ho_prolongate_prepare(po._p(b), L, 0), fast.ho_prolongate_cell(po._p(co), po._p(b), L - 1, po._p(ones))), 8 * (n + nc), n),
+    ]
+    for name, fn, nbytes, updates in table:
+        s_ = protocol(fn)
+        us = s_ * 1e6
+        rows.append(dict(kernel="CPU 1 core: " + name, us=us, GBps=nbytes / us * 1e-3, GDoFps=updates / us * 1e-3, algorithmic_bytes=nbytes))
+        print(f"{'CPU 1 core: ' + name:58s} {us:12.1f} us  {nbytes / us * 1e-3:8.2f} GB/s  {updates / us * 1e-3:8.3f} GDoF/s", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--level", type=int, default=8)
     ap.add_argument("--reps", type=int, default=200)
     ap.add_argument("--only", default=None, help="time only the kernel rows whose name contains this text (skips the cycles)")
+    ap.add_argument("--cpu", action="store_true",
+                    help="also time the CPU restatement of the reference kernels (oracle/, gcc -O3 -march=native, 1 thread) for apply, "
+                         "SOR, the Jacobi composition, restriction and prolongation (BASELINE.md section 2) -- a reported baseline")
     args = ap.parse_args()
     L, reps = args.level, args.reps
     n, inner = capi.cell_size(L), capi.cell_inner_size(L)
@@ -59,6 +102,8 @@ def main():
                          algorithmic_bytes=bytes_per_call))
         print(f"{name:44s} {us:10.2f} us  {bytes_per_call / us * 1e-3:8.1f} GB/s  {updates / us * 1e-3:8.1f} GDoF/s", flush=True)
 
+    if args.cpu:
+        cpu_rows(L, w, rows)
     p = lambda t, k: t[k % nbuf].data_ptr()  # noqa: E731
     timeit("apply Replace", lambda k: capi.p1_apply_cell(p(B, k), p(A, k), L, w, 0, sh), 16 * inner, inner)
     timeit("apply Add", lambda k: capi.p1_apply_cell(p(B, k), p(A, k), L, w, 1, sh), 24 * inner, inner)
