@@ -105,7 +105,8 @@ def test_conversions_and_mixed_axpy(env):
 def test_multigrid_with_the_fp32_smoother_converges_like_the_fp64_one(env, mesh):
     """V(3,3) cycles with MixedPrecisionJacobiSmoother against the same cycles with the double Jacobi smoother: the
     iterate and the residual are kept in double (defect correction), so the residual keeps falling far below float
-    accuracy, and a cycle is at least as effective as with 3 plain double sweeps (it does more work per step)"""
+    accuracy; on several macro-cells a cycle is at least as effective as with 3 plain double sweeps (it does more work per
+    step), on one macro-cell it is the same iteration"""
     torch, capi, host, po = env
     from hostutil import MultiCellOracle, upload
 
@@ -135,7 +136,12 @@ def test_multigrid_with_the_fp32_smoother_converges_like_the_fp64_one(env, mesh)
     # below float accuracy (6e-8 of the start would be the floor of a pure float iteration; here the float part only
     # computes corrections), still falling in the last cycle, and per cycle not much worse than the double smoother
     # (on several macro-cells the float sweeps are block Jacobi over the cells)
-    assert f32[-1] < 1e-6 * f32[0], (f32, f64)
+    if mesh == "tet_1el":
+        # one macro-cell with fixed boundary values: a smoothing phase IS three Jacobi sweeps (round 3) -- the double smoother's history
+        assert all(abs(a / b_ - 1.0) < 1e-3 for a, b_ in zip(f32, f64)), (f32, f64)
+        assert f32[-1] < 1e-4 * f32[0], (f32, f64)
+    else:
+        assert f32[-1] < 1e-6 * f32[0], (f32, f64)
     assert all(f32[i + 1] < 0.35 * f32[i] for i in range(8)), (f32, f64)
     assert f32[-1] <= 3.0 * f64[-1], (f32, f64)
     for o in (A, st):
