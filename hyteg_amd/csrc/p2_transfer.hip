@@ -17,6 +17,7 @@
 // The tables are built on the host from the micro-cell geometry (six micro-cell types, seven edge orientations) and the
 // shape functions -- nothing is transcribed from the generated kernels.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -342,6 +343,144 @@ __global__ __launch_bounds__( kThreads ) void p2_restrict_kernel( const P2Transf
    *out        = acc;
 }
 
+// ---- round 3: both transfers by ROWS ----------------------------------------------------------------------------------------
+// The thread-per-DoF kernels above spend ~400 instructions per fine DoF on index decoding (cube roots), 64-bit offsets, the class
+// of every touched DoF and table look-ups (level 6 -> 7: 51 us / 76 us = 0.06 / 0.04 of the roofline).  By rows everything that
+// does not depend on x is wave-uniform: a wave owns a run of one row (kind, y, z) -- a TILES_ROWS tile --, the parities of y
+// and z, hence the list of (source kind, offset, weight) terms, are the wave's, the source row bases are scalar arithmetic, and
+// a lane adds its x to them.
+//
+// Prolongation: lane l produces the fine DoFs x = x0 + 2 l and x0 + 2 l + 1 (x0 even): the two parities of x are two passes over
+// wave-uniform term lists, and the coarse values of a term are read at ( x0 >> 1 ) + l + dx -- consecutive lanes, consecutive
+// addresses.
+__device__ inline int row_base32( int N, int kind, int y, int z ) // index of ( 0, y, z ) of `kind` in its (vertex or edge) array
+{
+   const int W = width_of_kind( N, kind );
+   return ( kind == 0 ? 0 : ( kind - 1 ) * (int) tet64( N - 1 ) ) + cell_index( W, 0, y, z );
+}
+__global__ __launch_bounds__( 256 ) void p2_prolongate_rows_kernel( const P2TransferArgs A, const Tile* __restrict__ tiles, int ntiles )
+{
+   const int kind = blockIdx.y;
+   const int t    = __builtin_amdgcn_readfirstlane( (int) ( blockIdx.x * 4 + ( threadIdx.x >> 6 ) ) );
+   if ( t >= ntiles )
+      return;
+   const Tile tl = tiles[t];
+   const int  y = tl.ya, z = tl.z, x0 = tl.yb; // x0 is a multiple of the tile capacity (128): even
+   const int  W = width_of_kind( A.Nf, kind );
+   const int  R = W - z - y; // length of the fine row of this kind (<= 0: the row does not exist for this kind)
+   if ( x0 >= R )
+      return;
+   const int  lane = threadIdx.x & 63;
+   const int  by = y >> 1, bz = z >> 1, bx0 = x0 >> 1;
+   const int  fbase = row_base32( A.Nf, kind, y, z );
+   double*    dst   = kind == 0 ? A.dstV : A.dstE;
+   const bool all   = ( A.mask & HYTEG_HIP_MASK_ALL ) == HYTEG_HIP_MASK_ALL;
+#pragma unroll
+   for ( int px = 0; px < 2; ++px )
+   {
+      const int  x      = x0 + 2 * lane + px;
+      const bool exists = x < R;
+      const int  pat    = kind * 8 + px + 2 * ( y & 1 ) + 4 * ( z & 1 );
+      const int  n      = A.T->nprolong[pat];
+      double     acc    = 0.0;
+      for ( int k = 0; k < n; ++k )
+      {
+         const TEntry e  = A.T->prolong[pat][k]; // wave-uniform
+         const int    kc = e.kind;
+         const int    cb = row_base32( A.Nc, kc, by + e.dy, bz + e.dz ) + bx0 + e.dx;
+         const double* src = kc == 0 ? A.srcV : A.srcE;
+         // every term of an existing fine DoF lies inside the macro-cell; lanes past the row end read entry 0 and store nothing
+         acc = fma( e.w, src[exists ? cb + lane : 0], acc );
+      }
+      if ( exists && ( all || ( ( A.mask >> dof_class( A.Nf, kind, x, y, z ) ) & 1u ) ) )
+      {
+         double* out = dst + fbase + x;
+         *out        = A.update == HYTEG_HIP_ADD ? *out + acc : acc;
+      }
+   }
+}
+
+// Restriction: lane l owns the coarse DoF x = x0 + l of the wave's coarse row; the terms (fine kind, offset, weight) of the coarse
+// kind are wave-uniform, a fine row exists or not for the whole wave, its base is scalar, and the lane reads 2 x + dx in it.
+// The scale 1 / numNeighbourCells of a fine DoF on the macro-cell's boundary depends on x only through "on the face x = 0" and
+// "on the face x + y + z = N - 1": four wave-uniform scales per term, selected per lane.
+__device__ inline double class_scale( const Nnc14& inv, int f0, int f1, int f2, int f3 )
+{
+   const int cls = class_from_flags( f0, f1, f2, f3 );
+   return cls == 14 ? 1.0 : inv.inv[cls];
+}
+__global__ __launch_bounds__( 256 ) void p2_restrict_rows_kernel( const P2TransferArgs A, const Tile* __restrict__ tiles, int ntiles )
+{
+   const int kind = blockIdx.y;
+   const int t    = __builtin_amdgcn_readfirstlane( (int) ( blockIdx.x * 4 + ( threadIdx.x >> 6 ) ) );
+   if ( t >= ntiles )
+      return;
+   const Tile tl = tiles[t];
+   const int  y = tl.ya, z = tl.z, x0 = tl.yb;
+   const int  W = width_of_kind( A.Nc, kind );
+   const int  R = W - z - y;
+   if ( x0 >= R )
+      return;
+   const int  lane   = threadIdx.x & 63;
+   const int  x      = x0 + lane;
+   const bool exists = x < R;
+   const int  n      = A.T->nrestrict[kind];
+   const int  Nf     = A.Nf;
+   double     acc    = 0.0;
+   for ( int k = 0; k < n; ++k )
+   {
+      const TEntry e  = A.T->restrict_[kind][k]; // wave-uniform
+      const int    kf = e.kind;
+      const int    fy = 2 * y + e.dy, fz = 2 * z + e.dz;
+      const int    Wf = width_of_kind( Nf, kf );
+      const int    Rf = Wf - fz - fy; // length of the fine row
+      if ( fy < 0 || fz < 0 || Rf <= 0 )
+         continue; // the whole fine row lies outside the macro-cell
+      const int fb = row_base32( Nf, kf, fy, fz );
+      const int fx = 2 * x + e.dx;
+      // class of the fine DoF: end points p_e = ( fx, fy, fz ) + ends[e] (vertex DoFs: the point itself)
+      int  f0 = 1, f1 = 1, ex0 = 0, ex1 = 0, s0 = 0, s1 = 0;
+      if ( kf == 0 )
+      {
+         f0 = fz == 0, f1 = fy == 0;
+         s0 = s1 = fy + fz;
+      }
+      else
+      {
+         const int( *E )[3] = kEndsDev[kf - 1];
+         f0  = ( fz + E[0][2] == 0 ) && ( fz + E[1][2] == 0 );
+         f1  = ( fy + E[0][1] == 0 ) && ( fy + E[1][1] == 0 );
+         ex0 = E[0][0], ex1 = E[1][0];
+         s0  = fy + fz + E[0][0] + E[0][1] + E[0][2];
+         s1  = fy + fz + E[1][0] + E[1][1] + E[1][2];
+      }
+      const double sc00 = class_scale( A.nncInv, f0, f1, 0, 0 ), sc10 = class_scale( A.nncInv, f0, f1, 1, 0 ),
+                   sc01 = class_scale( A.nncInv, f0, f1, 0, 1 ), sc11 = class_scale( A.nncInv, f0, f1, 1, 1 );
+      const bool in  = exists && fx >= 0 && fx < Rf;
+      const bool f2  = ( fx + ex0 == 0 ) && ( fx + ex1 == 0 );
+      const bool f3  = ( fx + s0 == Nf - 1 ) && ( fx + s1 == Nf - 1 );
+      const double sc = f2 ? ( f3 ? sc11 : sc10 ) : ( f3 ? sc01 : sc00 );
+      const double* src = kf == 0 ? A.srcV : A.srcE;
+      const double  v   = src[in ? fb + fx : fb];
+      acc               = in ? fma( e.w * sc, v, acc ) : acc;
+   }
+   if ( exists && ( ( A.mask >> dof_class( A.Nc, kind, x, y, z ) ) & 1u ) )
+   {
+      double* out = kind == 0 ? A.dstV : A.dstE;
+      out[row_base32( A.Nc, kind, y, z ) + x] = acc;
+   }
+}
+
+// measurement switch: HYTEG_HIP_P2_TRANSFER_THREADS=1 selects the thread-per-DoF kernels of round 2
+inline bool transfer_by_threads()
+{
+   static const bool v = [] {
+      const char* e = std::getenv( "HYTEG_HIP_P2_TRANSFER_THREADS" );
+      return e && e[0] == '1';
+   }();
+   return v;
+}
+
 } // namespace
 
 extern "C" {
@@ -365,6 +504,16 @@ HYTEG_HIP_API int hyteg_hip_p2_prolongate_cell( double*            fine_vertex,
    A.dstV = fine_vertex, A.dstE = fine_edge, A.srcV = coarse_vertex, A.srcE = coarse_edge;
    A.Nc = ( 1 << coarse_level ) + 1, A.Nf = ( 1 << ( coarse_level + 1 ) ) + 1;
    A.update = update, A.mask = mask;
+   if ( !transfer_by_threads() && coarse_level + 1 <= 9 )
+   {
+      TileTable tt;
+      rc = get_tiles( coarse_level + 1, TILES_ROWS, 128, &tt );
+      if ( rc != HYTEG_HIP_OK )
+         return rc;
+      hipLaunchKernelGGL( p2_prolongate_rows_kernel, dim3( (unsigned) ( ( tt.count + 3 ) / 4 ), 8 ), dim3( 256 ), 0, as_stream( stream ), A, tt.dev, tt.count );
+      HH_CHECK_HIP( hipGetLastError() );
+      return HYTEG_HIP_OK;
+   }
    const int64_t most = tet64( A.Nf );
    hipLaunchKernelGGL( p2_prolongate_kernel, dim3( (unsigned) ( ( most + kThreads - 1 ) / kThreads ), 8 ), dim3( kThreads ), 0, as_stream( stream ), A );
    HH_CHECK_HIP( hipGetLastError() );
@@ -393,6 +542,16 @@ HYTEG_HIP_API int hyteg_hip_p2_restrict_cell( double*            coarse_vertex,
    {
       HH_REQUIRE( nnc[k] > 0.0, "p2_restrict_cell: neighbour counts must be positive" );
       A.nncInv.inv[k] = 1.0 / nnc[k];
+   }
+   if ( !transfer_by_threads() && coarse_level + 1 <= 9 )
+   {
+      TileTable tt;
+      rc = get_tiles( coarse_level, TILES_ROWS, 64, &tt );
+      if ( rc != HYTEG_HIP_OK )
+         return rc;
+      hipLaunchKernelGGL( p2_restrict_rows_kernel, dim3( (unsigned) ( ( tt.count + 3 ) / 4 ), 8 ), dim3( 256 ), 0, as_stream( stream ), A, tt.dev, tt.count );
+      HH_CHECK_HIP( hipGetLastError() );
+      return HYTEG_HIP_OK;
    }
    const int64_t most = tet64( A.Nc );
    hipLaunchKernelGGL( p2_restrict_kernel, dim3( (unsigned) ( ( most + kThreads - 1 ) / kThreads ), 8 ), dim3( kThreads ), 0, as_stream( stream ), A );
