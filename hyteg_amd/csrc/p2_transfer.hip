@@ -381,17 +381,25 @@ __global__ __launch_bounds__( 256 ) void p2_prolongate_rows_kernel( const P2Tran
       const int  x      = x0 + 2 * lane + px;
       const bool exists = x < R;
       const int  pat    = kind * 8 + px + 2 * ( y & 1 ) + 4 * ( z & 1 );
-      const int  n      = A.T->nprolong[pat];
-      double     acc    = 0.0;
-      for ( int k = 0; k < n; ++k )
+      // all kMaxProlong terms, unrolled: the entries behind the pattern's last term have weight 0 and offset 0 (a coarse vertex
+      // that exists whenever the fine DoF does), so the ten table entries, ten row bases and ten loads are independent of each
+      // other and in flight together (a loop over the pattern's own term count made every term wait for the previous one's
+      // load: 88 us instead of 51 us for the thread-per-DoF kernel)
+      double v[kMaxProlong], w[kMaxProlong];
+#pragma unroll
+      for ( int k = 0; k < kMaxProlong; ++k )
       {
-         const TEntry e  = A.T->prolong[pat][k]; // wave-uniform
-         const int    kc = e.kind;
-         const int    cb = row_base32( A.Nc, kc, by + e.dy, bz + e.dz ) + bx0 + e.dx;
+         const TEntry  e   = A.T->prolong[pat][k]; // wave-uniform
+         const int     kc  = e.kind;
+         const int     cb  = row_base32( A.Nc, kc, by + e.dy, bz + e.dz ) + bx0 + e.dx;
          const double* src = kc == 0 ? A.srcV : A.srcE;
-         // every term of an existing fine DoF lies inside the macro-cell; lanes past the row end read entry 0 and store nothing
-         acc = fma( e.w, src[exists ? cb + lane : 0], acc );
+         v[k]              = src[exists ? cb + lane : 0]; // lanes past the row end read entry 0 and store nothing
+         w[k]              = e.w;
       }
+      double acc = 0.0;
+#pragma unroll
+      for ( int k = 0; k < kMaxProlong; ++k )
+         acc = fma( w[k], v[k], acc ); // a zero weight adds an exact 0: the bits of the term-count loop
       if ( exists && ( all || ( ( A.mask >> dof_class( A.Nf, kind, x, y, z ) ) & 1u ) ) )
       {
          double* out = dst + fbase + x;
@@ -471,12 +479,17 @@ __global__ __launch_bounds__( 256 ) void p2_restrict_rows_kernel( const P2Transf
    }
 }
 
-// measurement switch: HYTEG_HIP_P2_TRANSFER_THREADS=1 selects the thread-per-DoF kernels of round 2
+// measurement switch: HYTEG_HIP_P2_TRANSFER_ROWS=1 selects the row kernels of round 3 -- correct (tests/test_gpu_p2_transfer.py
+// passes with them) but SLOWER than the thread-per-DoF kernels at level 6 -> 7: prolongation 88 us with a loop over the pattern's
+// term count, 136 us with all ten terms unrolled, against 51 us; restriction 166 us against 77 us.  The row bases of up to
+// 2 x 10 / 125 wave-uniform terms are scalar arithmetic (triangular and tetrahedral numbers, a division by 3 each), and the CU's
+// ONE scalar unit serialises them for all its waves: ~2000 scalar instructions per wave x 80,000 waves.  What would pay is term
+// lists known at compile time (as in the P2 apply), so that the bases become layout algebra with constant offsets.
 inline bool transfer_by_threads()
 {
    static const bool v = [] {
-      const char* e = std::getenv( "HYTEG_HIP_P2_TRANSFER_THREADS" );
-      return e && e[0] == '1';
+      const char* e = std::getenv( "HYTEG_HIP_P2_TRANSFER_ROWS" );
+      return !( e && e[0] == '1' );
    }();
    return v;
 }
