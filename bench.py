@@ -253,29 +253,38 @@ def main():
     copy_ptrs = [[(dsts[k].cell_pointer(c, level), srcs[k].cell_pointer(c, level)) for c in range(storage.n_local_cells)]
                  for k in range(nbuf)]
 
-    def copy_steps(first, count):
-        # the copy floor: the same ring pairs, every cell array read once and written once (nontemporal), same stream
-        for k in range(first, first + count):
-            for d, s_ in copy_ptrs[k % nbuf]:
-                capi.calib_copy(d, s_, n, True, stream.cuda_stream)
+    # the copy floor: the same ring pairs, every cell array read once and written once (nontemporal stores), same stream,
+    # issued by one C loop like the applies
+    if storage.n_local_cells == 1:
+        copy_steps = capi.calib_copy_ring([p[0] for p in copy_ptrs], n, True, stream.cuda_stream)
+    else:
+        def copy_steps(first, count, ev_start=None, ev_stop=None):
+            if ev_start:
+                capi.event_record(ev_start, stream.cuda_stream)
+            for k in range(first, first + count):
+                for d, s_ in copy_ptrs[k % nbuf]:
+                    capi.calib_copy(d, s_, n, True, stream.cuda_stream)
+            if ev_stop:
+                capi.event_record(ev_stop, stream.cuda_stream)
+
+    ev0, ev1 = capi.event_create_timing(), capi.event_create_timing()
 
     def region(fn):
         """EXACTLY K steps between barrier + synchronize on both sides (wall clock) and between two HIP events recorded on
-        the launch stream (device time)"""
+        the launch stream by the C loop that issues the K steps, directly before the first and after the last launch (device
+        time; an event recorded from Python sits 5-8 us of interpreter time in front of the first launch, which a K = 20
+        region of an otherwise idle GPU sees as 0.3 us per step: profiles/r03_k20_probe.txt)"""
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        ev0.record(stream)
-        fn(0, args.steps)
-        ev1.record(stream)
+        fn(0, args.steps, ev0, ev1)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        return time.perf_counter() - t0, ev0.elapsed_time(ev1)
+        return time.perf_counter() - t0, capi.event_elapsed_ms(ev0, ev1)
 
     def measure():
         # untimed: every ring pair is touched (twice) whatever --warmup says, so that no first access (page tables, TLB) of a

@@ -27,10 +27,13 @@ SIGNATURES = {
     "hyteg_hip_download": (_i, [_vp, _vp, _sz, _vp]),
     "hyteg_hip_copy": (_i, [_vp, _vp, _sz, _vp]),
     "hyteg_hip_calib_copy": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "hyteg_hip_calib_copy_ring": (_i, [C.POINTER(_vp), C.POINTER(_vp), _i, _i64, _i, _i, _i, _vp, _vp, _vp]),
     "hyteg_hip_stream_create": (_i, [C.POINTER(_vp)]),
     "hyteg_hip_stream_destroy": (_i, [_vp]),
     "hyteg_hip_stream_synchronize": (_i, [_vp]),
     "hyteg_hip_event_create": (_i, [C.POINTER(_vp)]),
+    "hyteg_hip_event_create_timing": (_i, [C.POINTER(_vp)]),
+    "hyteg_hip_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
     "hyteg_hip_event_destroy": (_i, [_vp]),
     "hyteg_hip_event_record": (_i, [_vp, _vp]),
     "hyteg_hip_stream_wait_event": (_i, [_vp, _vp]),
@@ -241,6 +244,19 @@ def event_create() -> int:
     return h.value
 
 
+def event_create_timing() -> int:
+    h = _vp()
+    check(lib().hyteg_hip_event_create_timing(C.byref(h)), "event_create_timing")
+    return h.value
+
+
+def event_elapsed_ms(start, stop) -> float:
+    """waits for `stop`; device time between the two timing events"""
+    ms = C.c_float()
+    check(lib().hyteg_hip_event_elapsed_ms(start, stop, C.byref(ms)), "event_elapsed_ms")
+    return float(ms.value)
+
+
 def event_destroy(ev) -> None:
     check(lib().hyteg_hip_event_destroy(ev), "event_destroy")
 
@@ -256,6 +272,19 @@ def stream_wait_event(stream, ev) -> None:
 def calib_copy(dst, src, n, nontemporal=True, stream=0) -> None:
     """streaming copy of n doubles (calibration of the practical bandwidth floor; bench.py roofline.copy_us)"""
     check(lib().hyteg_hip_calib_copy(dst, src, n, 1 if nontemporal else 0, stream), "calib_copy")
+
+
+def calib_copy_ring(pairs, n, nontemporal=True, stream=0):
+    """returns call(first, count, ev_start=None, ev_stop=None): `count` calib copies, copy k on pairs[(first + k) % len(pairs)]
+    (pairs of (dst, src) device pointers), issued by one C loop between the two optional timing events"""
+    m = len(pairs)
+    d, s = (_vp * m)(*[p[0] for p in pairs]), (_vp * m)(*[p[1] for p in pairs])
+    fn = lib().hyteg_hip_calib_copy_ring
+
+    def call(first, count, ev_start=None, ev_stop=None):
+        check(fn(d, s, m, n, 1 if nontemporal else 0, first, count, stream, ev_start, ev_stop), "calib_copy_ring")
+
+    return call
 
 
 def p1_residual_jacobi_start_f32(r_f32, e_f32, rhs, src, level, w, relax, stream=0):

@@ -133,6 +133,23 @@ HYTEG_HIP_API int hyteg_hip_event_create( hyteg_hip_event_t* event )
    return HYTEG_HIP_OK;
 }
 
+HYTEG_HIP_API int hyteg_hip_event_create_timing( hyteg_hip_event_t* event )
+{
+   HH_REQUIRE( event != nullptr, "event_create_timing: null out pointer" );
+   hipEvent_t e;
+   HH_CHECK_HIP( hipEventCreate( &e ) );
+   *event = reinterpret_cast< hyteg_hip_event_t >( e );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_event_elapsed_ms( hyteg_hip_event_t start, hyteg_hip_event_t stop, float* ms )
+{
+   HH_REQUIRE( start && stop && ms, "event_elapsed_ms: null argument" );
+   HH_CHECK_HIP( hipEventSynchronize( reinterpret_cast< hipEvent_t >( stop ) ) );
+   HH_CHECK_HIP( hipEventElapsedTime( ms, reinterpret_cast< hipEvent_t >( start ), reinterpret_cast< hipEvent_t >( stop ) ) );
+   return HYTEG_HIP_OK;
+}
+
 HYTEG_HIP_API int hyteg_hip_event_destroy( hyteg_hip_event_t event )
 {
    HH_CHECK_HIP( hipEventDestroy( reinterpret_cast< hipEvent_t >( event ) ) );

@@ -388,6 +388,23 @@ HYTEG_HIP_API int hyteg_hip_calib_copy( double* dst, const double* src, int64_t 
    return HYTEG_HIP_OK;
 }
 
+HYTEG_HIP_API int hyteg_hip_calib_copy_ring( double* const* dsts, const double* const* srcs, int npairs, int64_t n, int nontemporal, int first,
+                                             int count, hyteg_hip_stream_t stream, hyteg_hip_event_t start, hyteg_hip_event_t stop )
+{
+   HH_REQUIRE( dsts && srcs && npairs > 0 && count >= 0 && first >= 0, "calib_copy_ring: bad ring" );
+   if ( start )
+      HH_CHECK_HIP( hipEventRecord( reinterpret_cast< hipEvent_t >( start ), as_stream( stream ) ) );
+   for ( int k = first; k < first + count; ++k )
+   {
+      const int rc = hyteg_hip_calib_copy( dsts[k % npairs], srcs[k % npairs], n, nontemporal, stream );
+      if ( rc != HYTEG_HIP_OK )
+         return rc;
+   }
+   if ( stop )
+      HH_CHECK_HIP( hipEventRecord( reinterpret_cast< hipEvent_t >( stop ), as_stream( stream ) ) );
+   return HYTEG_HIP_OK;
+}
+
 // ---- layout ---------------------------------------------------------------------------------------
 HYTEG_HIP_API int64_t hyteg_hip_cell_width( int level ) { return ( (int64_t) 1 << level ) + 1; }
 HYTEG_HIP_API int64_t hyteg_hip_cell_size( int level ) { return tet64( hyteg_hip_cell_width( level ) ); }

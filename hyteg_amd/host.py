@@ -82,6 +82,7 @@ SIGNATURES = {
     "hyteg_host_operator_stencils": (_i, [_vp, _i, _i, _dp, _dp]),
     "hyteg_host_operator_apply": (_i, [_vp, _vp, _vp, _i, _i, _i]),
     "hyteg_host_operator_apply_cycle": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i]),
+    "hyteg_host_operator_apply_cycle_timed": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _vp]),
     "hyteg_host_operator_smooth_jac": (_i, [_vp, _vp, _vp, _vp, _d, _i, _i]),
     "hyteg_host_operator_smooth_sor": (_i, [_vp, _vp, _vp, _d, _i, _i, _i]),
     "hyteg_host_operator_compute_inverse_diagonal": (_i, [_vp]),
@@ -434,13 +435,18 @@ class P1ConstantOperator:
         self.prepared_cycle(srcs, dsts, level, flag, update)(first, steps)
 
     def prepared_cycle(self, srcs, dsts, level, flag, update=Replace):
-        """apply_cycle with the handle arrays built once: returns call(first, steps)"""
+        """apply_cycle with the handle arrays built once: returns call(first, steps, ev_start=None, ev_stop=None); the two
+        optional timing events of the C-ABI (capi.event_create_timing) are recorded on the storage's stream directly before
+        the first and after the last apply"""
         n = len(srcs)
         hs, hd = (_vp * n)(*[f.h for f in srcs]), (_vp * n)(*[f.h for f in dsts])
-        fn, h = lib().hyteg_host_operator_apply_cycle, self.h
+        fn, fnt, h = lib().hyteg_host_operator_apply_cycle, lib().hyteg_host_operator_apply_cycle_timed, self.h
 
-        def call(first, steps):
-            _ck(fn(h, n, hs, hd, level, flag, update, first, steps), "apply_cycle")
+        def call(first, steps, ev_start=None, ev_stop=None):
+            if ev_start is None and ev_stop is None:
+                _ck(fn(h, n, hs, hd, level, flag, update, first, steps), "apply_cycle")
+            else:
+                _ck(fnt(h, n, hs, hd, level, flag, update, first, steps, ev_start, ev_stop), "apply_cycle_timed")
 
         return call
 

@@ -410,6 +410,26 @@ HYTEG_HOST_API int hyteg_host_operator_apply_cycle( hh_operator_t op, int npairs
       }
    } );
 }
+HYTEG_HOST_API int hyteg_host_operator_apply_cycle_timed( hh_operator_t op, int npairs, const hh_function_t* srcs, const hh_function_t* dsts,
+                                                          int level, int flag, int update, int first, int steps, void* evStart, void* evStop )
+{
+   // the same loop between two timing events of the C-ABI, recorded on the storage's stream directly before the first and after
+   // the last apply (a measurement harness's bracket without its own call overhead inside)
+   return guarded( [&] {
+      if ( steps <= 0 || npairs <= 0 )
+         return;
+      hyteg_hip_stream_t stream = F( srcs[0] ).getStorage()->stream();
+      if ( evStart )
+         hipCheck( hyteg_hip_event_record( evStart, stream ), "apply_cycle_timed: record" );
+      for ( int k = 0; k < steps; ++k )
+      {
+         const int j = ( first + k ) % npairs;
+         WITH_OP( op, A.apply( F( srcs[j] ), F( dsts[j] ), (uint_t) level, DoFType( flag ), update ? Add : Replace ) );
+      }
+      if ( evStop )
+         hipCheck( hyteg_hip_event_record( evStop, stream ), "apply_cycle_timed: record" );
+   } );
+}
 HYTEG_HOST_API int hyteg_host_operator_smooth_jac( hh_operator_t op, hh_function_t dst, hh_function_t rhs, hh_function_t src, double relax, int level, int flag )
 {
    return guarded( [&] { WITH_OP( op, A.smooth_jac( F( dst ), F( rhs ), F( src ), relax, (uint_t) level, DoFType( flag ) ) ); } );

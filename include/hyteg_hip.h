@@ -91,6 +91,11 @@ HYTEG_HIP_API int hyteg_hip_copy( void* dev_dst, const void* dev_src, size_t byt
  * counterpart (the reference's counterpart of this measurement is the STREAM table of its kerncraft machine files,
  * data/kerncraftMachineFiles/SkylakeSP_Platinum-8147_2.7GHz.yml:412-420). */
 HYTEG_HIP_API int hyteg_hip_calib_copy( double* dst, const double* src, int64_t n, int nontemporal, hyteg_hip_stream_t stream );
+/* `count` such copies, copy k on pair (first + k) % npairs, between two timing events (hyteg_hip_event_create_timing; NULL =
+ * none) recorded on `stream` directly before the first and after the last launch. */
+typedef void* hyteg_hip_event_t;
+HYTEG_HIP_API int hyteg_hip_calib_copy_ring( double* const* dsts, const double* const* srcs, int npairs, int64_t n, int nontemporal, int first,
+                                             int count, hyteg_hip_stream_t stream, hyteg_hip_event_t start, hyteg_hip_event_t stop );
 HYTEG_HIP_API int hyteg_hip_stream_create( hyteg_hip_stream_t* stream );
 HYTEG_HIP_API int hyteg_hip_stream_destroy( hyteg_hip_stream_t stream );
 HYTEG_HIP_API int hyteg_hip_stream_synchronize( hyteg_hip_stream_t stream );
@@ -775,8 +780,10 @@ HYTEG_HIP_API int hyteg_hip_p2_restrict_cell( double*            coarse_vertex,
  * pairs (one per peer rank) enqueued on `stream`, no host synchronisation, no staging; the caller orders it against its
  * pack / reduce kernels with events.  librccl is resolved at run time (a copy the process already holds -- PyTorch
  * ships and loads its own -- is reused; HYTEG_HIP_RCCL_LIB overrides the search). */
-typedef void* hyteg_hip_event_t;
 HYTEG_HIP_API int hyteg_hip_event_create( hyteg_hip_event_t* event );
+/* events that carry a device timestamp: elapsed_ms waits for `stop` and returns the time between the two (hipEventElapsedTime) */
+HYTEG_HIP_API int hyteg_hip_event_create_timing( hyteg_hip_event_t* event );
+HYTEG_HIP_API int hyteg_hip_event_elapsed_ms( hyteg_hip_event_t start, hyteg_hip_event_t stop, float* ms );
 HYTEG_HIP_API int hyteg_hip_event_destroy( hyteg_hip_event_t event );
 HYTEG_HIP_API int hyteg_hip_event_record( hyteg_hip_event_t event, hyteg_hip_stream_t stream );
 HYTEG_HIP_API int hyteg_hip_stream_wait_event( hyteg_hip_stream_t stream, hyteg_hip_event_t event );

@@ -123,6 +123,10 @@ HYTEG_HOST_API int hyteg_host_operator_apply( hh_operator_t op, hh_function_t sr
  * lets a non-C++ driver time K applies without paying its own per-call overhead K times. */
 HYTEG_HOST_API int hyteg_host_operator_apply_cycle( hh_operator_t op, int npairs, const hh_function_t* srcs, const hh_function_t* dsts,
                                                     int level, int flag, int update, int first, int steps );
+/* the same loop between two timing events of the C-ABI (hyteg_hip_event_create_timing; NULL = none), recorded on the storage's
+ * stream directly before the first and after the last apply: the device time of exactly these `steps` applies */
+HYTEG_HOST_API int hyteg_host_operator_apply_cycle_timed( hh_operator_t op, int npairs, const hh_function_t* srcs, const hh_function_t* dsts,
+                                                          int level, int flag, int update, int first, int steps, void* ev_start, void* ev_stop );
 HYTEG_HOST_API int hyteg_host_operator_smooth_jac( hh_operator_t op, hh_function_t dst, hh_function_t rhs, hh_function_t src, double relax, int level, int flag );
 HYTEG_HOST_API int hyteg_host_operator_smooth_sor( hh_operator_t op, hh_function_t dst, hh_function_t rhs, double relax, int level, int flag, int backwards );
 HYTEG_HOST_API int hyteg_host_operator_compute_inverse_diagonal( hh_operator_t op );
