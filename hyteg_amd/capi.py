@@ -27,6 +27,9 @@ SIGNATURES = {
     "hyteg_hip_download": (_i, [_vp, _vp, _sz, _vp]),
     "hyteg_hip_copy": (_i, [_vp, _vp, _sz, _vp]),
     "hyteg_hip_calib_copy": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "hyteg_hip_p2_operator_table_closure_split": (_i, [_vp, _vp, _vp, _vp]),
+    "hyteg_hip_p2_operator_table_face_edge_weights": (_i, [_vp, C.POINTER(_i), _vp]),
+    "hyteg_hip_p2_sor_face_edgedofs_cell": (_i, [_vp, _vp, _i, C.POINTER(_i), _vp, _d, C.c_uint, _i, _vp]),
     "hyteg_hip_calib_copy_ring": (_i, [C.POINTER(_vp), C.POINTER(_vp), _i, _i64, _i, _i, _i, _vp, _vp, _vp]),
     "hyteg_hip_stream_create": (_i, [C.POINTER(_vp)]),
     "hyteg_hip_stream_destroy": (_i, [_vp]),
@@ -644,6 +647,32 @@ def p2_build_operator_table_from_stencils(inner, classes=None):
     out = (C.c_double * n)()
     check(lib().hyteg_hip_p2_build_operator_table_from_stencils(a, b, out), "p2_build_operator_table_from_stencils")
     return list(out)
+
+
+def p2_operator_table_closure_split(table):
+    """-> (outside, closure_vertex, closure_edge): the boundary-class rows of an operator table split by where the source lies"""
+    n = int(lib().hyteg_hip_p2_operator_table_size())
+    t = (C.c_double * n)(*[float(x) for x in table])
+    o, v, e = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+    check(lib().hyteg_hip_p2_operator_table_closure_split(t, o, v, e), "p2_operator_table_closure_split")
+    return list(o), list(v), list(e)
+
+
+def p2_operator_table_face_edge_weights(table, face_verts):
+    """-> [3][5]: this cell's share of the couplings between the edge DoFs inside a macro-face, in the face's frame"""
+    n = int(lib().hyteg_hip_p2_operator_table_size())
+    t = (C.c_double * n)(*[float(x) for x in table])
+    fv = (C.c_int * 3)(*[int(x) for x in face_verts])
+    w = (C.c_double * 15)()
+    check(lib().hyteg_hip_p2_operator_table_face_edge_weights(t, fv, w), "p2_operator_table_face_edge_weights")
+    return [list(w[5 * k:5 * k + 5]) for k in range(3)]
+
+
+def p2_sor_face_edgedofs_cell(dst_edge, q_edge, level, face_verts, face_w, relax, mask, backwards=False, stream=0):
+    fv = (C.c_int * 12)(*[int(x) for f in face_verts for x in f])
+    fw = (C.c_double * 60)(*[float(x) for f in face_w for t in f for x in t])
+    check(lib().hyteg_hip_p2_sor_face_edgedofs_cell(dst_edge, q_edge, level, fv, fw, float(relax), mask, 1 if backwards else 0, stream),
+          "p2_sor_face_edgedofs_cell")
 
 
 def _edge_blocks(base, level):

@@ -1718,4 +1718,259 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell_kinds( double*            
    return HYTEG_HIP_OK;
 }
 
+
+// ---- Gauss-Seidel / SOR on the macro-edges and macro-faces shared between macro-cells, in the reference's order ------------------
+// P2ConstantOperator::smooth_sor (src/constant_stencil_operator/P2ConstantOperator.cpp:1267-1330) sweeps macro-vertices, -edges,
+// -faces, -cells one class after the other; a primitive's sweep sees current values on itself and its boundary and ghost-layer
+// values for everything else.  Cell-centric form (as for P1, p1_sor_shell.hip): the ghost-layer part of every row is ONE apply
+// with the operator table whose weights for sources ON the primitive's closure are zeroed (summed over the cells by the additive
+// exchange); the closure part is evaluated with the complementary tables, and the only sequential piece -- the edge DoFs inside
+// a macro-face, which couple with each other -- is swept on every cell's copy with the total weights by the kernel below.
+} // extern "C"
+namespace {
+// faces of the cell (bit g; 0: z = 0, 1: y = 0, 2: x = 0, 3: x + y + z = n) that contain the macro-primitive of point class cls
+int class_face_flags( int cls )
+{
+   static const int edges[6] = { 0x3, 0x5, 0x9, 0x6, 0xA, 0xC }, verts[4] = { 0x7, 0xB, 0xD, 0xE };
+   return cls < 6 ? edges[cls] : ( cls < 10 ? 1 << ( cls - 6 ) : verts[cls - 10] );
+}
+int plane_fn( int g, const int* p ) { return g == 0 ? p[2] : ( g == 1 ? p[1] : ( g == 2 ? p[0] : -( p[0] + p[1] + p[2] ) ) ); }
+// the micro-vertices a DoF of a kind sits on, relative to its logical index (vertex DoF: one; edge DoF: its two end points)
+int kind_points( int kind, int pts[2][3] )
+{
+   static const int ends[7][2][3] = { { { 0, 0, 0 }, { 1, 0, 0 } }, { { 0, 0, 0 }, { 0, 1, 0 } }, { { 0, 0, 0 }, { 0, 0, 1 } },
+                                      { { 1, 0, 0 }, { 0, 1, 0 } }, { { 1, 0, 0 }, { 0, 0, 1 } }, { { 0, 1, 0 }, { 0, 0, 1 } },
+                                      { { 0, 1, 0 }, { 1, 0, 1 } } };
+   if ( kind == 0 )
+   {
+      pts[0][0] = pts[0][1] = pts[0][2] = 0;
+      return 1;
+   }
+   for ( int e = 0; e < 2; ++e )
+      for ( int r = 0; r < 3; ++r )
+         pts[e][r] = ends[kind - 1][e][r];
+   return 2;
+}
+// does the source DoF (kind K at offset d from a destination DoF of kind C and point class cls) lie on the closure of the
+// destination's macro-primitive, i.e. on every cell face that contains it?  A question about offsets only.
+bool source_on_closure( int C, int cls, int K, int dx, int dy, int dz )
+{
+   int       pd[2][3], ps[2][3];
+   const int nd = kind_points( C, pd ), ns = kind_points( K, ps ), flags = class_face_flags( cls );
+   for ( int g = 0; g < 4; ++g )
+   {
+      if ( !( ( flags >> g ) & 1 ) )
+         continue;
+      const int h = plane_fn( g, pd[0] );
+      for ( int e = 1; e < nd; ++e )
+         if ( plane_fn( g, pd[e] ) != h )
+            return false; // a DoF of this kind cannot lie on that face at all: the class row is never used
+      for ( int e = 0; e < ns; ++e )
+      {
+         const int q[3] = { dx + ps[e][0], dy + ps[e][1], dz + ps[e][2] };
+         if ( plane_fn( g, q ) != h )
+            return false;
+      }
+   }
+   return true;
+}
+
+// a macro-face in the cell's index space: its vertices in the order of their global ids are the cell-local vertices l0, l1, l2;
+// micro-vertex (i, j) of the face = O + i a + j b; edge DoF types of the face: X (i,j)-(i+1,j), XY (i+1,j)-(i,j+1), Y (i,j)-(i,j+1)
+struct P2FaceFrame
+{
+   int    O[3], a[3], b[3]; // O is filled per level (n * unit vector of l0)
+   int    kind[3];          // cell edge-DoF kind (1..6) of the face types X, XY, Y
+   int    off[3][3];        // logical index of face edge (t, i, j) in the cell = O + i a + j b + off[t]
+   double w[3][5];          // diagonal, then the four in-face neighbours of kFaceNb
+};
+// in-face neighbours of an edge DoF: (type, di, dj), the other edges of the two face triangles that share it
+const int kFaceNbHost[3][4][3] = { { { 1, 0, 0 }, { 2, 0, 0 }, { 1, 0, -1 }, { 2, 1, -1 } },
+                                   { { 0, 0, 0 }, { 2, 0, 0 }, { 0, 0, 1 }, { 2, 1, 0 } },
+                                   { { 0, 0, 0 }, { 1, 0, 0 }, { 0, -1, 1 }, { 1, -1, 0 } } };
+__constant__ int kFaceNb[3][4][3] = { { { 1, 0, 0 }, { 2, 0, 0 }, { 1, 0, -1 }, { 2, 1, -1 } },
+                                      { { 0, 0, 0 }, { 2, 0, 0 }, { 0, 0, 1 }, { 2, 1, 0 } },
+                                      { { 0, 0, 0 }, { 1, 0, 0 }, { 0, -1, 1 }, { 1, -1, 0 } } };
+bool face_frame( const int lv[3], P2FaceFrame& F, int& faceClass )
+{
+   static const int unit[4][3] = { { 0, 0, 0 }, { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } };
+   static const int dirs[6][3] = { { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 }, { -1, 1, 0 }, { -1, 0, 1 }, { 0, -1, 1 } };
+   static const int e0[6][3]   = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 1, 0, 0 }, { 1, 0, 0 }, { 0, 1, 0 } };
+   for ( int k = 0; k < 3; ++k )
+      if ( lv[k] < 0 || lv[k] > 3 )
+         return false;
+   if ( lv[0] == lv[1] || lv[0] == lv[2] || lv[1] == lv[2] )
+      return false;
+   const int missing = 6 - lv[0] - lv[1] - lv[2];
+   faceClass         = 6 + ( missing == 3 ? 0 : ( missing == 2 ? 1 : ( missing == 1 ? 2 : 3 ) ) );
+   for ( int r = 0; r < 3; ++r )
+   {
+      F.O[r] = unit[lv[0]][r]; // scaled by n by the caller
+      F.a[r] = unit[lv[1]][r] - unit[lv[0]][r];
+      F.b[r] = unit[lv[2]][r] - unit[lv[0]][r];
+   }
+   for ( int t = 0; t < 3; ++t )
+   {
+      int D[3], S[3]; // direction and start point (relative to micro-vertex (i, j)) of face type t
+      for ( int r = 0; r < 3; ++r )
+      {
+         D[r] = t == 0 ? F.a[r] : ( t == 1 ? F.b[r] - F.a[r] : F.b[r] );
+         S[r] = t == 1 ? F.a[r] : 0;
+      }
+      F.kind[t] = 0;
+      for ( int k = 0; k < 6; ++k )
+      {
+         const bool plus  = D[0] == dirs[k][0] && D[1] == dirs[k][1] && D[2] == dirs[k][2];
+         const bool minus = D[0] == -dirs[k][0] && D[1] == -dirs[k][1] && D[2] == -dirs[k][2];
+         if ( !plus && !minus )
+            continue;
+         F.kind[t] = k + 1;
+         for ( int r = 0; r < 3; ++r )
+            F.off[t][r] = ( plus ? S[r] : S[r] + D[r] ) - e0[k][r];
+      }
+      if ( F.kind[t] == 0 )
+         return false;
+   }
+   return true;
+}
+
+struct P2FaceSorArgs
+{
+   double*       u;
+   const double* q;
+   P2FaceFrame   F[4];
+   unsigned      mask;
+   int           N, backwards;
+   double        relax;
+};
+__device__ inline int64_t face_edge_index( const P2FaceFrame& F, int n, int t, int i, int j )
+{
+   const int x = F.O[0] + i * F.a[0] + j * F.b[0] + F.off[t][0], y = F.O[1] + i * F.a[1] + j * F.b[1] + F.off[t][1],
+             z = F.O[2] + i * F.a[2] + j * F.b[2] + F.off[t][2];
+   return edge_block_start( n, F.kind[t] ) + cell_index( n, x, y, z );
+}
+// P2::macroface::generated::sor_3D_macroface_P2_update_edgedofs[_backwards] on this cell's copy of the face: rows ascending, x
+// ascending, at every index X, XY, Y in place (backwards: everything reversed).  The order only matters between coupled DoFs,
+// and the stage 3 ( x + 2 y ) + type puts every DoF after the neighbours the loop visits before it and before the others: one
+// workgroup per face walks the stages, all DoFs of a stage at once.
+__global__ __launch_bounds__( 256 ) void p2_sor_face_edges_kernel( const P2FaceSorArgs A )
+{
+   const int f = blockIdx.x;
+   if ( !( ( A.mask >> ( 6 + f ) ) & 1u ) )
+      return;
+   const P2FaceFrame& F = A.F[f];
+   const int          n = A.N - 1, stages = 3 * ( 2 * n - 1 );
+   for ( int step = 0; step < stages; ++step )
+   {
+      const int s = A.backwards ? stages - 1 - step : step;
+      const int t = s % 3, qq = s / 3;
+      const int ylo = qq - n + 1 > 0 ? qq - n + 1 : 0, yhi = qq / 2;
+      for ( int y = ylo + (int) threadIdx.x; y <= yhi; y += (int) blockDim.x )
+      {
+         const int  x     = qq - 2 * y;
+         const bool inner = t == 0 ? y >= 1 : ( t == 1 ? x + y <= n - 2 : x >= 1 );
+         if ( !inner || x + y > n - 1 )
+            continue;
+         const int64_t i   = face_edge_index( F, n, t, x, y );
+         double        sum = A.q[i];
+#pragma unroll
+         for ( int k = 0; k < 4; ++k )
+            sum -= F.w[t][1 + k] * A.u[face_edge_index( F, n, kFaceNb[t][k][0], x + kFaceNb[t][k][1], y + kFaceNb[t][k][2] )];
+         A.u[i] = ( 1.0 - A.relax ) * A.u[i] + A.relax / F.w[t][0] * sum;
+      }
+      __syncthreads();
+   }
+}
+} // namespace
+extern "C" {
+
+HYTEG_HIP_API int hyteg_hip_p2_operator_table_closure_split( const double* table_host, double* outside, double* closure_vertex, double* closure_edge )
+{
+   HH_REQUIRE( table_host && outside && closure_vertex && closure_edge, "p2_operator_table_closure_split: null pointer" );
+   for ( int k = 0; k < kOperatorTableSize; ++k )
+      outside[k] = closure_vertex[k] = closure_edge[k] = 0.0;
+   for ( int c = 0; c < 8; ++c )
+   {
+      const KindStencil S = build_kind_stencil( c );
+      for ( int cls = 0; cls < 14; ++cls )
+         for ( int q = 0; q < S.n; ++q )
+         {
+            const int    at = class_offset( c ) + cls * S.n + q;
+            const double w  = table_host[at];
+            if ( source_on_closure( c, cls, S.kind[q], S.dx[q], S.dy[q], S.dz[q] ) )
+               ( S.kind[q] == 0 ? closure_vertex : closure_edge )[at] = w;
+            else
+               outside[at] = w;
+         }
+   }
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_p2_operator_table_face_edge_weights( const double* table_host, const int* face_verts, double* w )
+{
+   HH_REQUIRE( table_host && face_verts && w, "p2_operator_table_face_edge_weights: null pointer" );
+   P2FaceFrame F;
+   int         cls = 0;
+   HH_REQUIRE( face_frame( face_verts, F, cls ), "p2_operator_table_face_edge_weights: face_verts must be three different cell-local vertex ids" );
+   for ( int t = 0; t < 3; ++t )
+   {
+      const KindStencil S = build_kind_stencil( F.kind[t] );
+      for ( int k = 0; k < 5; ++k )
+      {
+         int kind = F.kind[t], d[3] = { 0, 0, 0 };
+         if ( k > 0 )
+         {
+            const int* nb = kFaceNbHost[t][k - 1];
+            kind          = F.kind[nb[0]];
+            for ( int r = 0; r < 3; ++r )
+               d[r] = nb[1] * F.a[r] + nb[2] * F.b[r] + F.off[nb[0]][r] - F.off[t][r];
+         }
+         double v = 0.0;
+         bool   found = false;
+         for ( int q = 0; q < S.n && !found; ++q )
+            if ( S.kind[q] == kind && S.dx[q] == d[0] && S.dy[q] == d[1] && S.dz[q] == d[2] )
+               v = table_host[class_offset( F.kind[t] ) + ( cls - 0 ) * S.n + q], found = true;
+         HH_REQUIRE( found, "p2_operator_table_face_edge_weights: a face neighbour is not in the stencil list (internal error)" );
+         w[5 * t + k] = v;
+      }
+   }
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API int hyteg_hip_p2_sor_face_edgedofs_cell( double* dst_edge, const double* q_edge, int level, const int* face_verts, const double* face_w,
+                                                       double relax, unsigned mask, int backwards, hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( dst_edge && q_edge && face_verts && face_w, "p2_sor_face_edgedofs_cell: null pointer" );
+   HH_REQUIRE( level >= 2 && level <= HYTEG_HIP_P2_MAX_LEVEL, "p2_sor_face_edgedofs_cell: level out of range (2..9)" );
+   HH_REQUIRE( dst_edge != q_edge, "p2_sor_face_edgedofs_cell: dst and q must differ" );
+   mask &= 0xFu << 6;
+   if ( mask == 0 )
+      return HYTEG_HIP_OK;
+   P2FaceSorArgs A;
+   A.u = dst_edge, A.q = q_edge, A.mask = mask, A.N = ( 1 << level ) + 1, A.backwards = backwards ? 1 : 0, A.relax = relax;
+   const int n = A.N - 1;
+   for ( int f = 0; f < 4; ++f )
+   {
+      int cls = 0;
+      if ( !( ( mask >> ( 6 + f ) ) & 1u ) )
+      {
+         A.F[f] = P2FaceFrame{};
+         continue;
+      }
+      HH_REQUIRE( face_frame( face_verts + 3 * f, A.F[f], cls ) && cls == 6 + f,
+                  "p2_sor_face_edgedofs_cell: face_verts[f] must be the three cell-local vertex ids of face f" );
+      for ( int r = 0; r < 3; ++r )
+         A.F[f].O[r] *= n;
+      for ( int t = 0; t < 3; ++t )
+      {
+         HH_REQUIRE( face_w[15 * f + 5 * t] != 0.0, "p2_sor_face_edgedofs_cell: zero diagonal weight" );
+         for ( int k = 0; k < 5; ++k )
+            A.F[f].w[t][k] = face_w[15 * f + 5 * t + k];
+      }
+   }
+   hipLaunchKernelGGL( p2_sor_face_edges_kernel, dim3( 4 ), dim3( 256 ), 0, as_stream( stream ), A );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
 } // extern "C"

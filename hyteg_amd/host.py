@@ -768,6 +768,9 @@ class P2ElementwiseLaplaceOperator:
     def smooth_sor(self, dst: "P2Function", rhs: "P2Function", relax, level, flag=Inner | NeumannBoundary, backwards=False):
         _ck(lib().hyteg_host_p2operator_smooth_sor(self.h, dst.h, rhs.h, float(relax), level, flag, int(bool(backwards))), "P2 smooth_sor")
 
+    def smooth_gs(self, dst: "P2Function", rhs: "P2Function", level, flag=Inner | NeumannBoundary):
+        self.smooth_sor(dst, rhs, 1.0, level, flag)
+
     def cg_solve(self, x: P2Function, b: P2Function, level, max_iter=1000, tol=1e-14):
         it = _i()
         _ck(lib().hyteg_host_p2_cg_solve(self.storage.h, self.h, x.h, b.h, level, max_iter, float(tol), C.byref(it)), "P2 CG")

@@ -240,26 +240,7 @@ class P1ConstantOperator
          throw std::runtime_error( "smooth_sor: dst and rhs must differ" );
       bool anyShell = false;
       forCells( [&]( uint_t, const MacroCell& cell ) { anyShell = anyShell || ( storage_->maskFor( cell, flag ) & HYTEG_HIP_MASK_SHELL ); } );
-      auto sweepCells = [&]() {
-         if ( storage_->useBatchSor( level ) )
-         {
-            const auto masks = storage_->masksFor( flag );
-            storage_->forCellChunks( [&]( int first, int count ) {
-               const auto u = dst.cellPointers( level, first, count ), r = rhs.cellPointers( level, first, count );
-               hipCheck( hyteg_hip_p1_sor_cells( count, u.data(), r.data(), (int) level, stencilTable( level ) + (size_t) first * 225, relax,
-                                                 backwards ? 1 : 0, masks.data() + first, storage_->stream() ),
-                         "smooth_sor: cells (batched)" );
-            } );
-            return;
-         }
-         forCells( [&]( uint_t c, const MacroCell& cell ) {
-            const unsigned mask = storage_->maskFor( cell, flag );
-            if ( ( mask & HYTEG_HIP_MASK_INNER ) && level >= HYTEG_HIP_MIN_LEVEL )
-               hipCheck( hyteg_hip_p1_sor_cell( dst.getCellPointer( c, level ), rhs.getCellPointer( c, level ), (int) level,
-                                                getCellStencils( cell.id, level ).inner, relax, backwards ? 1 : 0, storage_->stream() ),
-                         "smooth_sor: cell" );
-         } );
-      };
+      auto sweepCells = [&]() { launchSorCells( dst, rhs, relax, level, flag, backwards ); };
       if ( !anyShell && storage_->numRanks() == 1 )
       {
          sweepCells();
@@ -289,27 +270,7 @@ class P1ConstantOperator
                       "smooth_sor: rest" );
          } );
          rest.sumSharedCopies( level, flag );
-         if ( storage_->useBatchSor( level ) )
-         {
-            const auto masks = storage_->masksFor( flag, false, bits & HYTEG_HIP_MASK_SHELL );
-            storage_->forCellChunks( [&]( int first, int count ) {
-               const auto u = dst.cellPointers( level, first, count ), r = rhs.cellPointers( level, first, count ),
-                          q = rest.cellPointers( level, first, count );
-               hipCheck( hyteg_hip_p1_sor_shell_cells( count, u.data(), r.data(), q.data(), (int) level, shellTable( level ) + first, relax,
-                                                       masks.data() + first, backwards ? 1 : 0, storage_->stream() ),
-                         "smooth_sor: shell (batched)" );
-            } );
-            return;
-         }
-         forCells( [&]( uint_t c, const MacroCell& cell ) {
-            const auto&    T    = sorTables_.at( level ).at( cell.id );
-            const unsigned mask = storage_->maskFor( cell, flag ) & bits;
-            hipCheck( hyteg_hip_p1_sor_shell_cell( dst.getCellPointer( c, level ), rhs.getCellPointer( c, level ),
-                                                   rest.getCellPointer( c, level ), (int) level, &T.edgeVerts[0][0], &T.edgeW[0][0],
-                                                   &T.faceVerts[0][0], &T.faceW[0][0], T.vertexW, relax, mask, backwards ? 1 : 0,
-                                                   storage_->stream() ),
-                      "smooth_sor: shell" );
-         } );
+         launchSorShell( dst, rhs, rest, relax, level, flag, bits, backwards );
       };
       if ( !backwards )
       {
@@ -324,6 +285,71 @@ class P1ConstantOperator
          sweepShell( 0xFu << 10 ); // macro-vertices
       }
    }
+   // The two halves of smooth_sor for callers that provide the stencil sum over the neighbours outside a primitive's closure
+   // themselves (P2 operators: the vertex-to-vertex sweeps of P2ConstantOperator::smooth_sor_macro_{vertices,edges,faces,cells}
+   // see the edge DoFs as well): the sweeps of the point classes in `bits` on every cell's copies with the total weights, `rest`
+   // already summed over the cells; and the lexicographic macro-cell sweeps.
+   void smooth_sor_shell_given_rest( const P1Function< double >& dst, const P1Function< double >& rhs, const P1Function< double >& rest,
+                                     double relax, uint_t level, DoFType flagIn, unsigned bits, bool backwards = false ) const
+   {
+      launchSorShell( dst, rhs, rest, relax, level, dst.effectiveFlag( flagIn ), bits, backwards );
+   }
+   void smooth_sor_cells_only( const P1Function< double >& dst, const P1Function< double >& rhs, double relax, uint_t level, DoFType flagIn,
+                               bool backwards = false ) const
+   {
+      launchSorCells( dst, rhs, relax, level, dst.effectiveFlag( flagIn ), backwards );
+   }
+
+ private:
+   void launchSorCells( const P1Function< double >& dst, const P1Function< double >& rhs, double relax, uint_t level, DoFType flag,
+                        bool backwards ) const
+   {
+      if ( storage_->useBatchSor( level ) )
+      {
+         const auto masks = storage_->masksFor( flag );
+         storage_->forCellChunks( [&]( int first, int count ) {
+            const auto u = dst.cellPointers( level, first, count ), r = rhs.cellPointers( level, first, count );
+            hipCheck( hyteg_hip_p1_sor_cells( count, u.data(), r.data(), (int) level, stencilTable( level ) + (size_t) first * 225, relax,
+                                              backwards ? 1 : 0, masks.data() + first, storage_->stream() ),
+                      "smooth_sor: cells (batched)" );
+         } );
+         return;
+      }
+      forCells( [&]( uint_t c, const MacroCell& cell ) {
+         const unsigned mask = storage_->maskFor( cell, flag );
+         if ( ( mask & HYTEG_HIP_MASK_INNER ) && level >= HYTEG_HIP_MIN_LEVEL )
+            hipCheck( hyteg_hip_p1_sor_cell( dst.getCellPointer( c, level ), rhs.getCellPointer( c, level ), (int) level,
+                                             getCellStencils( cell.id, level ).inner, relax, backwards ? 1 : 0, storage_->stream() ),
+                      "smooth_sor: cell" );
+      } );
+   }
+   void launchSorShell( const P1Function< double >& dst, const P1Function< double >& rhs, const P1Function< double >& rest, double relax,
+                        uint_t level, DoFType flag, unsigned bits, bool backwards ) const
+   {
+      if ( storage_->useBatchSor( level ) )
+      {
+         const auto masks = storage_->masksFor( flag, false, bits & HYTEG_HIP_MASK_SHELL );
+         storage_->forCellChunks( [&]( int first, int count ) {
+            const auto u = dst.cellPointers( level, first, count ), r = rhs.cellPointers( level, first, count ),
+                       q = rest.cellPointers( level, first, count );
+            hipCheck( hyteg_hip_p1_sor_shell_cells( count, u.data(), r.data(), q.data(), (int) level, shellTable( level ) + first, relax,
+                                                    masks.data() + first, backwards ? 1 : 0, storage_->stream() ),
+                      "smooth_sor: shell (batched)" );
+         } );
+         return;
+      }
+      forCells( [&]( uint_t c, const MacroCell& cell ) {
+         const auto&    T    = sorTables_.at( level ).at( cell.id );
+         const unsigned mask = storage_->maskFor( cell, flag ) & bits;
+         hipCheck( hyteg_hip_p1_sor_shell_cell( dst.getCellPointer( c, level ), rhs.getCellPointer( c, level ),
+                                                rest.getCellPointer( c, level ), (int) level, &T.edgeVerts[0][0], &T.edgeW[0][0],
+                                                &T.faceVerts[0][0], &T.faceW[0][0], T.vertexW, relax, mask, backwards ? 1 : 0,
+                                                storage_->stream() ),
+                   "smooth_sor: shell" );
+      } );
+   }
+
+ public:
    // Several functions swept by the SAME launches (no counterpart in the reference, which sweeps one function at a time): the
    // Gauss-Seidel phases are chains of small dependent kernels whose duration does not depend on how many cells a launch
    // covers, and the batched kernels take any list of cell arrays -- so the three velocity components of the Stokes smoother

@@ -135,15 +135,14 @@ class P2ElementwiseOperator
    }
 
  protected:
-   // the six element matrices of local cell lc at level l and the operator table built from them, uploaded
-   void addElementMatrixTable( uint_t l, uint_t lc )
+   // the six element matrices of a macro-cell at level l (kernel INPUT)
+   static std::vector< double > elementMatricesOf( const MacroCell& cell, uint_t l )
    {
       // micro-cell vertex offsets of the six cell types, celldof::macrocell::getMicroVerticesFromMicroCell (CellDoFIndexing.hpp:155-198)
       static const int verts[6][4][3] = {
           { { 0, 0, 0 }, { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } }, { { 1, 0, 0 }, { 1, 1, 0 }, { 0, 1, 0 }, { 1, 0, 1 } },
           { { 1, 0, 0 }, { 0, 1, 0 }, { 1, 0, 1 }, { 0, 0, 1 } }, { { 1, 1, 0 }, { 1, 1, 1 }, { 0, 1, 1 }, { 1, 0, 1 } },
           { { 1, 0, 1 }, { 0, 1, 1 }, { 0, 0, 1 }, { 0, 1, 0 } }, { { 0, 1, 0 }, { 1, 1, 0 }, { 1, 0, 1 }, { 0, 1, 1 } } };
-      const MacroCell&      cell = storage_->getLocalCell( lc );
       const double          step = 1.0 / double( int64_t( 1 ) << l );
       std::vector< double > h( 600 );
       for ( int t = 0; t < 6; ++t )
@@ -156,7 +155,22 @@ class P2ElementwiseOperator
                          ( cell.coords[3][r] - cell.coords[0][r] ) * step * verts[t][k][2];
          P2Form::integrateAll( c, h.data() + 100 * t );
       }
-      std::vector< double > table( hyteg_hip_p2_operator_table_size() );
+      return h;
+   }
+   // the operator table (host copy) of ANY macro-cell of the mesh, local or not: the Gauss-Seidel tables need the shares of all
+   // cells at a macro-face
+   virtual std::vector< double > hostTableOf( const MacroCell& cell, uint_t l ) const
+   {
+      const std::vector< double > h = elementMatricesOf( cell, l );
+      std::vector< double >       table( hyteg_hip_p2_operator_table_size() );
+      hipCheck( hyteg_hip_p2_build_operator_table( h.data(), table.data() ), "P2ElementwiseOperator: operator table" );
+      return table;
+   }
+   // the six element matrices of local cell lc at level l and the operator table built from them, uploaded
+   void addElementMatrixTable( uint_t l, uint_t lc )
+   {
+      const std::vector< double > h = elementMatricesOf( storage_->getLocalCell( lc ), l );
+      std::vector< double >       table( hyteg_hip_p2_operator_table_size() );
       hipCheck( hyteg_hip_p2_build_operator_table( h.data(), table.data() ), "P2ElementwiseOperator: operator table" );
       elementMatrices_[l].push_back( storage_->uploadTable( table ) );
       hostMatrices_[l].push_back( h );
@@ -262,25 +276,34 @@ class P2ElementwiseOperator
       const P1Function< double >& sv = *sorTmpV_;
       const P1Function< double >& uv = dst.getVertexDoFFunction();
       const bool                  shared = storage_->getCells().size() > 1;
+      bool                        anyShell = false;
+      for ( uint_t c = 0; c < storage_->getNumberOfLocalCells(); ++c )
+         anyShell = anyShell || ( storage_->maskFor( storage_->getLocalCell( c ), flag ) & HYTEG_HIP_MASK_SHELL );
+      auto update = [&]( unsigned k, unsigned keep ) {
+         t.assignKinds( { 1.0, -1.0 }, { rhs, t }, level, flag, k, keep );
+         t.multElementwiseKinds( { *getInverseDiagonalValues(), t }, level, flag, k, keep );
+         dst.addKinds( { relax }, { t }, level, flag, k, keep );
+      };
+      auto cellEdgeSweep = [&]( int type ) {
+         applyKinds( dst, t, level, flag, 1u << type, HYTEG_HIP_MASK_INNER );
+         update( 1u << type, HYTEG_HIP_MASK_INNER );
+      };
+      if ( level >= 2 && ( anyShell || storage_->numRanks() > 1 ) )
+      {
+         smoothSorReferenceOrder( dst, rhs, relax, level, flag, backwards, cellEdgeSweep );
+         return;
+      }
+      // levels 0 and 1 (a DoF can lie on several macro-faces at once: no stencil per point class), or nothing shared is swept
       auto vertexSweep = [&]() {
          applyKinds( dst, t, level, flag, 1u );
          v2v_->apply( uv, sv, level, flag );
          tv.assign( { 1.0, -1.0, 1.0 }, { rhs.getVertexDoFFunction(), tv, sv }, level, flag );
          v2v_->smooth_sor( uv, tv, relax, level, flag, backwards );
       };
-      auto update = [&]( unsigned k, unsigned keep ) {
-         t.assignKinds( { 1.0, -1.0 }, { rhs, t }, level, flag, k, keep );
-         t.multElementwiseKinds( { *getInverseDiagonalValues(), t }, level, flag, k, keep );
-         dst.addKinds( { relax }, { t }, level, flag, k, keep );
-      };
       auto sharedEdgeSweep = [&]( int type ) {
          applyKinds( dst, t, level, flag, 0xFEu, HYTEG_HIP_MASK_SHELL ); // every cell's share of every shared edge DoF, summed
          update( 1u << type, HYTEG_HIP_MASK_SHELL );
          dst.syncSharedEdgeCopies( level, flag ); // the lowest-numbered neighbour cell's copy (and its frame) decides
-      };
-      auto cellEdgeSweep = [&]( int type ) {
-         applyKinds( dst, t, level, flag, 1u << type, HYTEG_HIP_MASK_INNER );
-         update( 1u << type, HYTEG_HIP_MASK_INNER );
       };
       if ( !backwards )
       {
@@ -301,6 +324,165 @@ class P2ElementwiseOperator
          vertexSweep();
       }
    }
+
+ private:
+   // tables of the sweeps over shared macro-primitives, per level (built on first use)
+   struct SorTables
+   {
+      std::vector< const double* >             outside, closureVertex, closureEdge; // device tables per local cell
+      std::vector< std::array< int, 12 > >     faceVerts;                            // per local cell: [face][3] local vertex ids by global id
+      std::vector< std::array< double, 60 > >  faceW;                                // per local cell: [face][type][5] total weights
+   };
+   const SorTables& sorTables( uint_t level ) const
+   {
+      auto it = sorTables_.find( level );
+      if ( it != sorTables_.end() )
+         return it->second;
+      SorTables                                T;
+      std::vector< std::array< double, 15 > >  faceTot( storage_->getFaces().size(), std::array< double, 15 >{} );
+      auto                                     faceVertsOf = []( const MacroCell& c, int f, int l[3] ) {
+         for ( int r = 0; r < 3; ++r )
+            l[r] = kCellFaceVerts[f][r];
+         std::sort( l, l + 3, [&]( int a, int b ) { return c.v[a] < c.v[b]; } );
+      };
+      for ( const auto& c : storage_->getCells() ) // all cells of the mesh: a face's weights are the sum of its cells' shares
+      {
+         const std::vector< double > table = hostTableOf( c, level );
+         for ( int f = 0; f < 4; ++f )
+         {
+            int    l[3];
+            double w[15];
+            faceVertsOf( c, f, l );
+            hipCheck( hyteg_hip_p2_operator_table_face_edge_weights( table.data(), l, w ), "P2 smooth_sor: face weights" );
+            for ( int k = 0; k < 15; ++k )
+               faceTot[c.faces[f]][k] += w[k];
+         }
+         if ( c.localIndex < 0 )
+            continue;
+         std::vector< double > o( table.size() ), cv( table.size() ), ce( table.size() );
+         hipCheck( hyteg_hip_p2_operator_table_closure_split( table.data(), o.data(), cv.data(), ce.data() ), "P2 smooth_sor: closure split" );
+         if ( (size_t) c.localIndex >= T.outside.size() )
+            T.outside.resize( c.localIndex + 1 ), T.closureVertex.resize( c.localIndex + 1 ), T.closureEdge.resize( c.localIndex + 1 ),
+                T.faceVerts.resize( c.localIndex + 1 ), T.faceW.resize( c.localIndex + 1 );
+         T.outside[c.localIndex]       = storage_->uploadTable( o );
+         T.closureVertex[c.localIndex] = storage_->uploadTable( cv );
+         T.closureEdge[c.localIndex]   = storage_->uploadTable( ce );
+      }
+      for ( const auto& c : storage_->getCells() )
+      {
+         if ( c.localIndex < 0 )
+            continue;
+         for ( int f = 0; f < 4; ++f )
+         {
+            int l[3];
+            faceVertsOf( c, f, l );
+            for ( int r = 0; r < 3; ++r )
+               T.faceVerts[c.localIndex][3 * f + r] = l[r];
+            for ( int k = 0; k < 15; ++k )
+               T.faceW[c.localIndex][15 * f + k] = faceTot[c.faces[f]][k];
+         }
+      }
+      return sorTables_.emplace( level, std::move( T ) ).first->second;
+   }
+   // P2ConstantOperator::smooth_sor (P2ConstantOperator.cpp:1267-1330) on a mesh with shared macro-primitives, levels >= 2.
+   // Forward: macro-vertices (vertex DoF), macro-edges (their vertex DoFs along the edge, then their edge DoFs), macro-faces (vertex
+   // DoFs rows ascending, then edge DoFs rows ascending with X, XY, Y at every index), macro-cells (vertex DoFs, edge DoFs by type);
+   // backwards the classes in reverse order and every loop reversed (a macro-edge still vertex DoFs first, P2MacroEdge.cpp:617-680).
+   // A row of a DoF on primitive P splits into
+   //    rest     sources outside the closure of P: ghost-layer values in the reference -- forward the values at the START of the
+   //             sweep (nothing is communicated downwards in between), backwards those at the start of the class;
+   //             ONE apply with the `outside` tables, summed over the cells by the additive exchange;
+   //    closure  sources on P or its boundary, current values: edge-DoF sources of a vertex DoF and vertex-DoF sources of an edge
+   //             DoF do not change while their counterpart is swept -- one apply with the closure tables per half-class;
+   //             vertex-vertex couplings are swept by the P1 kernels of the vertex-to-vertex operator on every cell's copy
+   //             (p1_sor_shell.hip), edge-edge couplings inside a macro-face by hyteg_hip_p2_sor_face_edgedofs_cell; the edge DoFs
+   //             of one macro-edge do not couple.
+   template < typename CellEdgeSweep >
+   void smoothSorReferenceOrder( const P2Function< double >& dst, const P2Function< double >& rhs, double relax, uint_t level, DoFType flag,
+                                 bool backwards, CellEdgeSweep&& cellEdgeSweep ) const
+   {
+      const SorTables& T = sorTables( level );
+      if ( !sorRest_ )
+         sorRest_.reset( new P2Function< double >( "p2_sor_rest", storage_, minLevel_, maxLevel_ ) );
+      const P2Function< double >& t     = *sorTmp_;
+      const P2Function< double >& rest  = *sorRest_;
+      const P1Function< double >& tv    = t.getVertexDoFFunction();
+      const P1Function< double >& restV = rest.getVertexDoFFunction();
+      const P1Function< double >& sv    = *sorTmpV_;
+      const P1Function< double >& uv    = dst.getVertexDoFFunction();
+      const P1Function< double >& bv    = rhs.getVertexDoFFunction();
+      const unsigned              V = 0xFu << 10, E = 0x3Fu, F = 0xFu << 6;
+      auto computeRest = [&]( unsigned classes ) {
+         launchWith( T.outside, 1.0, dst, rest, level, flag, classes, HYTEG_HIP_REPLACE );
+         restV.sumSharedCopies( level, flag );
+         rest.sumSharedEdgeCopies( level, flag );
+      };
+      auto vertexDoFs = [&]( unsigned classes ) {
+         if ( classes == V )
+         {
+            v2v_->smooth_sor_shell_given_rest( uv, bv, restV, relax, level, flag, classes, backwards );
+            return;
+         }
+         launchWith( T.closureEdge, 1.0, dst, t, level, flag, classes, HYTEG_HIP_REPLACE, 1u );
+         tv.sumSharedCopies( level, flag );
+         sv.assign( { 1.0, 1.0 }, { restV, tv }, level, flag );
+         v2v_->smooth_sor_shell_given_rest( uv, bv, sv, relax, level, flag, classes, backwards );
+      };
+      // q = rhs - rest - (vertex-DoF sources on the closure), at the edge DoFs of the given classes
+      auto edgeRightHandSide = [&]( unsigned classes ) {
+         launchWith( T.closureVertex, 1.0, dst, t, level, flag, classes, HYTEG_HIP_REPLACE, 0xFEu );
+         t.sumSharedEdgeCopies( level, flag );
+         t.assignKinds( { 1.0, -1.0, -1.0 }, { rhs, rest, t }, level, flag, 0xFEu, classes );
+      };
+      auto edgeDoFsOfMacroEdges = [&]() {
+         edgeRightHandSide( E );
+         t.multElementwiseKinds( { *getInverseDiagonalValues(), t }, level, flag, 0xFEu, E );
+         dst.assignKinds( { 1.0 - relax, relax }, { dst, t }, level, flag, 0xFEu, E );
+      };
+      auto edgeDoFsOfMacroFaces = [&]() {
+         edgeRightHandSide( F );
+         for ( uint_t c = 0; c < storage_->getNumberOfLocalCells(); ++c )
+            hipCheck( hyteg_hip_p2_sor_face_edgedofs_cell( dst.getEdgeCellPointer( c, level ), t.getEdgeCellPointer( c, level ), (int) level,
+                                                           T.faceVerts[c].data(), T.faceW[c].data(), relax,
+                                                           storage_->maskFor( storage_->getLocalCell( c ), flag ) & F, backwards ? 1 : 0,
+                                                           storage_->stream() ),
+                      "P2 smooth_sor: face edge DoFs" );
+      };
+      auto vertexDoFsOfCells = [&]() {
+         applyKinds( dst, t, level, flag, 1u, HYTEG_HIP_MASK_INNER );
+         v2v_->apply( uv, sv, level, flag );
+         tv.assign( { 1.0, -1.0, 1.0 }, { bv, tv, sv }, level, flag );
+         v2v_->smooth_sor_cells_only( uv, tv, relax, level, flag, backwards );
+      };
+      if ( !backwards )
+      {
+         computeRest( HYTEG_HIP_MASK_SHELL );
+         vertexDoFs( V );
+         vertexDoFs( E );
+         edgeDoFsOfMacroEdges();
+         vertexDoFs( F );
+         edgeDoFsOfMacroFaces();
+         vertexDoFsOfCells();
+         for ( int type = 1; type <= 7; ++type )
+            cellEdgeSweep( type );
+      }
+      else
+      {
+         for ( int type = 7; type >= 1; --type )
+            cellEdgeSweep( type );
+         vertexDoFsOfCells();
+         computeRest( F );
+         edgeDoFsOfMacroFaces();
+         vertexDoFs( F );
+         computeRest( E );
+         vertexDoFs( E );
+         edgeDoFsOfMacroEdges();
+         computeRest( V );
+         vertexDoFs( V );
+      }
+   }
+
+ public:
    void smooth_gs( const P2Function< double >& dst, const P2Function< double >& rhs, uint_t level, DoFType flag ) const
    {
       smooth_sor( dst, rhs, 1.0, level, flag );
@@ -384,6 +566,8 @@ class P2ElementwiseOperator
    mutable std::unique_ptr< P1ConstantOperator< forms::P2VertexToVertexForm< P2Form > > > v2v_; // smooth_sor
    mutable std::unique_ptr< P2Function< double > >                                        sorTmp_;
    mutable std::unique_ptr< P1Function< double > >                                        sorTmpV_;
+   mutable std::unique_ptr< P2Function< double > >                                        sorRest_;
+   mutable std::map< uint_t, SorTables >                                                  sorTables_;
    uint64_t                                                     uid_ = nextUid();
 };
 using P2ElementwiseLaplaceOperator = P2ElementwiseOperator< forms::P2LaplaceForm >; // P2ElementwiseOperator.hpp:454
@@ -422,16 +606,7 @@ class P2ConstantOperator : public P2ElementwiseOperator< P2Form >
                stencils_[l].push_back( CellStencils{} );
                continue;
             }
-            const MacroCell& cell = storage->getLocalCell( lc );
-            CellStencils     S;
-            // inner DoFs: the stencil maps must have exactly the keys of the layout; boundary classes: a subset of them
-            S.inner = flatten( P2Elements::P2Elements3D::assembleAtClass< P2Form >( cell, l, 14 ), true );
-            S.classes.assign( 14 * (size_t) total_, 0.0 );
-            for ( int cls = 0; cls < 14; ++cls )
-            {
-               const auto v = flatten( P2Elements::P2Elements3D::assembleAtClass< P2Form >( cell, l, cls ), false );
-               std::copy( v.begin(), v.end(), S.classes.begin() + (size_t) cls * total_ );
-            }
+            CellStencils          S = assembleStencils( storage->getLocalCell( lc ), l );
             std::vector< double > table( hyteg_hip_p2_operator_table_size() );
             hipCheck( hyteg_hip_p2_build_operator_table_from_stencils( S.inner.data(), S.classes.data(), table.data() ),
                       "P2ConstantOperator: operator table" );
@@ -444,6 +619,15 @@ class P2ConstantOperator : public P2ElementwiseOperator< P2Form >
    const std::vector< int >&    getStencilKeys() const { return keys_; }
 
  protected:
+   std::vector< double > hostTableOf( const MacroCell& cell, uint_t l ) const override
+   {
+      if ( l < 2 )
+         return Base::hostTableOf( cell, l );
+      const CellStencils    S = assembleStencils( cell, l );
+      std::vector< double > table( hyteg_hip_p2_operator_table_size() );
+      hipCheck( hyteg_hip_p2_build_operator_table_from_stencils( S.inner.data(), S.classes.data(), table.data() ), "P2ConstantOperator: operator table" );
+      return table;
+   }
    // diagonal: the weights with source kind = destination kind and offset 0
    std::vector< double > diagonalTable( uint_t level, uint_t localCell ) const override
    {
@@ -470,6 +654,19 @@ class P2ConstantOperator : public P2ElementwiseOperator< P2Form >
    {
       std::vector< double > inner, classes;
    };
+   // inner DoFs: the stencil maps must have exactly the keys of the layout; boundary classes: a subset of them
+   CellStencils assembleStencils( const MacroCell& cell, uint_t l ) const
+   {
+      CellStencils S;
+      S.inner = flatten( P2Elements::P2Elements3D::assembleAtClass< P2Form >( cell, l, 14 ), true );
+      S.classes.assign( 14 * (size_t) total_, 0.0 );
+      for ( int cls = 0; cls < 14; ++cls )
+      {
+         const auto v = flatten( P2Elements::P2Elements3D::assembleAtClass< P2Form >( cell, l, cls ), false );
+         std::copy( v.begin(), v.end(), S.classes.begin() + (size_t) cls * total_ );
+      }
+      return S;
+   }
    // values of the assembled maps in the order of the layout's keys; `complete`: every key of the layout must be present
    std::vector< double > flatten( const P2Elements::P2Elements3D::KindStencils& maps, bool complete ) const
    {

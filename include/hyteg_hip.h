@@ -661,6 +661,33 @@ HYTEG_HIP_API int    hyteg_hip_p2_elementwise_apply_cell_kinds( double*         
                                                           unsigned           kind_mask,
                                                           hyteg_hip_stream_t stream );
 
+/* ---- P2 Gauss-Seidel / SOR on macro-primitives shared between macro-cells, in the reference's order ----
+ * P2ConstantOperator::smooth_sor (src/constant_stencil_operator/P2ConstantOperator.cpp:1267-1330): macro-vertices (:157-201),
+ * macro-edges (:205-266, P2MacroEdge.cpp:617-680), macro-faces (:269-880, kernels
+ * P2generatedKernels/sor_3D_macroface_P2_update_{vertexdofs,edgedofs}*.cpp), macro-cells.  A primitive's sweep sees current
+ * values on itself and on its boundary and ghost-layer values elsewhere.  Pieces for a cell-centric implementation:
+ *  - hyteg_hip_p2_operator_table_closure_split (host arrays of hyteg_hip_p2_operator_table_size() doubles): splits the rows of
+ *    the 14 boundary point classes of an operator table by where the SOURCE lies: `outside` keeps the weights of sources that do
+ *    not lie on the closure of the destination's macro-primitive (what the reference reads from ghost layers), `closure_vertex` /
+ *    `closure_edge` the weights of vertex- / edge-DoF sources on it.  Inner rows and element matrices are zero in all three:
+ *    such tables serve the boundary classes at levels >= 2.
+ *  - hyteg_hip_p2_operator_table_face_edge_weights: this cell's share of the couplings between the edge DoFs INSIDE one macro-face,
+ *    in the face's own frame -- face_verts[3] = the cell-local vertex ids of the face's vertices in the order of their global ids
+ *    (x runs from the first to the second, y from the first to the third); w[3][5]: for the face types X, XY, Y the diagonal
+ *    and the four neighbours  X: XY(i,j) Y(i,j) XY(i,j-1) Y(i+1,j-1);  XY: X(i,j) Y(i,j) X(i,j+1) Y(i+1,j);
+ *    Y: X(i,j) XY(i,j) X(i-1,j+1) XY(i-1,j)  (the other edges of the two face triangles that share the edge).
+ *  - hyteg_hip_p2_sor_face_edgedofs_cell: sor_3D_macroface_P2_update_edgedofs[_backwards] on this cell's copy of its faces in
+ *    `mask` (bits 6..9): rows ascending, x ascending, X, XY, Y at every index, each in place,
+ *        u_i = (1 - relax) u_i + relax / w_ii ( q_i - sum_{in-face neighbours} w_ij u_j ),
+ *    q = rhs - (everything that does not change during the sweep), face_w[4][3][5] = the TOTAL weights (sum of the shares of
+ *    the cells at the face), face_verts[4][3] as above per face.  Every cell at a face runs the same sweep on its own copy.
+ *    Levels 2..9. */
+HYTEG_HIP_API int hyteg_hip_p2_operator_table_closure_split( const double* table_host, double* outside, double* closure_vertex, double* closure_edge );
+HYTEG_HIP_API int hyteg_hip_p2_operator_table_face_edge_weights( const double* table_host, const int* face_verts /* 3 */, double* w /* 15 */ );
+HYTEG_HIP_API int hyteg_hip_p2_sor_face_edgedofs_cell( double* dst_edge, const double* q_edge, int level, const int* face_verts /* 12 */,
+                                                       const double* face_w /* 60 */, double relax, unsigned mask, int backwards,
+                                                       hyteg_hip_stream_t stream );
+
 /* a10: additive exchange of shared points (the reduce-into-owner of VertexDoFAdditivePackInfo.hpp:676-745,
  * followed by the copy back into every adjacent cell).  A group is one physical DoF; its entries are the
  * places that hold a partial value of it: (buffer index into `bases`, element offset).
