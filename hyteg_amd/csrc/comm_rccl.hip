@@ -12,6 +12,7 @@
 // it with torch) must not map a second one, and a process that never communicates does not need any.
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include <mutex>
@@ -136,8 +137,13 @@ HYTEG_HIP_API int hyteg_hip_event_create( hyteg_hip_event_t* event )
 HYTEG_HIP_API int hyteg_hip_event_create_timing( hyteg_hip_event_t* event )
 {
    HH_REQUIRE( event != nullptr, "event_create_timing: null out pointer" );
-   hipEvent_t e;
-   HH_CHECK_HIP( hipEventCreate( &e ) );
+   // hipEventDisableSystemFence: "for events that are only used to measure timing ... avoids the cost of cache writeback and
+   // invalidation, and the performance impact of those actions on the execution of following work" (hip_runtime_api.h); results
+   // are read after a stream / device synchronisation, never through these events.  HYTEG_HIP_TIMING_EVENT_FENCE=1 keeps the fence.
+   const char*    env   = std::getenv( "HYTEG_HIP_TIMING_EVENT_FENCE" );
+   const unsigned flags = ( env && env[0] == '1' ) ? hipEventDefault : hipEventDisableSystemFence;
+   hipEvent_t     e;
+   HH_CHECK_HIP( hipEventCreateWithFlags( &e, flags ) );
    *event = reinterpret_cast< hyteg_hip_event_t >( e );
    return HYTEG_HIP_OK;
 }

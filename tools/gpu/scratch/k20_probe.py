@@ -53,10 +53,14 @@ def run(name, fn, **kw):
     ev = sorted(x[0] for x in v); ho = sorted(x[1] for x in v); wl = sorted(x[2] for x in v)
     print(f"{name:58s} event/K med {ev[R//2]:7.3f} min {ev[0]:7.3f} | host loop med {ho[R//2]:7.1f} us | wall/K med {wl[R//2]:7.3f}", flush=True)
 
+import os
 E0, E1 = capi.event_create_timing(), capi.event_create_timing()
+os.environ["HYTEG_HIP_TIMING_EVENT_FENCE"] = "1"
+F0, F1 = capi.event_create_timing(), capi.event_create_timing()
+del os.environ["HYTEG_HIP_TIMING_EVENT_FENCE"]
 ring = capi.calib_copy_ring(ptr, n, True, stream.cuda_stream)
 
-def region_c(fn):
+def region_c(fn, E0=E0, E1=E1):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     fn(0, K, E0, E1)
@@ -65,8 +69,8 @@ def region_c(fn):
     t2 = time.perf_counter()
     return capi.event_elapsed_ms(E0, E1) * 1e3 / K, (t1 - t0) * 1e6, (t2 - t0) * 1e6 / K
 
-def run_c(name, fn):
-    v = [region_c(fn) for _ in range(R)]
+def run_c(name, fn, **kw):
+    v = [region_c(fn, **kw) for _ in range(R)]
     ev = sorted(x[0] for x in v); ho = sorted(x[1] for x in v); wl = sorted(x[2] for x in v)
     print(f"{name:58s} event/K med {ev[R//2]:7.3f} min {ev[0]:7.3f} | host loop med {ho[R//2]:7.1f} us | wall/K med {wl[R//2]:7.3f}", flush=True)
 
@@ -79,6 +83,8 @@ for rep in range(2):
     run(f"host-layer cycle, K={K}, 8 untimed applies in front", cyc, pre=8, first=8)
     run_c(f"host-layer cycle, K={K}, events recorded by the C loop", cyc)
     run_c(f"copy ring, K={K}, events recorded by the C loop", ring)
+    run_c(f"host-layer cycle, K={K}, C loop, events WITH system fence", cyc, E0=F0, E1=F1)
+    run_c(f"copy ring, K={K}, C loop, events WITH system fence", ring, E0=F0, E1=F1)
     run(f"direct C-ABI loop (python), K={K}", direct)
     run(f"copy floor, K={K}", copy)
     run(f"copy floor, K={K}, 3 untimed copies in front", copy, pre=3, first=3)
