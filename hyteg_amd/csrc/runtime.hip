@@ -231,6 +231,11 @@ HYTEG_HIP_API int hyteg_hip_malloc( void** dev_ptr, size_t bytes )
 {
    HH_REQUIRE( dev_ptr != nullptr, "malloc: null out pointer" );
    *dev_ptr = nullptr;
+   // arrays of 1 MiB and more get whole 2 MiB fragments of their own: the size is rounded up so that the array's last page
+   // fragment is not shared with the next allocation (the address of such an allocation is 2 MiB-aligned already)
+   constexpr size_t kFragment = size_t( 2 ) << 20;
+   if ( bytes >= ( size_t( 1 ) << 20 ) )
+      bytes = ( bytes + kFragment - 1 ) / kFragment * kFragment;
    HH_CHECK_HIP( hipMalloc( dev_ptr, bytes ) );
    return HYTEG_HIP_OK;
 }
