@@ -315,7 +315,10 @@ def main():
         per_step_us = sorted(evs[k].elapsed_time(evs[k + 1]) * 1e3 for k in range(args.steps))
         return walls, devs, copies, per_step_us
 
-    pre_warm = 2 * nbuf
+    # untimed, before the W warm-up steps: the GPU's clocks follow the load over tens of milliseconds, and a run of 25 regions of
+    # K = 20 steps is 5 ms of work after seconds of set-up -- without this its regions measure the ramp (10.1-10.3 us per launch
+    # against 9.5 with it and 9.3 for K = 2000, same box; HYTEG_BENCH_PREWARM=0 switches it off, at least 2 * nbuf applies remain)
+    pre_warm = max(2 * nbuf, int(os.environ.get("HYTEG_BENCH_PREWARM", "10000")))
     walls, devs, copies, per_step_us = measure()
     if world > 1 and ctx.transport == "p2p":
         ok, err = True, ""
