@@ -19,6 +19,8 @@
 
 #include <atomic>
 
+#include <cstdlib>
+
 #include "common.hpp"
 #include "sor_dataflow.hpp"
 
@@ -396,19 +398,74 @@ int get_sor_pipeline( int level, int nsweeps, bool backwards, const SorPipelineT
 // of the sweep, blockIdx.x = cell.  Same update order and the same summation order as p1_sor_plane_kernel.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kSmallThreads = 256;
+// the inner points of a cell sorted by hyperplane t = x + 2 y + 3 z (array order inside a plane), with what the neighbour
+// offsets need; round 3: the kernel used to scan all (z, y) candidates of every plane -- 96 planes x 930 candidates at level 5,
+// one integer division each, most of them off the plane: 1.5 us per plane, 137 us per level-5 sweep
+struct SorPlanePoint
+{
+   int   i;    // array index
+   short W, y; // slice width N - z, row
+};
+struct SorPlaneTable
+{
+   const SorPlanePoint* pts = nullptr;
+   const int*           off = nullptr; // [nplanes + 1]
+   int                  nplanes = 0;
+};
+int get_sor_planes( int level, const SorPlaneTable** out )
+{
+   static std::mutex                                     mtx;
+   static std::map< std::pair< int, int >, SorPlaneTable > cache;
+   int                                                   dev = 0;
+   HH_CHECK_HIP( hipGetDevice( &dev ) );
+   std::lock_guard< std::mutex > lock( mtx );
+   auto                          it = cache.find( { dev, level } );
+   if ( it == cache.end() )
+   {
+      const int N = ( 1 << level ) + 1, n = N - 1;
+      const int tmin = 6, tmax = 1 + 2 + 3 * ( n - 3 );
+      SorPlaneTable tab;
+      tab.nplanes = tmax >= tmin ? tmax - tmin + 1 : 0;
+      std::vector< std::vector< SorPlanePoint > > byT( (size_t) std::max( tab.nplanes, 0 ) );
+      for ( int z = 1; z <= n - 3; ++z )
+         for ( int y = 1; y <= n - 2 - z; ++y )
+            for ( int x = 1; x <= n - 1 - y - z; ++x )
+               byT[(size_t) ( x + 2 * y + 3 * z - tmin )].push_back(
+                   SorPlanePoint{ (int) ( slice_start( N, z ) + row_start( N - z, y ) + x ), (short) ( N - z ), (short) y } );
+      std::vector< SorPlanePoint > flat;
+      std::vector< int >           off( 1, 0 );
+      for ( const auto& v : byT )
+      {
+         flat.insert( flat.end(), v.begin(), v.end() );
+         off.push_back( (int) flat.size() );
+      }
+      void *pp = nullptr, *po = nullptr;
+      HH_CHECK_HIP( hipMalloc( &pp, std::max< size_t >( 1, flat.size() ) * sizeof( SorPlanePoint ) ) );
+      HH_CHECK_HIP( hipMalloc( &po, off.size() * sizeof( int ) ) );
+      if ( !flat.empty() )
+         HH_CHECK_HIP( hipMemcpy( pp, flat.data(), flat.size() * sizeof( SorPlanePoint ), hipMemcpyHostToDevice ) );
+      HH_CHECK_HIP( hipMemcpy( po, off.data(), off.size() * sizeof( int ), hipMemcpyHostToDevice ) );
+      tab.pts = static_cast< const SorPlanePoint* >( pp ), tab.off = static_cast< const int* >( po );
+      it = cache.emplace( std::make_pair( dev, level ), tab ).first;
+   }
+   *out = &it->second;
+   return HYTEG_HIP_OK;
+}
 struct SorSmallArgs
 {
-   double*       u[HYTEG_HIP_MAX_BATCH];
-   const double* rhs[HYTEG_HIP_MAX_BATCH];
-   const double* stencils; // device table [cell][15][15], or null: the one stencil in `w` (single-cell entry point)
-   int           N, size, backwards;
-   double        relax, one_minus_relax;
-   double        w[15];
+   double*              u[HYTEG_HIP_MAX_BATCH];
+   const double*        rhs[HYTEG_HIP_MAX_BATCH];
+   const double*        stencils; // device table [cell][15][15], or null: the one stencil in `w` (single-cell entry point)
+   const SorPlanePoint* pts;
+   const int*           off;
+   int                  N, size, backwards, nplanes;
+   double               relax, one_minus_relax;
+   double               w[15];
 };
 __global__ __launch_bounds__( kSmallThreads ) void p1_sor_small_kernel( const SorSmallArgs A )
 {
    extern __shared__ double lu[];
-   const int                cell = blockIdx.x, N = A.N, n = N - 1;
+   const int                cell = blockIdx.x;
    double*                  ug   = A.u[cell];
    const double*            rhs  = A.rhs[cell];
    const double*            w    = A.stencils ? A.stencils + (size_t) cell * 225 + 14 * 15 : A.w;
@@ -416,19 +473,14 @@ __global__ __launch_bounds__( kSmallThreads ) void p1_sor_small_kernel( const So
    for ( int i = threadIdx.x; i < A.size; i += kSmallThreads )
       lu[i] = ug[i];
    __syncthreads();
-   const int tmin = 6, tmax = 1 + 2 + 3 * ( n - 3 );
-   const int nzy  = ( n - 3 ) * ( n - 2 ); // candidate (z, y) pairs: z in [1, n-3], y in [1, n-2]
-   for ( int k = 0; k <= tmax - tmin; ++k )
+   for ( int k = 0; k < A.nplanes; ++k )
    {
-      const int t = A.backwards ? tmax - k : tmin + k;
-      for ( int c = threadIdx.x; c < nzy; c += kSmallThreads )
+      const int t = A.backwards ? A.nplanes - 1 - k : k;
+      for ( int c = A.off[t] + (int) threadIdx.x; c < A.off[t + 1]; c += kSmallThreads )
       {
-         const int z = 1 + c / ( n - 2 ), y = 1 + c % ( n - 2 );
-         const int x = t - 2 * y - 3 * z;
-         if ( x < 1 || x + y + z > n - 1 )
-            continue;
-         const int W = N - z, R = W - y, S0 = tri( W ), Sm = tri( W + 1 );
-         const int i = slice_start( N, z ) + row_start( W, y ) + x;
+         const SorPlanePoint P = A.pts[c];
+         const int i = P.i, W = P.W, y = P.y;
+         const int R = W - y, S0 = tri( W ), Sm = tri( W + 1 );
          double    acc = -w[3] * lu[i - Sm + W + 1];          // BN
          acc           = fma( -w[10], lu[i + R], acc );       // N
          acc           = fma( -w[5], lu[i - R], acc );        // SE
@@ -525,6 +577,10 @@ HYTEG_HIP_API int hyteg_hip_p1_sor_cells( int                  ncells,
    {
       // the stencil table is indexed by the position in the batch: compact batches need the original cell index,
       // so the kernel gets one launch per run of consecutive selected cells
+      const SorPlaneTable* planes = nullptr;
+      const int            prc    = get_sor_planes( level, &planes );
+      if ( prc != HYTEG_HIP_OK )
+         return prc;
       int k = 0;
       while ( k < m )
       {
@@ -535,6 +591,7 @@ HYTEG_HIP_API int hyteg_hip_p1_sor_cells( int                  ncells,
          for ( int j = k; j <= e; ++j )
             A.u[j - k] = u[sel[j]], A.rhs[j - k] = rhs[sel[j]];
          A.stencils = stencils_dev + (size_t) sel[k] * 225;
+         A.pts = planes->pts, A.off = planes->off, A.nplanes = planes->nplanes;
          A.N = N, A.size = (int) tet64( N ), A.backwards = backwards ? 1 : 0;
          A.relax = relax, A.one_minus_relax = 1.0 + ( -relax );
          const size_t lds = (size_t) A.size * sizeof( double );
@@ -653,14 +710,24 @@ HYTEG_HIP_API int hyteg_hip_p1_sor_cell( double*            u,
    A.invc            = 1.0 / w[7];
    for ( int k = 0; k < 15; ++k )
       A.st.w[k] = w[k];
-   if ( level <= 4 && g_sorAlgorithm.load( std::memory_order_relaxed ) == HYTEG_HIP_SOR_AUTO )
+   static const int smallMax = [] {
+      const char* e = std::getenv( "HYTEG_HIP_SOR_SMALL_MAX_LEVEL" ); // measurement switch
+      return e ? std::atoi( e ) : 4; // level 5: 53 us here against 65 us blocked, but the pipelined sweeps (blocked) would no longer be
+                                     // bit-identical to consecutive single sweeps there: the two forms sum a row in different orders
+   }();
+   if ( level <= smallMax && level <= 5 && g_sorAlgorithm.load( std::memory_order_relaxed ) == HYTEG_HIP_SOR_AUTO )
    {
       // the whole cell array fits into LDS: ONE workgroup runs all hyperplanes of the sweep in one launch (the kernel of the
       // batched entry point with one cell; same update order and summation order as the plane kernel).  Measured against one
-      // launch per plane: 5 / 11 / 28 us instead of 5 / 33 / 125 us at levels 2 / 3 / 4; at level 5 it loses against the blocked
-      // form (120 vs 65 us: 96 planes of 930 candidate rows for 256 threads).
+      // launch per plane: 5 / 11 / 28 us instead of 5 / 33 / 125 us at levels 2 / 3 / 4 (round 1, scanning candidates; with
+      // the plane table of round 3: 4.7 / 8.0 / 21 us, profiles/r03_sor_small_planes.txt).
       SorSmallArgs S{};
+      const SorPlaneTable* planes = nullptr;
+      const int            prc    = get_sor_planes( level, &planes );
+      if ( prc != HYTEG_HIP_OK )
+         return prc;
       S.u[0] = u, S.rhs[0] = rhs, S.stencils = nullptr;
+      S.pts = planes->pts, S.off = planes->off, S.nplanes = planes->nplanes;
       S.N = A.N, S.size = (int) tet64( A.N ), S.backwards = backwards ? 1 : 0;
       S.relax = relax, S.one_minus_relax = A.one_minus_relax;
       for ( int k = 0; k < 15; ++k )
