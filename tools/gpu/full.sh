@@ -2,7 +2,7 @@
 # whole GPU suite + the two bench lines + smoke.  usage: full.sh [tag]
 TAG=${1:-full}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03_$TAG; mkdir -p $O
-timeout -k 10 1000 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; echo "pytest rc $?"; tail -5 $O/pytest_gpu.log
+timeout -k 10 1000 python -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; echo "pytest rc $?"; tail -5 $O/pytest_gpu.log
 python bench.py --steps 20 --warmup 5 > $O/bench_driver_args.json 2> $O/bench_driver_args.err || tail -5 $O/bench_driver_args.err
 python bench.py > $O/bench_default.json 2> $O/bench_default.err || tail -5 $O/bench_default.err
 for f in bench_driver_args bench_default; do tail -1 $O/$f.json | python -c "
