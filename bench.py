@@ -390,6 +390,9 @@ def main():
                 "level": level,
                 "macro_cells": world,
                 "pre_warm_applies": pre_warm,
+                "pre_warm_note": "untimed applies BEFORE the W warm-up steps of the contract: two passes over the buffer ring (no first access "
+                                 "inside the timed region) and, by default, 10000 applies (~0.1 s) that bring the GPU's clocks up; "
+                                 "HYTEG_BENCH_PREWARM=0 leaves only the ring passes (K = 20: 10.1-10.3 us per launch instead of 9.5, DESIGN 3.1)",
                 "mesh_note": "1/2/4/8 GPUs run tet_1el / pyramid_2el / pyramid_4el / regular_octahedron_8el (one macro-cell per GPU);"
                              " they stand in for the MultigridStudies cube, whose 6 or 24 cells do not give one cell per GPU",
                 "halo_exchange": (f"transport '{ctx.transport}': "
