@@ -205,7 +205,7 @@ __device__ inline BrickTask zm_decode_task( const ZMarchArgs& A, int task )
 // boundary of 8 entries of dst (doubles: 64 bytes) inside lanes 1..7 (at a boundary of 4 entries in lane 4 where it would fall
 // on lane 8) and is 56 entries long (doubles: 448 bytes), so that no 64-byte line of dst is written by two waves except the
 // first and the last line of a row (round 3: the PMC write traffic of the 62-wide form is 1.11 x the bytes of dst).
-template < int MODE, int NY, int LZ, int EX_AUX, bool DEC, int PFD, typename T, int XS = 62, int ST_AUX = 2 >
+template < int MODE, int NY, int LZ, int EX_AUX, bool DEC, int PFD, typename T, int XS = 62, int ST_AUX = 2, int SRC_AUX = 0 >
 __device__ inline void zmarch_body( const ZMarchArgs& A, const BrickTask* tasks, int ntasks, int xcd_chunk )
 {
    static_assert( XS == 62 || ( XS == 56 && !DEC ), "x-stride: 62 (plain) or 56 (aligned store windows, table mode)" );
@@ -260,7 +260,7 @@ __device__ inline void zmarch_body( const ZMarchArgs& A, const BrickTask* tasks,
          if ( need )
          {
             const int last8 = ( W_q - ( ym + r ) - 1 - t.xb ) * SZ; // byte offset of the row's last entry from lane 0's
-            S[q][r]         = zm_load2< T, 0 >( rs, min( lane_off, last8 ), ix * SZ );
+            S[q][r]         = zm_load2< T, SRC_AUX >( rs, min( lane_off, last8 ), ix * SZ );
          }
          ix += W_q - ( ym + r ); // next row of the same slice
       }
@@ -432,11 +432,11 @@ __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_k
 // as leading scalar arguments: built with -mllvm -amdgpu-kernarg-preload-count=4 the command processor places them in SGPRs
 // at wave launch, so the task load does not wait for a kernel-argument load first (one scalar round trip less in the start-up
 // chain of DESIGN 3.1).  The rest of the arguments stay in the struct.
-template < int MODE, int NY, int LZ, int EX_AUX = 0, bool DEC = false, int PFD = 1, typename T = double, int XS = 62, int ST_AUX = 2 >
+template < int MODE, int NY, int LZ, int EX_AUX = 0, bool DEC = false, int PFD = 1, typename T = double, int XS = 62, int ST_AUX = 2, int SRC_AUX = 0 >
 __global__ __launch_bounds__( 64 * kZMarchWavesPerBlock ) void p1_apply_zmarch_preload_kernel( const BrickTask* tasks, int ntasks, int xcd_chunk,
                                                                                               const ZMarchArgs A )
 {
-   zmarch_body< MODE, NY, LZ, EX_AUX, DEC, PFD, T, XS, ST_AUX >( A, tasks, ntasks, xcd_chunk );
+   zmarch_body< MODE, NY, LZ, EX_AUX, DEC, PFD, T, XS, ST_AUX, SRC_AUX >( A, tasks, ntasks, xcd_chunk );
 }
 
 // host: bricks of NY rows x XS outputs x LZ slices, ordered z-chunk, y-chunk, x-chunk (memory order); zs (optional)

@@ -31,14 +31,14 @@ BrickShape g_shape_override{ 0, 0, 0 }; // hyteg_hip_set_apply_shape (tuning kno
 // the three-stream ones; from level 9 on (several generations) 4 x 4, two slices ahead
 inline BrickShape default_shape( int mode, int level, bool f32 )
 {
+   // Chosen from tools/apply_shape_sweep.py with every operand class 2.2 x larger than the Infinity Cache (HBM regime,
+   // profiles/r03_apply_shape_sweep_hbm.txt).  The first sweep of round 3 ran on rings whose SOURCE arrays fitted into that cache
+   // and preferred 2 x 8, one slice ahead, for level-8 Replace (9.15 against 9.50 us); read from HBM that shape is the slower
+   // one (13.3 against 12.5 us).  Levels <= 7: arrays of a few MB, cache-resident in any cycle; levels >= 9: HBM either way.
    if ( level <= 7 )
       return ( mode == APPLY_REPLACE || f32 ) ? BrickShape{ 2, 4, 1 } : BrickShape{ 4, 4, 1 };
    if ( level == 8 )
-   {
-      if ( mode == APPLY_REPLACE || f32 )
-         return BrickShape{ 2, 8, 1 };
-      return mode == APPLY_JACOBI ? BrickShape{ 4, 8, 2 } : BrickShape{ 4, 8, 1 };
-   }
+      return ( mode == APPLY_ADD || mode == APPLY_RESIDUAL ) ? BrickShape{ 4, 8, 1 } : BrickShape{ 4, 8, 2 };
    return BrickShape{ 4, 4, 2 };
 }
 
@@ -83,7 +83,7 @@ int launch_zmarch_shape( void* dst, const T* src, const T* rhs, const T* invdiag
 }
 
 // the shapes compiled in: the defaults and the runners-up of the sweep (so that the sweep can be repeated on another box)
-#define HYTEG_ZM_SHAPES( X ) X( 2, 8, 1 ) X( 4, 8, 2 ) X( 4, 8, 1 ) X( 4, 4, 2 ) X( 4, 4, 1 ) X( 2, 4, 1 )
+#define HYTEG_ZM_SHAPES( X ) X( 2, 8, 1 ) X( 4, 8, 2 ) X( 4, 8, 1 ) X( 4, 4, 2 ) X( 4, 4, 1 ) X( 2, 4, 1 ) X( 8, 4, 2 )
 
 inline bool shape_compiled( const BrickShape& s )
 {

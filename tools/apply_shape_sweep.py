@@ -13,7 +13,7 @@ import torch  # noqa: E402
 
 from hyteg_amd import capi  # noqa: E402
 
-SHAPES = [(2, 8, 1), (4, 8, 2), (4, 8, 1), (4, 4, 2), (4, 4, 1), (2, 4, 1)]  # HYTEG_ZM_SHAPES of p1_apply.hip (2x8x2 was in the first sweep)
+SHAPES = [(2, 8, 1), (4, 8, 2), (4, 8, 1), (4, 4, 2), (4, 4, 1), (2, 4, 1), (8, 4, 2)]  # HYTEG_ZM_SHAPES of p1_apply.hip (2x8x2 was in the first sweep)
 
 
 def main():
@@ -29,7 +29,9 @@ def main():
     for L in args.levels:
         n, inner = capi.cell_size(L), capi.cell_inner_size(L)
         capi.prepare_level(L)
-        nbuf = max(3, int(1.5 * 256 * 2**20) // (3 * n * 8) + 1)
+        # the SOURCE arrays alone (also the float ones) exceed the 256 MiB Infinity Cache 2.2 times: the nontemporal stores of the
+        # destination do not stay in that cache, so a ring that merely exceeds it in total is read from it (round 3)
+        nbuf = max(3, -(-int(2.2 * 256 * 2**20) // (n * 4)))
         nbuf = min(nbuf, 64)  # small levels: cache-resident either way
         A = [torch.rand(n, dtype=torch.float64, device="cuda") for _ in range(nbuf)]
         B = [torch.rand(n, dtype=torch.float64, device="cuda") for _ in range(nbuf)]

@@ -71,7 +71,9 @@ def main():
     nc = capi.cell_size(L - 1)
     stream = torch.cuda.current_stream()
     sh = stream.cuda_stream
-    nbuf = max(2, int(1.5 * 256 * 2**20) // (3 * n * 8) + 1)
+    # every array class (sources, destinations, third operands) alone exceeds the 256 MiB Infinity Cache 2.2 times: a ring that only
+    # exceeds it in total is READ from that cache when the destination is written with nontemporal stores (round 3)
+    nbuf = max(2, -(-int(2.2 * 256 * 2**20) // (n * 8)))
     A = [torch.rand(n, dtype=torch.float64, device="cuda") for _ in range(nbuf)]
     B = [torch.rand(n, dtype=torch.float64, device="cuda") for _ in range(nbuf)]
     Cc = [torch.rand(n, dtype=torch.float64, device="cuda") for _ in range(nbuf)]
@@ -120,9 +122,9 @@ def main():
     timeit("prolongate Replace (coarse L-1 -> fine L)", lambda k: capi.p1_prolongate_cell(p(Co, k), p(B, k), L - 1, ones, 0, sh),
            8 * (n + nc), n)
     # float32 instantiations: algorithmic bytes halve
-    Af = [t.to(torch.float32) for t in A[:max(2, nbuf // 2)]]
-    Bf = [t.to(torch.float32) for t in B[:max(2, nbuf // 2)]]
-    Cf = [t.to(torch.float32) for t in Cc[:max(2, nbuf // 2)]]
+    Af = [t.to(torch.float32) for t in A] + [torch.rand(n, dtype=torch.float32, device="cuda") for _ in range(nbuf)]  # 2 nbuf: half the bytes
+    Bf = [t.to(torch.float32) for t in B] + [torch.rand(n, dtype=torch.float32, device="cuda") for _ in range(nbuf)]
+    Cf = [t.to(torch.float32) for t in Cc] + [torch.rand(n, dtype=torch.float32, device="cuda") for _ in range(nbuf)]
     pf = lambda t, k: t[k % len(t)].data_ptr()  # noqa: E731
     timeit("apply Replace, float32", lambda k: capi.p1_apply_cell_f32(pf(Bf, k), pf(Af, k), L, w, 0, sh), 8 * inner, inner)
     timeit("Jacobi fused, float32 (scalar inverse diagonal)",

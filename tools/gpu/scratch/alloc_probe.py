@@ -36,11 +36,14 @@ def ring_exact_interleaved_all_src_first():
 def ring_rounded():
     r = -(-n * 8 // MB2) * MB2
     return [(hmalloc(r), hmalloc(r)) for _ in range(nbuf)], None
-def ring_arena(pad):
+def ring_arena(pad, m=None):
+    m = m or nbuf
     r = -(-n * 8 // MB2) * MB2 + pad
-    base = hmalloc(2 * nbuf * r + MB2)
+    base = hmalloc(2 * m * r + MB2)
     b = -(-base // MB2) * MB2
-    return [(b + (2 * k) * r, b + (2 * k + 1) * r) for k in range(nbuf)], None
+    return [(b + (2 * k) * r, b + (2 * k + 1) * r) for k in range(m)], None
+def ring_exact_m(m):
+    return [(hmalloc(n * 8), hmalloc(n * 8)) for _ in range(m)], None
 def ring_torch(m=None):
     m = m or nbuf
     keep = [(torch.empty(n, dtype=torch.float64, device="cuda"), torch.empty(n, dtype=torch.float64, device="cuda")) for _ in range(m)]
@@ -85,6 +88,11 @@ for name, mk in [("host layer: P1Function arrays (bench.py's ring)", ring_host),
                  ("torch.empty, ring of 6 pairs (275 MB: the shape sweep's)", lambda: ring_torch(6)),
                  ("torch.empty, ring of 3 pairs (137 MB < Infinity Cache)", lambda: ring_torch(3)),
                  ("torch.empty, ring of 18 pairs (824 MB)", lambda: ring_torch(18)),
+                 ("hipMalloc per array, ring of 18 pairs", lambda: ring_exact_m(18)),
+                 ("ONE arena of 18 pairs (864 MB in one hipMalloc)", lambda: ring_arena(0, 18)),
+                 ("ONE arena of 36 pairs (1.7 GB in one hipMalloc)", lambda: ring_arena(0, 36)),
+                 ("torch.empty, ring of 12 pairs (550 MB)", lambda: ring_torch(12)),
+                 ("torch.empty, ring of 14 pairs (641 MB)", lambda: ring_torch(14)),
                  ("hipMalloc(n*8) per array again", ring_exact),
                  ("host layer: P1Function arrays again", ring_host)]:
     pairs, keep = mk()
