@@ -312,7 +312,7 @@ def main():
                 copies.append(region(copy_steps)[1])
         # the ring of rounds 1-2 (sources fit into the Infinity Cache), for continuity: NOT the headline
         small.clear()
-        if world == 1:
+        if world == 1 and os.environ.get("HYTEG_BENCH_SMALL_RING", "1") != "0":
             apply_steps_small_ring(0, 4 * nbuf_small)
             for r in range(min(9, max(1, args.regions))):
                 small.append(region(apply_steps_small_ring)[1])

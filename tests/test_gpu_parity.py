@@ -57,7 +57,7 @@ def test_apply_replace_and_add(env, level, tet):
         assert _rel(got[m], ref[m]) < TOL
 
 
-COMPILED_SHAPES = [(2, 8, 1), (4, 8, 2), (4, 8, 1), (4, 4, 2), (4, 4, 1), (2, 4, 1)]  # HYTEG_ZM_SHAPES of p1_apply.hip
+COMPILED_SHAPES = [(2, 8, 1), (4, 8, 2), (4, 8, 1), (4, 4, 2), (4, 4, 1), (2, 4, 1), (8, 4, 2)]  # HYTEG_ZM_SHAPES of p1_apply.hip
 
 
 @pytest.mark.parametrize("level", [3, 6, 8])

@@ -158,7 +158,7 @@ def main():
     nv2, ne2 = capi.cell_size(L2), capi.p2_edge_array_size(L2)
     p2op = host.P2ElementwiseLaplaceOperator(st, L2, L2)  # element matrices (kernel input) from the host layer's P2LaplaceForm
     em = torch.from_numpy(capi.p2_build_operator_table(p2op.element_matrices(L2))).to("cuda")
-    nb2 = max(2, int(1.5 * 256 * 2**20) // (2 * (nv2 + ne2) * 8) + 1)
+    nb2 = max(2, -(-int(2.2 * 256 * 2**20) // ((nv2 + ne2) * 8)))  # the sources alone 2.2 x the Infinity Cache
     SV = [torch.rand(nv2, dtype=torch.float64, device="cuda") for _ in range(nb2)]
     SE = [torch.rand(ne2, dtype=torch.float64, device="cuda") for _ in range(nb2)]
     DV = [torch.zeros(nv2, dtype=torch.float64, device="cuda") for _ in range(nb2)]

@@ -5,6 +5,9 @@
 # Outputs under gpurun_out/prof_bench and gpurun_out/pmc_bench; post-process with tools/pmc_traffic.py.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_bench; P=$R/gpurun_out/pmc_bench; mkdir -p $O $P
+# HYTEG_BENCH_SMALL_RING=0: without the extra regions on the Infinity-Cache-sized ring, so that every launch of the apply kernel in the
+# trace is an HBM-regime launch and the average of the stats file is the figure bench.py reports
+export HYTEG_BENCH_SMALL_RING=0
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 $R/bench.py --steps 500 --warmup 50 --regions 5 --no-cpu-baseline > $O/bench.log 2>&1 || echo "stats pass failed"
 for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   N=$(echo $C | tr " " "_" | cut -c1-24)
