@@ -5,8 +5,9 @@
 
 A "step" is ONE P1ConstantLaplaceOperator::apply(src, dst, level, Inner, Replace) through the C++ host layer
 (hyteg_amd/host, the mirror of HyTeG's operator API), which calls the HIP kernels through the C-ABI.  Inputs are
-resident in HBM before the timed region; a ring of function pairs larger than the 256 MiB Infinity Cache is cycled
-so that every apply streams from HBM.  For N > 1 (launched by torch.distributed.run, one rank per GPU) the mesh has
+resident in HBM before the timed region; a ring of function pairs whose SOURCE arrays alone are 2.2 x the 256 MiB
+Infinity Cache is cycled so that every apply streams from HBM (a ring that exceeds the cache only in total is read
+from it: the destination's nontemporal stores do not occupy the cache -- see the comment at the ring below).  For N > 1 (launched by torch.distributed.run, one rank per GPU) the mesh has
 N macro-cells, one per GPU (weak scaling); the shares of the macro-face/edge/vertex DoFs the cells have in common
 are exchanged over RCCL inside every apply, overlapped with the interior kernel.  Rank 0 prints ONE JSON line with
 the whole-job aggregate.
