@@ -134,7 +134,11 @@ int launch_apply( double* dst, const double* src, const double* rhs, const doubl
 {
    // z-march register kernel whenever byte offsets fit the 32-bit buffer addressing (level <= 10);
    // the LDS-tiled kernel (pointer addressing) covers level 11
-   if ( tet64( ( 1 << level ) + 1 ) * 8 < ( (int64_t) 1 << 31 ) )
+   static const bool forceTiled = [] {
+      const char* e = getenv( "HYTEG_HIP_APPLY_LDS_TILED" ); // measurement switch: the LDS-tiled kernel of round 1 at every level
+      return e && e[0] == '1';
+   }();
+   if ( !forceTiled && tet64( ( 1 << level ) + 1 ) * 8 < ( (int64_t) 1 << 31 ) )
       return launch_zmarch< MODE >( dst, src, rhs, invdiag, level, w, relax, stream );
 
    TileTable tt;
