@@ -70,6 +70,12 @@ int launch_zmarch_shape( void* dst, const T* src, const T* rhs, const T* invdiag
    int nblocks = ( bt.count + kZMarchWavesPerBlock - 1 ) / kZMarchWavesPerBlock;
    nblocks     = ( nblocks + 7 ) & ~7;
    A.xcd_chunk = nblocks / 8;
+   static const bool xcdSlabs = [] {
+      const char* e = getenv( "HYTEG_HIP_APPLY_XCD_SLABS" ); // measurement switch: 0 = workgroups in launch order (XCDs interleaved brick by brick)
+      return !( e && e[0] == '0' );
+   }();
+   if ( !xcdSlabs )
+      A.xcd_chunk = 0;
    // dst of Add is read exactly once per element and written right after: nontemporal load (18.6 -> 17.2 us).  rhs /
    // inverse diagonal of Jacobi are re-read by the next sweep of the smoother and stay plain (nontemporal: 12.4 -> 17.6 us
    // when they are still in the Infinity Cache, -2% when they are not).
