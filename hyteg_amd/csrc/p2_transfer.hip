@@ -211,27 +211,29 @@ __device__ inline bool dof_exists( int N, int kind, int x, int y, int z )
    const int W = width_of_kind( N, kind );
    return x >= 0 && y >= 0 && z >= 0 && x + y + z <= W - 1;
 }
-__device__ inline int64_t dof_offset( int N, int kind, int x, int y, int z )
+// 32-bit index arithmetic throughout (round 3; levels <= 9: the largest index is 6 tet(512) + tet(511) < 2^31): the 64-bit
+// products of the first version were a large part of the ~600 instructions a fine DoF cost
+__device__ inline int dof_offset( int N, int kind, int x, int y, int z )
 {
    const int W = width_of_kind( N, kind );
-   return ( kind == 0 ? 0 : (int64_t) ( kind - 1 ) * tet64( N - 1 ) ) + cell_index( W, x, y, z );
+   return ( kind == 0 ? 0 : ( kind - 1 ) * (int) tet32( (unsigned) ( N - 1 ) ) ) + cell_index( W, x, y, z );
 }
 // slice z of entry i of a tetrahedral array of width W
-__device__ inline int slice_of( int W, int64_t i )
+__device__ inline int slice_of( int W, int i )
 {
-   const int64_t rest = tet64( W ) - i;
-   int           m    = (int) cbrtf( 6.0f * (float) rest );
-   m                  = m < 1 ? 1 : ( m > W ? W : m );
-   while ( m > 1 && tet64( m - 1 ) >= rest )
+   const unsigned rest = tet32( (unsigned) W ) - (unsigned) i;
+   int            m    = (int) cbrtf( 6.0f * (float) rest );
+   m                   = m < 1 ? 1 : ( m > W ? W : m );
+   while ( m > 1 && tet32( (unsigned) ( m - 1 ) ) >= rest )
       --m;
-   while ( tet64( m ) < rest )
+   while ( tet32( (unsigned) m ) < rest )
       ++m;
    return W - m;
 }
-__device__ inline void decode( int W, int64_t i, int& x, int& y, int& z )
+__device__ inline void decode( int W, int i, int& x, int& y, int& z )
 {
    z           = slice_of( W, i );
-   const int j = (int) ( i - ( tet64( W ) - tet64( W - z ) ) );
+   const int j = i - (int) ( tet32( (unsigned) W ) - tet32( (unsigned) ( W - z ) ) );
    y           = row_of( W - z, j );
    x           = j - row_start( W - z, y );
 }
@@ -291,8 +293,8 @@ __global__ __launch_bounds__( kThreads ) void p2_prolongate_kernel( const P2Tran
 {
    const int     kind = blockIdx.y;
    const int     W    = width_of_kind( A.Nf, kind );
-   const int64_t i    = (int64_t) blockIdx.x * kThreads + threadIdx.x;
-   if ( W <= 0 || i >= tet64( W ) )
+   const int i    = (int) ( blockIdx.x * kThreads + threadIdx.x );
+   if ( W <= 0 || i >= (int) tet32( (unsigned) W ) )
       return;
    int x, y, z;
    decode( W, i, x, y, z );
@@ -300,16 +302,18 @@ __global__ __launch_bounds__( kThreads ) void p2_prolongate_kernel( const P2Tran
       return;
    const int     pat = kind * 8 + ( x & 1 ) + 2 * ( y & 1 ) + 4 * ( z & 1 );
    const int     bx = x >> 1, by = y >> 1, bz = z >> 1;
-   const TEntry* e   = A.T->prolong[pat];
-   const int     n   = A.T->nprolong[pat];
-   double        acc = 0.0;
+   const TEntry* e = A.T->prolong[pat];
+   const int n   = A.T->nprolong[pat];
+   double    acc = 0.0;
+   // one term per iteration: neighbouring lanes have different patterns (1 to 10 terms, 5 on average); padding every lane to ten
+   // terms with all loads in flight (50.7 us) or to groups of four (49.0 us) costs more loads than it saves waiting (44.0 us)
    for ( int k = 0; k < n; ++k )
    {
-      const int     kc  = e[k].kind;
-      const int64_t off = dof_offset( A.Nc, kc, bx + e[k].dx, by + e[k].dy, bz + e[k].dz );
-      acc               = fma( e[k].w, kc == 0 ? A.srcV[off] : A.srcE[off], acc );
+      const int kc  = e[k].kind;
+      const int off = dof_offset( A.Nc, kc, bx + e[k].dx, by + e[k].dy, bz + e[k].dz );
+      acc           = fma( e[k].w, kc == 0 ? A.srcV[off] : A.srcE[off], acc );
    }
-   double* out = kind == 0 ? A.dstV + i : A.dstE + (int64_t) ( kind - 1 ) * tet64( A.Nf - 1 ) + i;
+   double* out = kind == 0 ? A.dstV + i : A.dstE + ( kind - 1 ) * (int) tet32( (unsigned) ( A.Nf - 1 ) ) + i;
    *out        = A.update == HYTEG_HIP_ADD ? *out + acc : acc;
 }
 
@@ -318,8 +322,8 @@ __global__ __launch_bounds__( kThreads ) void p2_restrict_kernel( const P2Transf
 {
    const int     kind = blockIdx.y;
    const int     W    = width_of_kind( A.Nc, kind );
-   const int64_t i    = (int64_t) blockIdx.x * kThreads + threadIdx.x;
-   if ( W <= 0 || i >= tet64( W ) )
+   const int i    = (int) ( blockIdx.x * kThreads + threadIdx.x );
+   if ( W <= 0 || i >= (int) tet32( (unsigned) W ) )
       return;
    int x, y, z;
    decode( W, i, x, y, z );
@@ -328,18 +332,32 @@ __global__ __launch_bounds__( kThreads ) void p2_restrict_kernel( const P2Transf
    const TEntry* e   = A.T->restrict_[kind];
    const int     n   = A.T->nrestrict[kind];
    double        acc = 0.0;
-   for ( int k = 0; k < n; ++k )
+   // chunks of kChunk terms with all their loads in flight together (round 3; the table is padded with zero entries -- weight 0,
+   // the fine vertex ( 2x, 2y, 2z ) -- up to kMaxRestrict, a multiple of kChunk).  A fine DoF outside the macro-cell contributes
+   // weight 0 times entry 0 of the array: an exact 0, the bits of the loop that skipped it.
+   constexpr int kChunk = 16;
+   static_assert( kMaxRestrict % kChunk == 0, "restriction table padding" );
+   for ( int k0 = 0; k0 < n; k0 += kChunk )
    {
-      const int kf = e[k].kind;
-      const int fx = 2 * x + e[k].dx, fy = 2 * y + e[k].dy, fz = 2 * z + e[k].dz;
-      if ( !dof_exists( A.Nf, kf, fx, fy, fz ) )
-         continue;
-      const int     cls   = dof_class( A.Nf, kf, fx, fy, fz );
-      const double  scale = cls == 14 ? 1.0 : A.nncInv.inv[cls];
-      const int64_t off   = dof_offset( A.Nf, kf, fx, fy, fz );
-      acc                 = fma( e[k].w * scale, kf == 0 ? A.srcV[off] : A.srcE[off], acc );
+      double v[kChunk], ws[kChunk];
+#pragma unroll
+      for ( int j = 0; j < kChunk; ++j )
+      {
+         const TEntry t  = e[k0 + j];
+         const int    kf = t.kind;
+         const int    fx = 2 * x + t.dx, fy = 2 * y + t.dy, fz = 2 * z + t.dz;
+         const bool   ex = dof_exists( A.Nf, kf, fx, fy, fz );
+         const int    cls   = dof_class( A.Nf, kf, fx, fy, fz );
+         const double scale = cls == 14 ? 1.0 : A.nncInv.inv[cls];
+         const int    off   = ex ? dof_offset( A.Nf, kf, fx, fy, fz ) : 0;
+         v[j]               = kf == 0 ? A.srcV[off] : A.srcE[off];
+         ws[j]              = ex ? t.w * scale : 0.0;
+      }
+#pragma unroll
+      for ( int j = 0; j < kChunk; ++j )
+         acc = fma( ws[j], v[j], acc );
    }
-   double* out = kind == 0 ? A.dstV + i : A.dstE + (int64_t) ( kind - 1 ) * tet64( A.Nc - 1 ) + i;
+   double* out = kind == 0 ? A.dstV + i : A.dstE + ( kind - 1 ) * (int) tet32( (unsigned) ( A.Nc - 1 ) ) + i;
    *out        = acc;
 }
 
