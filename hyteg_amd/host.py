@@ -60,6 +60,23 @@ SIGNATURES = {
     "hyteg_host_function_sum_shared": (_i, [_vp, _i, _i]),
     "hyteg_host_function_sync_shared": (_i, [_vp, _i, _i]),
     "hyteg_host_function_set_all_inner": (_i, [_vp, _i]),
+    "hyteg_host_th_function_create": (_i, [_vp, C.c_char_p, _i, _i, C.POINTER(_vp)]),
+    "hyteg_host_th_function_destroy": (_i, [_vp]),
+    "hyteg_host_th_function_velocity": (_i, [_vp, _i, C.POINTER(_vp)]),
+    "hyteg_host_th_function_pressure": (_i, [_vp, C.POINTER(_vp)]),
+    "hyteg_host_th_function_assign": (_i, [_vp, _i, _dp, C.POINTER(_vp), _i, _i]),
+    "hyteg_host_th_function_interpolate_constant": (_i, [_vp, _d, _i, _i]),
+    "hyteg_host_th_function_dot": (_i, [_vp, _vp, _i, _i, C.POINTER(_d)]),
+    "hyteg_host_th_operator_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "hyteg_host_th_operator_destroy": (_i, [_vp]),
+    "hyteg_host_th_operator_apply": (_i, [_vp, _vp, _vp, _i, _i]),
+    "hyteg_host_th_operator_apply_block": (_i, [_vp, _i, _vp, _vp, _i, _i]),
+    "hyteg_host_th_gmg_create": (_i, [_vp, _i, _i, _d, _i, _i, _i, _i, _d, C.POINTER(_vp)]),
+    "hyteg_host_th_minres_create": (_i, [_vp, _i, _i, _i, _d, C.POINTER(_vp)]),
+    "hyteg_host_th_solver_solve": (_i, [_vp, _vp, _vp, _vp, _i]),
+    "hyteg_host_th_solver_destroy": (_i, [_vp]),
+    "hyteg_host_th_project_pressure_mean": (_i, [_vp, _i]),
+    "hyteg_host_th_form_element_matrix": (_i, [_i, _i, _dp, _dp]),
     "hyteg_host_stokes_function_create": (_i, [_vp, C.c_char_p, _i, _i, C.POINTER(_vp)]),
     "hyteg_host_stokes_function_destroy": (_i, [_vp]),
     "hyteg_host_stokes_function_component": (_i, [_vp, _i, C.POINTER(_vp)]),
@@ -680,8 +697,12 @@ class StokesSolver:
 class P2Function:
     """hyteg::P2Function<double>: vertex DoFs (the P1 cell array) + edge DoFs (EdgeDoFIndexing.hpp layout)"""
 
-    def __init__(self, storage: Storage, name: str, min_level: int, max_level: int):
+    def __init__(self, storage: Storage, name: str, min_level: int, max_level: int, _borrowed=None):
         self.storage = storage
+        self._borrowed = _borrowed is not None
+        if _borrowed is not None:
+            self.h = _borrowed
+            return
         h = _vp()
         _ck(lib().hyteg_host_p2function_create(storage.h, name.encode(), min_level, max_level, C.byref(h)), "P2Function")
         self.h = h
@@ -724,9 +745,9 @@ class P2Function:
         return r.value
 
     def close(self):
-        if self.h:
+        if self.h and not self._borrowed:
             lib().hyteg_host_p2function_destroy(self.h)
-            self.h = None
+        self.h = None
 
 
 def p2_prolongate(f: "P2Function", source_level, flag, add=False):
@@ -814,3 +835,101 @@ class P2ConstantLaplaceOperator(P2ElementwiseLaplaceOperator):
         out, n = np.empty(512), C.c_int(0)
         _ck(lib().hyteg_host_p2operator_constant_stencils(self.h, cell, level, out.ctypes.data_as(_dp), 512, C.byref(n)), "constant_stencils")
         return out[:n.value].copy()
+
+
+class TaylorHoodFunction:
+    """hyteg::P2P1TaylorHoodFunction<double>: three P2 velocity components and a P1 pressure (all-inner boundary condition)"""
+
+    def __init__(self, storage: Storage, name: str, min_level: int, max_level: int):
+        self.storage = storage
+        h = _vp()
+        _ck(lib().hyteg_host_th_function_create(storage.h, name.encode(), min_level, max_level, C.byref(h)), "TaylorHoodFunction")
+        self.h = h
+        self.velocity = []
+        for k in range(3):
+            c = _vp()
+            _ck(lib().hyteg_host_th_function_velocity(self.h, k, C.byref(c)), "th velocity")
+            self.velocity.append(P2Function(storage, "", min_level, max_level, _borrowed=c))
+        c = _vp()
+        _ck(lib().hyteg_host_th_function_pressure(self.h, C.byref(c)), "th pressure")
+        self.pressure = P1Function(storage, "", min_level, max_level, _borrowed=c)
+
+    def assign(self, scalars, funcs, level, flag=All):
+        n = len(funcs)
+        sc = (_d * n)(*[float(v) for v in scalars])
+        hs = (_vp * n)(*[f.h for f in funcs])
+        _ck(lib().hyteg_host_th_function_assign(self.h, n, sc, hs, level, flag), "th assign")
+
+    def interpolate(self, value, level, flag=All):
+        _ck(lib().hyteg_host_th_function_interpolate_constant(self.h, float(value), level, flag), "th interpolate")
+
+    def dot(self, other, level, flag=All):
+        r = _d()
+        _ck(lib().hyteg_host_th_function_dot(self.h, other.h, level, flag, C.byref(r)), "th dot")
+        return r.value
+
+    def project_pressure_mean(self, level):
+        _ck(lib().hyteg_host_th_project_pressure_mean(self.h, level), "th projectMean")
+
+    def close(self):
+        if self.h:
+            lib().hyteg_host_th_function_destroy(self.h)
+            self.h = None
+
+
+class TaylorHoodStokesOperator:
+    """hyteg::P2P1TaylorHoodStokesOperator"""
+
+    def __init__(self, storage: Storage, min_level: int, max_level: int):
+        self.storage = storage
+        h = _vp()
+        _ck(lib().hyteg_host_th_operator_create(storage.h, min_level, max_level, C.byref(h)), "TaylorHoodStokesOperator")
+        self.h = h
+
+    def apply(self, src, dst, level, flag):
+        _ck(lib().hyteg_host_th_operator_apply(self.h, src.h, dst.h, level, flag), "th apply")
+
+    def apply_div(self, src, dst, level, flag):
+        _ck(lib().hyteg_host_th_operator_apply_block(self.h, 0, src.h, dst.h, level, flag), "th div")
+
+    def apply_divt(self, src, dst, level, flag):
+        _ck(lib().hyteg_host_th_operator_apply_block(self.h, 1, src.h, dst.h, level, flag), "th divT")
+
+    def close(self):
+        if self.h:
+            lib().hyteg_host_th_operator_destroy(self.h)
+            self.h = None
+
+
+class TaylorHoodSolver:
+    def __init__(self, h):
+        self.h = h
+
+    @classmethod
+    def gmg(cls, storage, min_level, max_level, uzawa_relax=0.4, pre=3, post=3, increment=0, coarse_max_iter=200, coarse_rel_tol=1e-12):
+        h = _vp()
+        _ck(lib().hyteg_host_th_gmg_create(storage.h, min_level, max_level, float(uzawa_relax), pre, post, increment, coarse_max_iter,
+                                           float(coarse_rel_tol), C.byref(h)), "th gmg")
+        return cls(h)
+
+    @classmethod
+    def minres(cls, storage, min_level, max_level, max_iter=100, rel_tol=1e-10):
+        h = _vp()
+        _ck(lib().hyteg_host_th_minres_create(storage.h, min_level, max_level, max_iter, float(rel_tol), C.byref(h)), "th minres")
+        return cls(h)
+
+    def solve(self, op, x, b, level):
+        _ck(lib().hyteg_host_th_solver_solve(self.h, op.h, x.h, b.h, level), "th solve")
+
+    def close(self):
+        if self.h:
+            lib().hyteg_host_th_solver_destroy(self.h)
+            self.h = None
+
+
+def taylor_hood_form_element_matrix(which, k, coords):
+    """10 x 10 padded element matrix of a mixed block: which 0 = div (P2 -> P1), 1 = divT (P1 -> P2); component k"""
+    co = np.ascontiguousarray(coords, dtype=np.float64).reshape(12)
+    out = np.empty(100)
+    _ck(lib().hyteg_host_th_form_element_matrix(which, k, co.ctypes.data_as(_dp), out.ctypes.data_as(_dp)), "th_form_element_matrix")
+    return out.reshape(10, 10)

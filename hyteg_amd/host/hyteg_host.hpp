@@ -32,3 +32,4 @@
 #include "gridtransfer.hpp"
 #include "solvers.hpp"
 #include "stokes.hpp"
+#include "taylorhood.hpp"

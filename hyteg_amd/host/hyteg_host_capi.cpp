@@ -955,3 +955,148 @@ HYTEG_HOST_API int hyteg_host_p2_cg_solve( hh_storage_t s, hh_p2operator_t op, h
    } );
 }
 }
+
+
+/* ---- P2-P1 Taylor-Hood Stokes (taylorhood.hpp) ---- */
+namespace {
+struct THFunctionH
+{
+   std::shared_ptr< P2P1TaylorHoodFunction< double > > p;
+   P2FunctionH                                         comp[3]; // aliasing views of the velocity components
+   FunctionH                                           pressure;
+};
+struct THOperatorH
+{
+   std::shared_ptr< P2P1TaylorHoodStokesOperator > p;
+};
+struct THSolverH
+{
+   std::shared_ptr< Solver< P2P1TaylorHoodStokesOperator > > p;
+};
+P2P1TaylorHoodFunction< double >& FT( hh_th_function_t f ) { return *static_cast< THFunctionH* >( f )->p; }
+} // namespace
+
+HYTEG_HOST_API int hyteg_host_th_function_create( hh_storage_t s, const char* name, int minL, int maxL, hh_th_function_t* out )
+{
+   return guarded( [&] {
+      auto* h = new THFunctionH{};
+      h->p    = std::make_shared< P2P1TaylorHoodFunction< double > >( name, static_cast< StorageH* >( s )->p, (uint_t) minL, (uint_t) maxL );
+      *out    = h;
+   } );
+}
+HYTEG_HOST_API int hyteg_host_th_function_destroy( hh_th_function_t f ) { return guarded( [&] { delete static_cast< THFunctionH* >( f ); } ); }
+HYTEG_HOST_API int hyteg_host_th_function_velocity( hh_th_function_t f, int k, hh_p2function_t* out )
+{
+   return guarded( [&] {
+      auto* h = static_cast< THFunctionH* >( f );
+      if ( k < 0 || k > 2 )
+         throw std::runtime_error( "th_function_velocity: k = 0, 1, 2" );
+      const P2Function< double >& c = h->p->uvw()[(uint_t) k];
+      h->comp[k].p                  = std::shared_ptr< P2Function< double > >( h->p, const_cast< P2Function< double >* >( &c ) );
+      *out                          = &h->comp[k];
+   } );
+}
+HYTEG_HOST_API int hyteg_host_th_function_pressure( hh_th_function_t f, hh_function_t* out )
+{
+   return guarded( [&] {
+      auto* h       = static_cast< THFunctionH* >( f );
+      h->pressure.p = std::shared_ptr< P1Function< double > >( h->p, const_cast< P1Function< double >* >( &h->p->p() ) );
+      *out          = &h->pressure;
+   } );
+}
+HYTEG_HOST_API int hyteg_host_th_function_assign( hh_th_function_t dst, int n, const double* scalars, const hh_th_function_t* fs, int level, int flag )
+{
+   return guarded( [&] {
+      std::vector< std::reference_wrapper< const P2P1TaylorHoodFunction< double > > > r;
+      for ( int i = 0; i < n; ++i )
+         r.push_back( std::cref( FT( fs[i] ) ) );
+      FT( dst ).assign( std::vector< double >( scalars, scalars + n ), r, (uint_t) level, DoFType( flag ) );
+   } );
+}
+HYTEG_HOST_API int hyteg_host_th_function_interpolate_constant( hh_th_function_t f, double value, int level, int flag )
+{
+   return guarded( [&] { FT( f ).interpolate( value, (uint_t) level, DoFType( flag ) ); } );
+}
+HYTEG_HOST_API int hyteg_host_th_function_dot( hh_th_function_t a, hh_th_function_t b, int level, int flag, double* out )
+{
+   return guarded( [&] { *out = FT( a ).dotGlobal( FT( b ), (uint_t) level, DoFType( flag ) ); } );
+}
+HYTEG_HOST_API int hyteg_host_th_operator_create( hh_storage_t s, int minL, int maxL, hh_th_operator_t* out )
+{
+   return guarded( [&] {
+      *out = new THOperatorH{ std::make_shared< P2P1TaylorHoodStokesOperator >( static_cast< StorageH* >( s )->p, (uint_t) minL, (uint_t) maxL ) };
+   } );
+}
+HYTEG_HOST_API int hyteg_host_th_operator_destroy( hh_th_operator_t op ) { return guarded( [&] { delete static_cast< THOperatorH* >( op ); } ); }
+HYTEG_HOST_API int hyteg_host_th_operator_apply( hh_th_operator_t op, hh_th_function_t src, hh_th_function_t dst, int level, int flag )
+{
+   return guarded( [&] { static_cast< THOperatorH* >( op )->p->apply( FT( src ), FT( dst ), (uint_t) level, DoFType( flag ) ); } );
+}
+// single blocks, for the parity tests: which = 0 div (velocity of src -> pressure of dst), 1 divT (pressure of src -> velocity of dst)
+HYTEG_HOST_API int hyteg_host_th_operator_apply_block( hh_th_operator_t op, int which, hh_th_function_t src, hh_th_function_t dst, int level, int flag )
+{
+   return guarded( [&] {
+      auto& A = *static_cast< THOperatorH* >( op )->p;
+      if ( which == 0 )
+         A.div.apply( FT( src ).uvw(), FT( dst ).p(), (uint_t) level, DoFType( flag ), Replace );
+      else if ( which == 1 )
+         A.divT.apply( FT( src ).p(), FT( dst ).uvw(), (uint_t) level, DoFType( flag ), Replace );
+      else
+         throw std::runtime_error( "th_operator_apply_block: which = 0 (div) or 1 (divT)" );
+   } );
+}
+// GeometricMultigridSolver< P2P1TaylorHoodStokesOperator > as tests/hyteg/convergence/P2P1Stokes3DUzawaConvergenceTest.cpp:150-163 composes it:
+// UzawaSmoother( relax ) over StokesVelocityBlockBlockDiagonalPreconditioner( GaussSeidelSmoother ), P2P1StokesToP2P1Stokes transfer with
+// projectMean after the restriction, V( pre, post ) + increment; coarse grid: MinResSolver preconditioned with
+// StokesPressureBlockPreconditioner< ., P1LumpedInvMassOperator > (the reference's test uses PETSc's LU there)
+HYTEG_HOST_API int hyteg_host_th_gmg_create( hh_storage_t s, int minL, int maxL, double uzawa_relax, int pre, int post, int increment,
+                                             int coarse_max_iter, double coarse_rel_tol, hh_th_solver_t* out )
+{
+   return guarded( [&] {
+      using Op     = P2P1TaylorHoodStokesOperator;
+      auto storage = static_cast< StorageH* >( s )->p;
+      auto gs      = std::make_shared< GaussSeidelSmoother< P2ConstantLaplaceOperator > >();
+      auto vel     = std::make_shared< TaylorHoodVelocityBlockPreconditioner >( gs );
+      auto uzawa   = std::make_shared< UzawaSmoother< Op > >( storage, vel, (uint_t) minL, (uint_t) maxL, uzawa_relax );
+      auto prec    = std::make_shared< StokesPressureBlockPreconditioner< Op, P1LumpedInvMassOperator > >( storage, (uint_t) minL, (uint_t) minL );
+      auto coarse  = std::make_shared< MinResSolver< Op > >( storage, (uint_t) minL, (uint_t) minL, (uint_t) coarse_max_iter, coarse_rel_tol, 1e-16, prec );
+      *out = new THSolverH{ std::make_shared< GeometricMultigridSolver< Op, P2P1StokesToP2P1StokesRestriction, P2P1StokesToP2P1StokesProlongation > >(
+          storage, uzawa, coarse, std::make_shared< P2P1StokesToP2P1StokesRestriction >( true ), std::make_shared< P2P1StokesToP2P1StokesProlongation >(),
+          (uint_t) minL, (uint_t) maxL, (uint_t) pre, (uint_t) post, (uint_t) increment ) };
+   } );
+}
+HYTEG_HOST_API int hyteg_host_th_minres_create( hh_storage_t s, int minL, int maxL, int max_iter, double rel_tol, hh_th_solver_t* out )
+{
+   return guarded( [&] {
+      using Op     = P2P1TaylorHoodStokesOperator;
+      auto storage = static_cast< StorageH* >( s )->p;
+      auto prec    = std::make_shared< StokesPressureBlockPreconditioner< Op, P1LumpedInvMassOperator > >( storage, (uint_t) minL, (uint_t) maxL );
+      *out = new THSolverH{ std::make_shared< MinResSolver< Op > >( storage, (uint_t) minL, (uint_t) maxL, (uint_t) max_iter, rel_tol, 1e-16, prec ) };
+   } );
+}
+HYTEG_HOST_API int hyteg_host_th_solver_solve( hh_th_solver_t solver, hh_th_operator_t op, hh_th_function_t x, hh_th_function_t b, int level )
+{
+   return guarded( [&] { static_cast< THSolverH* >( solver )->p->solve( *static_cast< THOperatorH* >( op )->p, FT( x ), FT( b ), (uint_t) level ); } );
+}
+HYTEG_HOST_API int hyteg_host_th_solver_destroy( hh_th_solver_t solver ) { return guarded( [&] { delete static_cast< THSolverH* >( solver ); } ); }
+HYTEG_HOST_API int hyteg_host_th_project_pressure_mean( hh_th_function_t f, int level )
+{
+   return guarded( [&] { projectMean( FT( f ).p(), (uint_t) level ); } );
+}
+// the 10 x 10 element matrix (FEniCS ordering) a mixed block hands to the P2 kernel: which = 0 div (edge rows zero), 1 divT (edge
+// columns zero), component k, tetrahedron coords[4][3] -- for the pins against the reference's FEniCS forms
+HYTEG_HOST_API int hyteg_host_th_form_element_matrix( int which, int k, const double* coords12, double* out100 )
+{
+   return guarded( [&] {
+      std::array< Point3D, 4 > c;
+      for ( int v = 0; v < 4; ++v )
+         for ( int r = 0; r < 3; ++r )
+            c[v][r] = coords12[3 * v + r];
+      if ( k < 0 || k > 2 || which < 0 || which > 1 )
+         throw std::runtime_error( "th_form_element_matrix: which = 0, 1; k = 0, 1, 2" );
+      if ( which == 0 )
+         k == 0 ? forms::P2ToP1DivForm< 0 >::integrateAll( c, out100 ) : ( k == 1 ? forms::P2ToP1DivForm< 1 >::integrateAll( c, out100 ) : forms::P2ToP1DivForm< 2 >::integrateAll( c, out100 ) );
+      else
+         k == 0 ? forms::P1ToP2DivTForm< 0 >::integrateAll( c, out100 ) : ( k == 1 ? forms::P1ToP2DivTForm< 1 >::integrateAll( c, out100 ) : forms::P1ToP2DivTForm< 2 >::integrateAll( c, out100 ) );
+   } );
+}

@@ -274,6 +274,7 @@ class P1P1StokesOperator
    using srcType            = P1StokesFunction< double >;
    using dstType            = P1StokesFunction< double >;
    using VelocityOperator_T = P1ConstantLaplaceOperator;
+   static constexpr bool hasPspgBlock = true; // has_pspg_block< P1P1StokesOperator >, P1P1StokesOperator.hpp:95
 
    P1P1StokesOperator( const std::shared_ptr< PrimitiveStorage >& storage, uint_t minLevel, uint_t maxLevel )
    : lapl( storage, minLevel, maxLevel )
@@ -367,8 +368,16 @@ class UzawaSmoother : public Solver< OperatorType >
       r_.uvw().assign( { 1.0, -1.0 }, { b.uvw(), r_.uvw() }, level, flag_ );
       for ( uint_t i = 0; i < numGSIterationsVelocity_; ++i )
          velocitySmoother_->solve( A, x, r_, level );
-      A.pspg.apply( x.p(), r_.p(), level, flag_, Replace );
-      A.div.apply( x.uvw(), r_.p(), level, flag_, Add );
+      // has_pspg_block (composites/StokesOperatorTraits.hpp): with a stabilised operator the pressure residual contains C p
+      // (UzawaSmoother.hpp:262-288), without one -- Taylor-Hood -- it is b.p - div u (:390-450); both scale it with the inverse
+      // diagonal of the PSPG operator
+      if constexpr ( OperatorType::hasPspgBlock )
+      {
+         A.pspg.apply( x.p(), r_.p(), level, flag_, Replace );
+         A.div.apply( x.uvw(), r_.p(), level, flag_, Add );
+      }
+      else
+         A.div.apply( x.uvw(), r_.p(), level, flag_, Replace );
       r_.p().assign( { 1.0, -1.0 }, { b.p(), r_.p() }, level, flag_ );
       r_.p().assign( { relaxParam_ }, { r_.p() }, level, flag_ );
       A.pspg_inv_diag_.apply( r_.p(), x.p(), level, flag_, Add );

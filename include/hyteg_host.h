@@ -255,6 +255,38 @@ HYTEG_HOST_API int hyteg_host_p2_solver_destroy( hh_p2solver_t solver );
 HYTEG_HOST_API int hyteg_host_p2_cg_solve( hh_storage_t s, hh_p2operator_t op, hh_p2function_t x, hh_p2function_t b, int level, int max_iter,
                                            double tol, int* iterations );
 
+/* ---- P2-P1 Taylor-Hood Stokes (BASELINE config 5's "P2-P1 Stokes block operator"; hyteg_amd/host/taylorhood.hpp) ----
+ * P2P1TaylorHoodFunction (composites/P2P1TaylorHoodFunction.hpp): three P2 velocity components + a P1 pressure (all-inner boundary
+ * condition); P2P1TaylorHoodStokesOperator::apply (mixed_operator/P2P1TaylorHoodStokesOperator.hpp:55-64): Laplace on the velocity,
+ * divT (P1 -> P2) added, div (P2 -> P1) into the pressure.  The handles returned by _velocity / _pressure are views that live as
+ * long as the Taylor-Hood function.  gmg: the composition of tests/hyteg/convergence/P2P1Stokes3DUzawaConvergenceTest.cpp:150-163
+ * (Uzawa over Gauss-Seidel, quadratic / linear transfer, projectMean after the restriction) with pressure-preconditioned MINRES on the
+ * coarsest level in place of PETSc's LU. */
+typedef void* hh_th_function_t;
+typedef void* hh_th_operator_t;
+typedef void* hh_th_solver_t;
+HYTEG_HOST_API int hyteg_host_th_function_create( hh_storage_t s, const char* name, int min_level, int max_level, hh_th_function_t* out );
+HYTEG_HOST_API int hyteg_host_th_function_destroy( hh_th_function_t f );
+HYTEG_HOST_API int hyteg_host_th_function_velocity( hh_th_function_t f, int k, hh_p2function_t* out );
+HYTEG_HOST_API int hyteg_host_th_function_pressure( hh_th_function_t f, hh_function_t* out );
+HYTEG_HOST_API int hyteg_host_th_function_assign( hh_th_function_t dst, int n, const double* scalars, const hh_th_function_t* fs, int level, int flag );
+HYTEG_HOST_API int hyteg_host_th_function_interpolate_constant( hh_th_function_t f, double value, int level, int flag );
+HYTEG_HOST_API int hyteg_host_th_function_dot( hh_th_function_t a, hh_th_function_t b, int level, int flag, double* out );
+HYTEG_HOST_API int hyteg_host_th_operator_create( hh_storage_t s, int min_level, int max_level, hh_th_operator_t* out );
+HYTEG_HOST_API int hyteg_host_th_operator_destroy( hh_th_operator_t op );
+HYTEG_HOST_API int hyteg_host_th_operator_apply( hh_th_operator_t op, hh_th_function_t src, hh_th_function_t dst, int level, int flag );
+/* which: 0 div (velocity of src -> pressure of dst), 1 divT (pressure of src -> velocity of dst) */
+HYTEG_HOST_API int hyteg_host_th_operator_apply_block( hh_th_operator_t op, int which, hh_th_function_t src, hh_th_function_t dst, int level, int flag );
+HYTEG_HOST_API int hyteg_host_th_gmg_create( hh_storage_t s, int min_level, int max_level, double uzawa_relax, int pre, int post, int increment,
+                                             int coarse_max_iter, double coarse_rel_tol, hh_th_solver_t* out );
+HYTEG_HOST_API int hyteg_host_th_minres_create( hh_storage_t s, int min_level, int max_level, int max_iter, double rel_tol, hh_th_solver_t* out );
+HYTEG_HOST_API int hyteg_host_th_solver_solve( hh_th_solver_t solver, hh_th_operator_t op, hh_th_function_t x, hh_th_function_t b, int level );
+HYTEG_HOST_API int hyteg_host_th_solver_destroy( hh_th_solver_t solver );
+HYTEG_HOST_API int hyteg_host_th_project_pressure_mean( hh_th_function_t f, int level );
+/* the 10 x 10 element matrix (FEniCS ordering) of a mixed block as the P2 kernel gets it: which 0 = div (p2_to_p1_tet_div_tet, edge rows
+ * zero), 1 = divT (p1_to_p2_tet_divt_tet, edge columns zero); component k; coords[4][3] */
+HYTEG_HOST_API int hyteg_host_th_form_element_matrix( int which, int k, const double* coords12, double* out100 );
+
 #ifdef __cplusplus
 }
 #endif

@@ -515,7 +515,7 @@ def ref_fenics():
         if not hasattr(l, n):
             continue
         getattr(l, n).restype, getattr(l, n).argtypes = None, [_P, _P]
-    for n in ("ref_p1_tet_div", "ref_p1_tet_divt"):
+    for n in ("ref_p1_tet_div", "ref_p1_tet_divt", "ref_p2_to_p1_tet_div", "ref_p1_to_p2_tet_divt"):
         if hasattr(l, n):
             getattr(l, n).restype, getattr(l, n).argtypes = None, [_P, _P, C.c_int]
     return l
@@ -536,3 +536,17 @@ def ref_element_matrix(ref, coords, form):
     else:
         ref.ref_p1_tet_pspg(_p(A), _p(c))
     return A.reshape(4, 4)
+
+
+def ref_taylor_hood_block(ref, coords, which, k):
+    """the reference's FEniCS element matrix of a mixed Taylor-Hood block, padded to 10 x 10 in FEniCS P2 ordering:
+    which 0: p2_to_p1_tet_div_tet_cell_integral_k (4 x 10, rows = P1 test functions), 1: p1_to_p2_tet_divt_tet_cell_integral_k (10 x 4)"""
+    c = np.ascontiguousarray(coords, dtype=np.float64).reshape(12)
+    A = np.zeros(40)
+    (ref.ref_p2_to_p1_tet_div if which == 0 else ref.ref_p1_to_p2_tet_divt)(_p(A), _p(c), k)
+    M = np.zeros((10, 10))
+    if which == 0:
+        M[:4, :] = A.reshape(4, 10)
+    else:
+        M[:, :4] = A.reshape(10, 4)
+    return M
