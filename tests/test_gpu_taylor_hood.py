@@ -174,3 +174,47 @@ def test_p2p1_stokes_3d_uzawa_convergence():
     assert res[-1] < 5.0e-5, (e_uvw, e_p, res)
     for o in (solver, u, f, r, exact, err, tmp, ones, L, st):
         o.close()
+
+
+def test_taylor_hood_v_cycle_on_the_spherical_shell():
+    """config 5 in its literal wording -- the P2-P1 Stokes block operator's V-cycle on a spherical-shell mesh: the set-up of
+    apps/stokesSphere/StokesSphere.cpp (plume right-hand side, V(2,2) with increment 2, Uzawa( 0.3 ), pressure-preconditioned MINRES
+    on the coarsest level) with the Taylor-Hood operator on the shell of hyteg_amd/meshgen.py (ntan 2, three layers, 120 tetrahedra,
+    levels 2-3): the residual of the inner equations falls in every cycle"""
+    host, hu, po = _env()
+    lo, hi = 2, 3
+    st = host.Storage.from_gmsh(hu.MESHES / "spherical_shell_ntan2_3layers.msh")
+    L = host.TaylorHoodStokesOperator(st, lo, hi)
+    u, f, r = (host.TaylorHoodFunction(st, n_, lo, hi) for n_ in ("u", "f", "r"))
+    src, radius = np.array([0.0, 0.0, 1.5]), 0.6
+
+    def plume(k):
+        def fn(p):
+            d = np.sqrt(((p - src[None, :]) ** 2).sum(axis=1))
+            return np.where(d < radius, p[:, k] * (radius - d), 0.0)
+        return fn
+
+    f.interpolate(0.0, hi, host.All)
+    u.interpolate(0.0, hi, host.All)
+    for k in range(3):
+        for c, (v, e) in enumerate(_fields(hu, po, st, hi, plume(k))):
+            f.velocity[k].upload(hi, v, e, c)
+    flag = host.Inner | host.NeumannBoundary
+
+    def residual():
+        r.interpolate(0.0, hi, host.All)
+        L.apply(u, r, hi, flag)
+        r.assign([1.0, -1.0], [f, r], hi, flag)
+        return np.sqrt(r.dot(r, hi, flag))
+
+    solver = host.TaylorHoodSolver.gmg(st, lo, hi, uzawa_relax=0.3, pre=2, post=2, increment=2, coarse_max_iter=50, coarse_rel_tol=1e-16)
+    res = [residual()]
+    assert res[0] > 0.0
+    for _ in range(4):
+        solver.solve(L, u, f, hi)
+        u.project_pressure_mean(hi)
+        res.append(residual())
+    assert all(b < 0.9 * a for a, b in zip(res, res[1:])), res
+    assert res[-1] < 0.2 * res[0], res
+    for o in (solver, u, f, r, L, st):
+        o.close()
