@@ -94,6 +94,50 @@ def _run_cycle(host, st, min_level, max_level):
     return res, out
 
 
+def _run_taylor_hood(host, st, min_level, max_level):
+    """P2P1TaylorHoodStokesOperator::apply and two V(2,2) cycles of its Uzawa multigrid (MINRES on the coarsest level): residual
+    history, the applied operator and the iterate, every DoF array of every local cell"""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from hostutil import cell_points
+    from oracle import p1_oracle as po
+
+    L = host.TaylorHoodStokesOperator(st, min_level, max_level)
+    x, b, r = (host.TaylorHoodFunction(st, n, min_level, max_level) for n in ("x", "b", "r"))
+    flag = host.Inner | host.NeumannBoundary
+    for lvl in range(min_level, max_level + 1):
+        for fn in (x, b, r):
+            fn.interpolate(0.0, lvl, host.All)
+    for c in range(st.n_local_cells):
+        gid, co, nnc = st.local_cell(c)
+        P, E = cell_points(co, max_level), po.edge_midpoints(co, max_level)
+        for k in range(3):
+            x.velocity[k].upload(max_level, FUNCS[k](P[:, 0], P[:, 1], P[:, 2]), FUNCS[k](E[:, 0], E[:, 1], E[:, 2]), c)
+        x.pressure.upload_cell(c, max_level, np.ascontiguousarray(FUNCS[3](P[:, 0], P[:, 1], P[:, 2])))
+    L.apply(x, r, max_level, flag)
+    applied = {st.local_cell(c)[0]: [r.velocity[k].download(max_level, c) for k in range(3)] + [r.pressure.download_cell(c, max_level)]
+               for c in range(st.n_local_cells)}
+    # boundary data only: zero start inside
+    for k in range(3):
+        x.velocity[k].interpolate(0.0, max_level, host.Inner)
+    x.pressure.interpolate(0.0, max_level, host.All)
+
+    def residual():
+        L.apply(x, r, max_level, flag)
+        r.assign([1.0, -1.0], [b, r], max_level, flag)
+        return np.sqrt(r.dot(r, max_level, flag))
+
+    gmg = host.TaylorHoodSolver.gmg(st, min_level, max_level, uzawa_relax=0.3, pre=2, post=2, increment=2, coarse_max_iter=40, coarse_rel_tol=1e-16)
+    res = [residual()]
+    for _ in range(2):
+        gmg.solve(L, x, b, max_level)
+        res.append(residual())
+    out = {st.local_cell(c)[0]: [x.velocity[k].download(max_level, c) for k in range(3)] + [x.pressure.download_cell(c, max_level)]
+           for c in range(st.n_local_cells)}
+    for o in (gmg, x, b, r, L):
+        o.close()
+    return res, (applied, out)
+
+
 def _worker(rank, world, port, level, q, transport):
     sys.path.insert(0, str(ROOT))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -108,10 +152,13 @@ def _worker(rank, world, port, level, q, transport):
     try:
         st = host.Storage.from_gmsh(MESH, rank, world)
         st.set_stream(torch.cuda.current_stream().cuda_stream)
+        taylor_hood = not isinstance(level, int) and level[0] == "th"
+        if taylor_hood:
+            level = level[1:]
         levels = [level] if isinstance(level, int) else list(range(level[0], level[1] + 1))
-        ctx = DistributedContext(st, levels, torch.device("cuda", 0), transport=transport)
+        ctx = DistributedContext(st, levels, torch.device("cuda", 0), transport=transport, dof_kinds=(0, 1) if taylor_hood else (0,))
         assert ctx.transport == ("p2p" if transport == "p2p" else "hooks"), ctx.transport_note
-        out = _run(host, st, level) if isinstance(level, int) else _run_cycle(host, st, *level)
+        out = _run(host, st, level) if isinstance(level, int) else (_run_taylor_hood if taylor_hood else _run_cycle)(host, st, *level)
         st.check_transport()
         q.put((rank,) + out)
         dist.barrier()
@@ -198,5 +245,50 @@ def test_stokes_v_cycle_with_minres_coarse_solver_on_two_ranks(transport):
             for k in range(4):
                 scale = max(1.0, np.abs(ref_out[gid][k]).max())
                 assert np.abs(comps[k] - ref_out[gid][k]).max() <= 1e-7 * scale, f"component {k} differs on rank {rank}, cell {gid}"
+            cells += 1
+    assert cells == 8
+
+
+def _flat(parts):
+    """velocity components come as (vertex array, edge array), the pressure as one array"""
+    return [a for p in parts for a in (p if isinstance(p, tuple) else (p,))]
+
+
+def test_taylor_hood_operator_and_v_cycle_on_two_ranks():
+    """the P2-P1 Taylor-Hood operator (P2 Laplace, mixed div / divT blocks: vertex- and edge-DoF shares through the additive exchange)
+    and its Uzawa multigrid cycle on two ranks reproduce the single-rank numbers"""
+    import torch
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, str(ROOT))
+    from hyteg_amd import host
+
+    assert torch.cuda.is_available()
+    levels, world = (2, 3), 2
+    st = host.Storage.from_gmsh(MESH)
+    st.set_stream(torch.cuda.current_stream().cuda_stream)
+    ref_res, (ref_applied, ref_out) = _run_taylor_hood(host, st, *levels)
+    assert ref_res[-1] < 0.5 * ref_res[0], ref_res
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ("th",) + levels, q, "auto"), daemon=True) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = []
+    for _ in range(world):
+        results.append(q.get(timeout=400))
+        assert results[-1][0] != "error", results[-1]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cells = 0
+    for rank, res, (applied, out) in results:
+        assert np.allclose(res, ref_res, rtol=1e-6, atol=0.0), (res, ref_res)
+        for gid in out:
+            for got, want in zip(_flat(applied[gid]), _flat(ref_applied[gid])):
+                assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), f"apply differs on rank {rank}, cell {gid}"
+            for got, want in zip(_flat(out[gid]), _flat(ref_out[gid])):
+                assert np.abs(got - want).max() <= 1e-7 * max(1.0, np.abs(want).max()), f"iterate differs on rank {rank}, cell {gid}"
             cells += 1
     assert cells == 8
