@@ -231,8 +231,10 @@ HYTEG_HIP_API int hyteg_hip_malloc( void** dev_ptr, size_t bytes )
 {
    HH_REQUIRE( dev_ptr != nullptr, "malloc: null out pointer" );
    *dev_ptr = nullptr;
-   // arrays of 1 MiB and more get whole 2 MiB fragments of their own: the size is rounded up so that the array's last page
-   // fragment is not shared with the next allocation (the address of such an allocation is 2 MiB-aligned already)
+   // arrays of 1 MiB and more are rounded up to whole 2 MiB fragments, as torch's allocator does (their addresses are 2 MiB-aligned
+   // already).  Measured in round 3 (tools/gpu/scratch/alloc_probe.py): no effect on the kernels' speed, on any box met --
+   // hipMalloc per array, rounded sizes, one arena and torch's allocator all run the apply at the same rate; kept because it
+   // costs nothing and keeps an array's last page fragment to itself.
    constexpr size_t kFragment = size_t( 2 ) << 20;
    if ( bytes >= ( size_t( 1 ) << 20 ) )
       bytes = ( bytes + kFragment - 1 ) / kFragment * kFragment;
