@@ -259,6 +259,46 @@ def main():
     us1 = (time.perf_counter() - t0) * 1e6 / 20
     rows.append(dict(kernel="P1P1StokesOperator::apply cube_24el L5", us=us1))
     print(f"P1P1StokesOperator::apply, cube_24el level 5 (24 cells, 10 scalar applies): {us1:9.1f} us", flush=True)
+    # P2-P1 Taylor-Hood (config 5's literal wording): the reference's P2P1Stokes3DUzawaConvergenceTest configuration (cube_24el, levels 2-3,
+    # V(3,3), Uzawa(0.4) over Gauss-Seidel, MINRES on the coarsest level) and one level more; operator apply; one P2 Gauss-Seidel sweep
+    for lo_t, hi_t in ((2, 3), (2, 4)):
+        Lt = host.TaylorHoodStokesOperator(s3, lo_t, hi_t)
+        ut, ft = host.TaylorHoodFunction(s3, "u", lo_t, hi_t), host.TaylorHoodFunction(s3, "f", lo_t, hi_t)
+        ut.interpolate(0.0, hi_t, host.All)
+        ft.interpolate(1.0, hi_t, host.Inner)
+        th = host.TaylorHoodSolver.gmg(s3, lo_t, hi_t, uzawa_relax=0.4, pre=3, post=3, increment=0, coarse_max_iter=60, coarse_rel_tol=1e-16)
+        th.solve(Lt, ut, ft, hi_t)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            th.solve(Lt, ut, ft, hi_t)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 2 * 1e3
+        rows.append(dict(kernel=f"Taylor-Hood V(3,3) Uzawa/GS cube_24el L{lo_t}-{hi_t}, MINRES(60) coarse", ms=ms))
+        print(f"P2-P1 Taylor-Hood V(3,3), Uzawa(0.4) over GS, cube_24el levels {lo_t}-{hi_t}, MINRES(60) on the coarsest level: {ms:9.2f} ms/cycle", flush=True)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            Lt.apply(ut, ft, hi_t, host.Inner | host.NeumannBoundary)
+        torch.cuda.synchronize()
+        us1 = (time.perf_counter() - t0) * 1e6 / 10
+        rows.append(dict(kernel=f"P2P1TaylorHoodStokesOperator::apply cube_24el L{hi_t}", us=us1))
+        print(f"P2P1TaylorHoodStokesOperator::apply, cube_24el level {hi_t} (24 cells: 3 P2 Laplace + 3 divT + 3 div): {us1:9.1f} us", flush=True)
+        for o in (th, ut, ft, Lt):
+            o.close()
+    A2g = host.P2ConstantLaplaceOperator(s3, 4, 4)
+    A2g.compute_inverse_diagonal()
+    xg, bg = host.P2Function(s3, "x", 4, 4), host.P2Function(s3, "b", 4, 4)
+    xg.interpolate(0.0, 4, host.All)
+    bg.interpolate(1.0, 4, host.Inner)
+    A2g.smooth_sor(xg, bg, 1.0, 4, host.Inner)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        A2g.smooth_sor(xg, bg, 1.0, 4, host.Inner)
+    torch.cuda.synchronize()
+    usg = (time.perf_counter() - t0) * 1e6 / 5
+    rows.append(dict(kernel="P2 Gauss-Seidel sweep (reference order on shared primitives) cube_24el L4", us=usg))
+    print(f"P2 Gauss-Seidel sweep in the reference's order, cube_24el level 4 (24 cells): {usg:9.1f} us", flush=True)
     print(json.dumps({"level": L, "device": capi.device_name(), "rows": rows}))
 
 
