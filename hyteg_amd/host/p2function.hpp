@@ -243,6 +243,24 @@ class P2Function
       }
       if ( ( kinds & 0xFEu ) == 0 )
          return;
+      if ( storage_->useBatch( level ) )
+      {
+         // all local cells in one launch per chunk (as the vertex-DoF part above)
+         const auto masks = storage_->masksFor( flag, false, keep );
+         storage_->forCellChunks( [&]( int first, int count ) {
+            std::vector< double* >       dst;
+            std::vector< const double* > srcs; // [function][cell]
+            for ( int c = first; c < first + count; ++c )
+               dst.push_back( getEdgeCellPointer( (uint_t) c, level ) );
+            for ( const auto& f : functions )
+               for ( int c = first; c < first + count; ++c )
+                  srcs.push_back( f.get().getEdgeCellPointer( (uint_t) c, level ) );
+            hipCheck( hyteg_hip_p2_edge_vector_cells_kinds( op, count, dst.data(), (int) functions.size(), srcs.data(), scalars.data(), (int) level,
+                                                            masks.data() + first, kinds, storage_->stream() ),
+                      "P2Function vector op (batched)" );
+         } );
+         return;
+      }
       forCells( [&]( uint_t c, const MacroCell& cell ) {
          const double* es[HYTEG_HIP_MAX_SRCS];
          for ( uint_t k = 0; k < functions.size(); ++k )

@@ -661,6 +661,13 @@ HYTEG_HIP_API int    hyteg_hip_p2_elementwise_apply_cell_kinds( double*         
                                                           unsigned           kind_mask,
                                                           hyteg_hip_stream_t stream );
 
+/* hyteg_hip_p2_edge_vector_cell_kinds for up to HYTEG_HIP_MAX_BATCH macro-cells of one level in ONE launch (the EdgeDoFFunction loops over
+ * the macro-cells of a rank, src/hyteg/edgedofspace/EdgeDoFFunction.cpp): dst and masks are HOST arrays of ncells entries, srcs a HOST
+ * array [nsrc][ncells] of device pointers */
+HYTEG_HIP_API int hyteg_hip_p2_edge_vector_cells_kinds( int op, int ncells, double* const* dst, int nsrc, const double* const* srcs,
+                                                        const double* scalars, int level, const unsigned* masks, unsigned kind_mask,
+                                                        hyteg_hip_stream_t stream );
+
 /* ---- P2 Gauss-Seidel / SOR on macro-primitives shared between macro-cells, in the reference's order ----
  * P2ConstantOperator::smooth_sor (src/constant_stencil_operator/P2ConstantOperator.cpp:1267-1330): macro-vertices (:157-201),
  * macro-edges (:205-266, P2MacroEdge.cpp:617-680), macro-faces (:269-880, kernels
