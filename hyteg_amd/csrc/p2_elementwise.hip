@@ -729,37 +729,46 @@ __device__ inline void p2_inner_body( const P2FastArgs& A )
 }
 
 // all eight destination kinds in one launch (blockIdx.y = kind): one ramp-up instead of eight, kinds overlap
-__global__ __launch_bounds__( kThreads ) void p2_inner_kernel( const P2FastArgs A )
+__device__ inline void p2_inner_dispatch( const P2FastArgs& A, int kind )
 {
-   if ( !( ( A.kinds >> blockIdx.y ) & 1u ) )
+   if ( !( ( A.kinds >> kind ) & 1u ) )
       return;
-   switch ( blockIdx.y )
+   switch ( kind )
    {
-   case 0:
-      p2_inner_body< 0 >( A );
-      break;
-   case 1:
-      p2_inner_body< 1 >( A );
-      break;
-   case 2:
-      p2_inner_body< 2 >( A );
-      break;
-   case 3:
-      p2_inner_body< 3 >( A );
-      break;
-   case 4:
-      p2_inner_body< 4 >( A );
-      break;
-   case 5:
-      p2_inner_body< 5 >( A );
-      break;
-   case 6:
-      p2_inner_body< 6 >( A );
-      break;
-   default:
-      p2_inner_body< 7 >( A );
-      break;
+   case 0: p2_inner_body< 0 >( A ); break;
+   case 1: p2_inner_body< 1 >( A ); break;
+   case 2: p2_inner_body< 2 >( A ); break;
+   case 3: p2_inner_body< 3 >( A ); break;
+   case 4: p2_inner_body< 4 >( A ); break;
+   case 5: p2_inner_body< 5 >( A ); break;
+   case 6: p2_inner_body< 6 >( A ); break;
+   default: p2_inner_body< 7 >( A ); break;
    }
+}
+__global__ __launch_bounds__( kThreads ) void p2_inner_kernel( const P2FastArgs A ) { p2_inner_dispatch( A, (int) blockIdx.y ); }
+// the same for up to HYTEG_HIP_MAX_BATCH macro-cells of one level (blockIdx.z = cell): the cells' arrays, operator tables and point
+// masks travel as pointer lists in the kernel arguments
+struct P2BatchPtrs
+{
+   double*       dstV[HYTEG_HIP_MAX_BATCH];
+   double*       dstE[HYTEG_HIP_MAX_BATCH];
+   const double* srcV[HYTEG_HIP_MAX_BATCH];
+   const double* srcE[HYTEG_HIP_MAX_BATCH];
+   const double* table[HYTEG_HIP_MAX_BATCH];
+   unsigned      mask[HYTEG_HIP_MAX_BATCH];
+};
+__device__ inline P2FastArgs p2_batch_view( const P2FastArgs& F, const P2BatchPtrs& P, int cell )
+{
+   P2FastArgs A = F;
+   A.dstV = P.dstV[cell], A.dstE = P.dstE[cell], A.srcV = P.srcV[cell], A.srcE = P.srcE[cell], A.table = P.table[cell];
+   return A;
+}
+__global__ __launch_bounds__( kThreads ) void p2_inner_batch_kernel( const P2FastArgs F, const P2BatchPtrs P )
+{
+   const int cell = blockIdx.z;
+   if ( !( P.mask[cell] & HYTEG_HIP_MASK_INNER ) )
+      return;
+   p2_inner_dispatch( p2_batch_view( F, P, cell ), (int) blockIdx.y );
 }
 
 // =====================================================================================================================
@@ -1185,6 +1194,17 @@ __device__ inline void p2_boundary_dispatch( const P2ClassArgs& B, int kind, int
    }
 }
 __global__ __launch_bounds__( kThreads ) void p2_boundary_kernel( const P2ClassArgs B ) { p2_boundary_dispatch( B, blockIdx.y, blockIdx.x ); }
+__global__ __launch_bounds__( kThreads ) void p2_boundary_batch_kernel( const P2FastArgs F, const P2BatchPtrs P )
+{
+   const int      cell  = blockIdx.z;
+   const unsigned shell = P.mask[cell] & HYTEG_HIP_MASK_SHELL;
+   if ( shell == 0 )
+      return;
+   P2ClassArgs B;
+   B.F    = p2_batch_view( F, P, cell );
+   B.mask = shell;
+   p2_boundary_dispatch( B, blockIdx.y, blockIdx.x );
+}
 
 // inner rows and boundary DoFs in ONE launch (they write disjoint DoFs and read the same sources): the boundary workgroups
 // -- thread per DoF, a long chain of index arithmetic and dependent loads -- come first and run beside the row waves
@@ -1969,6 +1989,46 @@ __global__ __launch_bounds__( 256 ) void p2_sor_face_edges_kernel( const P2FaceS
 }
 } // namespace
 extern "C" {
+
+HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cells_kinds( int ncells, double* const* dst_vertex, double* const* dst_edge, const double* const* src_vertex,
+                                                              const double* const* src_edge, int level, const double* const* optables_dev, double alpha,
+                                                              int update, const unsigned* masks, unsigned kind_mask, hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( dst_vertex && dst_edge && src_vertex && src_edge && optables_dev && masks, "p2_elementwise_apply_cells_kinds: null pointer" );
+   HH_REQUIRE( ncells >= 1 && ncells <= HYTEG_HIP_MAX_BATCH, "p2_elementwise_apply_cells_kinds: 1 <= ncells <= HYTEG_HIP_MAX_BATCH" );
+   HH_REQUIRE( level >= 2 && level <= 6, "p2_elementwise_apply_cells_kinds: levels 2..6 (below: the micro-cell gather per cell; above: the row kernels per cell)" );
+   HH_REQUIRE( update == HYTEG_HIP_REPLACE || update == HYTEG_HIP_ADD, "p2_elementwise_apply_cells_kinds: bad update" );
+   kind_mask &= 0xFFu;
+   if ( kind_mask == 0 )
+      return HYTEG_HIP_OK;
+   P2BatchPtrs P{};
+   unsigned    any = 0;
+   for ( int c = 0; c < ncells; ++c )
+   {
+      HH_REQUIRE( dst_vertex[c] && dst_edge[c] && src_vertex[c] && src_edge[c] && optables_dev[c], "p2_elementwise_apply_cells_kinds: null array" );
+      HH_REQUIRE( dst_vertex[c] != src_vertex[c] && dst_edge[c] != src_edge[c], "p2_elementwise_apply_cells_kinds: dst and src must differ" );
+      P.dstV[c] = dst_vertex[c], P.dstE[c] = dst_edge[c], P.srcV[c] = src_vertex[c], P.srcE[c] = src_edge[c], P.table[c] = optables_dev[c];
+      P.mask[c] = masks[c] & HYTEG_HIP_MASK_ALL;
+      any |= P.mask[c];
+   }
+   if ( any == 0 )
+      return HYTEG_HIP_OK;
+   P2FastArgs F{};
+   F.alpha = alpha, F.N = ( 1 << level ) + 1, F.update = update, F.kinds = kind_mask;
+   hipStream_t s = as_stream( stream );
+   if ( any & HYTEG_HIP_MASK_INNER )
+   {
+      const int64_t largest = tet64( F.N );
+      hipLaunchKernelGGL( p2_inner_batch_kernel, dim3( (unsigned) ( ( largest + kThreads - 1 ) / kThreads ), 8, (unsigned) ncells ), dim3( kThreads ), 0, s, F, P );
+   }
+   if ( any & HYTEG_HIP_MASK_SHELL )
+   {
+      const int nbx = ( 4 * tri( F.N ) + kThreads - 1 ) / kThreads;
+      hipLaunchKernelGGL( p2_boundary_batch_kernel, dim3( (unsigned) nbx, 8, (unsigned) ncells ), dim3( kThreads ), 0, s, F, P );
+   }
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
 
 HYTEG_HIP_API int hyteg_hip_p2_operator_table_closure_split( const double* table_host, double* outside, double* closure_vertex, double* closure_edge )
 {

@@ -549,6 +549,33 @@ class P2ElementwiseOperator
    void launchWith( const std::vector< const double* >& tables, double alpha, const P2Function< double >& src, const P2Function< double >& dst,
                     uint_t level, DoFType flag, unsigned keep, int update, unsigned kinds = 0xFFu ) const
    {
+      std::vector< double* >       dv, de;
+      std::vector< const double* > sv, se;
+      for ( uint_t c = 0; c < storage_->getNumberOfLocalCells(); ++c )
+      {
+         dv.push_back( dst.getVertexDoFFunction().getCellPointer( c, level ) ), de.push_back( dst.getEdgeCellPointer( c, level ) );
+         sv.push_back( src.getVertexDoFFunction().getCellPointer( c, level ) ), se.push_back( src.getEdgeCellPointer( c, level ) );
+      }
+      launchPointers( tables, alpha, sv, se, dv, de, level, storage_->masksFor( flag, false, keep ), update, kinds );
+   }
+   // the kernel launches of one operator application over the local cells, given the cells' arrays (mixed operators pass a P1
+   // function's arrays as vertex part)
+   void launchPointers( const std::vector< const double* >& tables, double alpha, const std::vector< const double* >& sv,
+                        const std::vector< const double* >& se, const std::vector< double* >& dv, const std::vector< double* >& de, uint_t level,
+                        const std::vector< unsigned >& masks, int update, unsigned kinds ) const
+   {
+      const uint_t nLocal = storage_->getNumberOfLocalCells();
+      if ( storage_->useBatch( level ) && level >= 2 && level <= 6 )
+      {
+         // small levels, several cells: all local cells in two launches per chunk (inner DoFs, boundary DoFs) instead of two or three per
+         // cell -- a Taylor-Hood cycle on 24 cells issued 62,000 apply launches of 3-5 us each (round 3)
+         storage_->forCellChunks( [&]( int first, int count ) {
+            hipCheck( hyteg_hip_p2_elementwise_apply_cells_kinds( count, dv.data() + first, de.data() + first, sv.data() + first, se.data() + first, (int) level,
+                                                                  tables.data() + first, alpha, update, masks.data() + first, kinds, storage_->stream() ),
+                      "P2ElementwiseOperator::gemv (batched)" );
+         } );
+         return;
+      }
       // the cells of a rank are independent launches: alternating between the storage's stream and a side stream lets a launch start
       // while the last waves of the previous one drain -- level 7, 24 cells: 1110 -> 1033 us per apply, 6 cells: no difference
       // (profiles/r03_cell_streams.txt); HYTEG_AMD_CELL_STREAMS=1 keeps one stream
@@ -556,16 +583,12 @@ class P2ElementwiseOperator
          const char* e = std::getenv( "HYTEG_AMD_CELL_STREAMS" );
          return e && e[0] == '1';
       }();
-      PrimitiveStorage::SideChain chain( *storage_, !oneStream && storage_->getNumberOfLocalCells() >= 8 && level >= 5 );
-      for ( uint_t c = 0; c < storage_->getNumberOfLocalCells(); ++c )
+      PrimitiveStorage::SideChain chain( *storage_, !oneStream && nLocal >= 8 && level >= 5 );
+      for ( uint_t c = 0; c < nLocal; ++c )
       {
          ( c & 1u ) ? chain.toSide() : chain.toMain();
-         const MacroCell& cell = storage_->getLocalCell( c );
-         hipCheck( hyteg_hip_p2_elementwise_apply_cell_kinds( dst.getVertexDoFFunction().getCellPointer( c, level ),
-                                                              dst.getEdgeCellPointer( c, level ),
-                                                              src.getVertexDoFFunction().getCellPointer( c, level ),
-                                                              src.getEdgeCellPointer( c, level ), (int) level, tables.at( c ), alpha, update,
-                                                              storage_->maskFor( cell, flag ) & keep, kinds, storage_->stream() ),
+         hipCheck( hyteg_hip_p2_elementwise_apply_cell_kinds( dv[c], de[c], sv[c], se[c], (int) level, tables.at( c ), alpha, update, masks[c], kinds,
+                                                              storage_->stream() ),
                    "P2ElementwiseOperator::gemv" );
       }
       chain.join();

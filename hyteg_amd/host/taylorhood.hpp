@@ -100,13 +100,14 @@ class P2ToP1Operator : public P2ElementwiseOperator< Form >
    {
       const DoFType flag = dst.effectiveFlag( flagIn );
       tmpP1_.setBoundaryConditionAllInner( dst.hasAllInnerBoundaryCondition() );
+      std::vector< double* >       dv, de;
+      std::vector< const double* > sv, se;
       for ( uint_t c = 0; c < this->storage_->getNumberOfLocalCells(); ++c )
-         hipCheck( hyteg_hip_p2_elementwise_apply_cell_kinds( tmpP1_.getCellPointer( c, level ), tmp_.getEdgeCellPointer( c, level ),
-                                                              src.getVertexDoFFunction().getCellPointer( c, level ), src.getEdgeCellPointer( c, level ),
-                                                              (int) level, this->elementMatrices_.at( level ).at( c ), 1.0, HYTEG_HIP_REPLACE,
-                                                              this->storage_->maskFor( this->storage_->getLocalCell( c ), flag ), 1u,
-                                                              this->storage_->stream() ),
-                   "P2ToP1Operator::apply" );
+      {
+         dv.push_back( tmpP1_.getCellPointer( c, level ) ), de.push_back( tmp_.getEdgeCellPointer( c, level ) );
+         sv.push_back( src.getVertexDoFFunction().getCellPointer( c, level ) ), se.push_back( src.getEdgeCellPointer( c, level ) );
+      }
+      this->launchPointers( this->elementMatrices_.at( level ), 1.0, sv, se, dv, de, level, this->storage_->masksFor( flag ), HYTEG_HIP_REPLACE, 1u );
       if ( this->storage_->getCells().size() > 1 )
          tmpP1_.sumSharedCopies( level, flagIn );
       if ( updateType == Replace )
@@ -134,13 +135,14 @@ class P1ToP2Operator : public P2ElementwiseOperator< Form >
    {}
    void apply( const P1Function< double >& src, const P2Function< double >& dst, uint_t level, DoFType flag, UpdateType updateType = Replace ) const
    {
+      std::vector< double* >       dv, de;
+      std::vector< const double* > sv, se;
       for ( uint_t c = 0; c < this->storage_->getNumberOfLocalCells(); ++c )
-         hipCheck( hyteg_hip_p2_elementwise_apply_cell_kinds( tmp_.getVertexDoFFunction().getCellPointer( c, level ), tmp_.getEdgeCellPointer( c, level ),
-                                                              src.getCellPointer( c, level ), zero_.getEdgeCellPointer( c, level ), (int) level,
-                                                              this->elementMatrices_.at( level ).at( c ), 1.0, HYTEG_HIP_REPLACE,
-                                                              this->storage_->maskFor( this->storage_->getLocalCell( c ), flag ), 0xFFu,
-                                                              this->storage_->stream() ),
-                   "P1ToP2Operator::apply" );
+      {
+         dv.push_back( tmp_.getVertexDoFFunction().getCellPointer( c, level ) ), de.push_back( tmp_.getEdgeCellPointer( c, level ) );
+         sv.push_back( src.getCellPointer( c, level ) ), se.push_back( zero_.getEdgeCellPointer( c, level ) );
+      }
+      this->launchPointers( this->elementMatrices_.at( level ), 1.0, sv, se, dv, de, level, this->storage_->masksFor( flag ), HYTEG_HIP_REPLACE, 0xFFu );
       if ( this->storage_->getCells().size() > 1 )
       {
          tmp_.getVertexDoFFunction().sumSharedCopies( level, flag );

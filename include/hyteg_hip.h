@@ -668,6 +668,13 @@ HYTEG_HIP_API int hyteg_hip_p2_edge_vector_cells_kinds( int op, int ncells, doub
                                                         const double* scalars, int level, const unsigned* masks, unsigned kind_mask,
                                                         hyteg_hip_stream_t stream );
 
+/* hyteg_hip_p2_elementwise_apply_cell_kinds for up to HYTEG_HIP_MAX_BATCH macro-cells of one level in two launches (inner DoFs, boundary
+ * DoFs; P2ElementwiseOperator::gemv's loop over the macro-cells, P2ElementwiseOperator.cpp:131-223): all arguments per cell as HOST
+ * arrays of ncells entries.  Levels 2..6 (thread-per-DoF kernels: where a launch per cell is pure launch latency). */
+HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cells_kinds( int ncells, double* const* dst_vertex, double* const* dst_edge, const double* const* src_vertex,
+                                                              const double* const* src_edge, int level, const double* const* optables_dev, double alpha,
+                                                              int update, const unsigned* masks, unsigned kind_mask, hyteg_hip_stream_t stream );
+
 /* ---- P2 Gauss-Seidel / SOR on macro-primitives shared between macro-cells, in the reference's order ----
  * P2ConstantOperator::smooth_sor (src/constant_stencil_operator/P2ConstantOperator.cpp:1267-1330): macro-vertices (:157-201),
  * macro-edges (:205-266, P2MacroEdge.cpp:617-680), macro-faces (:269-880, kernels
