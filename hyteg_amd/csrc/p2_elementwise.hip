@@ -1987,6 +1987,55 @@ __global__ __launch_bounds__( 256 ) void p2_sor_face_edges_kernel( const P2FaceS
       __syncthreads();
    }
 }
+// the same with the face's edge DoFs staged in LDS in the FACE's layout -- type t, row j, position i at t tri(n) + row_start(n, j) + i --
+// (levels <= 6: 3 tri(64) doubles = 50 KB): a stage then costs an LDS round trip and a barrier instead of dependent global loads
+// (48 us per call at level 3 with the kernel above, where 45 stages move a few hundred values)
+__device__ inline int face_lds_index( int n, int t, int i, int j ) { return t * tri( n ) + row_start( n, j ) + i; }
+__global__ __launch_bounds__( 256 ) void p2_sor_face_edges_lds_kernel( const P2FaceSorArgs A )
+{
+   extern __shared__ double lu[]; // [3][tri(n)]
+   const int f = blockIdx.x;
+   if ( !( ( A.mask >> ( 6 + f ) ) & 1u ) )
+      return;
+   const P2FaceFrame& F = A.F[f];
+   const int          n = A.N - 1, T = tri( n ), stages = 3 * ( 2 * n - 1 );
+   // every edge DoF of the face plane (inner ones and those on its boundary edges): (t, i, j) with i + j <= n - 1
+   for ( int e = threadIdx.x; e < 3 * T; e += (int) blockDim.x )
+   {
+      const int t = e / T, r = e - t * T;
+      const int j = row_of( n, r ), i = r - row_start( n, j );
+      lu[e]       = A.u[face_edge_index( F, n, t, i, j )];
+   }
+   __syncthreads();
+   for ( int step = 0; step < stages; ++step )
+   {
+      const int s = A.backwards ? stages - 1 - step : step;
+      const int t = s % 3, qq = s / 3;
+      const int ylo = qq - n + 1 > 0 ? qq - n + 1 : 0, yhi = qq / 2;
+      for ( int y = ylo + (int) threadIdx.x; y <= yhi; y += (int) blockDim.x )
+      {
+         const int  x     = qq - 2 * y;
+         const bool inner = t == 0 ? y >= 1 : ( t == 1 ? x + y <= n - 2 : x >= 1 );
+         if ( !inner || x + y > n - 1 )
+            continue;
+         const int l   = face_lds_index( n, t, x, y );
+         double    sum = A.q[face_edge_index( F, n, t, x, y )];
+#pragma unroll
+         for ( int k = 0; k < 4; ++k )
+            sum -= F.w[t][1 + k] * lu[face_lds_index( n, kFaceNb[t][k][0], x + kFaceNb[t][k][1], y + kFaceNb[t][k][2] )];
+         lu[l] = ( 1.0 - A.relax ) * lu[l] + A.relax / F.w[t][0] * sum;
+      }
+      __syncthreads();
+   }
+   for ( int e = threadIdx.x; e < 3 * T; e += (int) blockDim.x )
+   {
+      const int  t = e / T, r = e - t * T;
+      const int  j = row_of( n, r ), i = r - row_start( n, j );
+      const bool inner = t == 0 ? j >= 1 : ( t == 1 ? i + j <= n - 2 : i >= 1 );
+      if ( inner )
+         A.u[face_edge_index( F, n, t, i, j )] = lu[e];
+   }
+}
 } // namespace
 extern "C" {
 
@@ -2114,7 +2163,16 @@ HYTEG_HIP_API int hyteg_hip_p2_sor_face_edgedofs_cell( double* dst_edge, const d
             A.F[f].w[t][k] = face_w[15 * f + 5 * t + k];
       }
    }
-   hipLaunchKernelGGL( p2_sor_face_edges_kernel, dim3( 4 ), dim3( 256 ), 0, as_stream( stream ), A );
+   const size_t lds = (size_t) 3 * tri( n ) * sizeof( double );
+   if ( level <= 6 )
+   {
+      if ( lds > 48 * 1024 )
+         HH_CHECK_HIP( hipFuncSetAttribute( reinterpret_cast< const void* >( p2_sor_face_edges_lds_kernel ), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int) lds ) );
+      hipLaunchKernelGGL( p2_sor_face_edges_lds_kernel, dim3( 4 ), dim3( 256 ), lds, as_stream( stream ), A );
+   }
+   else
+      hipLaunchKernelGGL( p2_sor_face_edges_kernel, dim3( 4 ), dim3( 256 ), 0, as_stream( stream ), A );
    HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;
 }
