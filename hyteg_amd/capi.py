@@ -113,6 +113,7 @@ SIGNATURES = {
     "hyteg_hip_p2_edge_vector_cell_kinds": (_i, [_i, _vp, _i, C.POINTER(_vp), _dp, _i, C.c_uint, C.c_uint, _vp]),
     "hyteg_hip_p2_elementwise_apply_cells_kinds": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i, C.POINTER(_vp), _d, _i,
                                                    C.POINTER(C.c_uint), C.c_uint, _vp]),
+    "hyteg_hip_p2_edge_dot_cells_masked": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), _i, C.POINTER(C.c_uint), _vp, _vp]),
     "hyteg_hip_p2_edge_vector_cells_kinds": (_i, [_i, _i, C.POINTER(_vp), _i, C.POINTER(_vp), _dp, _i, C.POINTER(C.c_uint), C.c_uint, _vp]),
     "hyteg_hip_p2_edge_dot_cell_masked": (_i, [_vp, _vp, _i, C.c_uint, _vp, _vp, _vp]),
     "hyteg_hip_p2_elementwise_apply_cell": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _d, _i, C.c_uint, _vp]),

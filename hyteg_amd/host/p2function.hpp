@@ -160,6 +160,19 @@ class P2Function
    {
       double       sum = vertexDoFFunction_.dotLocal( rhs.vertexDoFFunction_, level, flag );
       const uint_t nl  = storage_->getNumberOfLocalCells();
+      if ( storage_->useBatch( level ) )
+      {
+         const auto masks = storage_->masksFor( flag, true );
+         storage_->forCellChunks( [&]( int first, int count ) {
+            std::vector< const double* > a, b;
+            for ( int c = first; c < first + count; ++c )
+               a.push_back( getEdgeCellPointer( (uint_t) c, level ) ), b.push_back( rhs.getEdgeCellPointer( (uint_t) c, level ) );
+            hipCheck( hyteg_hip_p2_edge_dot_cells_masked( count, a.data(), b.data(), (int) level, masks.data() + first, storage_->dotResult() + first,
+                                                          storage_->stream() ),
+                      "P2Function::dotLocal (batched)" );
+         } );
+      }
+      else
       forCells( [&]( uint_t c, const MacroCell& cell ) {
          hipCheck( hyteg_hip_p2_edge_dot_cell_masked( getEdgeCellPointer( c, level ), rhs.getEdgeCellPointer( c, level ), (int) level,
                                                       storage_->ownedMaskFor( cell, flag ), storage_->dotResult() + c, storage_->dotWorkspace(),

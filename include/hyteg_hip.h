@@ -668,6 +668,10 @@ HYTEG_HIP_API int hyteg_hip_p2_edge_vector_cells_kinds( int op, int ncells, doub
                                                         const double* scalars, int level, const unsigned* masks, unsigned kind_mask,
                                                         hyteg_hip_stream_t stream );
 
+/* hyteg_hip_p2_edge_dot_cell_masked for up to HYTEG_HIP_MAX_BATCH macro-cells in one launch: results_dev[c] = the masked dot product of cell c
+ * (a, b, masks: HOST arrays of ncells entries; one workgroup per cell, fixed summation order) */
+HYTEG_HIP_API int hyteg_hip_p2_edge_dot_cells_masked( int ncells, const double* const* a, const double* const* b, int level, const unsigned* masks,
+                                                      double* results_dev, hyteg_hip_stream_t stream );
 /* hyteg_hip_p2_elementwise_apply_cell_kinds for up to HYTEG_HIP_MAX_BATCH macro-cells of one level in two launches (inner DoFs, boundary
  * DoFs; P2ElementwiseOperator::gemv's loop over the macro-cells, P2ElementwiseOperator.cpp:131-223): all arguments per cell as HOST
  * arrays of ncells entries.  Levels 2..6 (thread-per-DoF kernels: where a launch per cell is pure launch latency). */
