@@ -3,6 +3,9 @@
 // 37-64,217-424; P2toP2QuadraticRestriction.cpp:35-47,131-286)
 #pragma once
 
+#include <map>
+#include <memory>
+
 #include "p2function.hpp"
 
 namespace hyteg {
@@ -18,12 +21,17 @@ class P2toP2QuadraticProlongation
    // fine += interpolant: formed in a temporary (Replace), made bit-identical on shared DoFs, then added
    void prolongateAndAdd( const P2Function< double >& function, const uint_t& sourceLevel, const DoFType& flag ) const
    {
-      P2Function< double > tmp( "p2_prolongate_tmp", function.getStorage(), sourceLevel + 1, sourceLevel + 1 );
-      run( function, tmp, sourceLevel, flag );
-      function.add( { 1.0 }, { tmp }, sourceLevel + 1, flag );
+      // the temporary is kept per (storage, level): creating it allocates and clears an array pair per macro-cell, and a multigrid
+      // cycle comes through here once per level and function
+      auto& slot = tmp_[std::make_pair( function.getStorage().get(), sourceLevel + 1 )];
+      if ( !slot )
+         slot.reset( new P2Function< double >( "p2_prolongate_tmp", function.getStorage(), sourceLevel + 1, sourceLevel + 1 ) );
+      run( function, *slot, sourceLevel, flag );
+      function.add( { 1.0 }, { *slot }, sourceLevel + 1, flag );
    }
 
  private:
+   mutable std::map< std::pair< const PrimitiveStorage*, uint_t >, std::unique_ptr< P2Function< double > > > tmp_;
    static void run( const P2Function< double >& src, const P2Function< double >& dst, uint_t sourceLevel, DoFType flag )
    {
       auto        storage = src.getStorage();
