@@ -29,6 +29,9 @@ SIGNATURES = {
     "hyteg_hip_calib_copy": (_i, [_vp, _vp, _i64, _i, _vp]),
     "hyteg_hip_p2_operator_table_closure_split": (_i, [_vp, _vp, _vp, _vp]),
     "hyteg_hip_p2_operator_table_face_edge_weights": (_i, [_vp, C.POINTER(_i), _vp]),
+    "hyteg_hip_p2_sor_face_frames_bytes": (_sz, []),
+    "hyteg_hip_p2_sor_face_frames": (_i, [_i, C.POINTER(_i), _vp, _vp]),
+    "hyteg_hip_p2_sor_face_edgedofs_cells": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), _i, _vp, _d, C.POINTER(C.c_uint), _i, _vp]),
     "hyteg_hip_p2_sor_face_edgedofs_cell": (_i, [_vp, _vp, _i, C.POINTER(_i), _vp, _d, C.c_uint, _i, _vp]),
     "hyteg_hip_calib_copy_ring": (_i, [C.POINTER(_vp), C.POINTER(_vp), _i, _i64, _i, _i, _i, _vp, _vp, _vp]),
     "hyteg_hip_stream_create": (_i, [C.POINTER(_vp)]),

@@ -2050,25 +2050,21 @@ __global__ __launch_bounds__( 256 ) void p2_sor_face_edges_kernel( const P2FaceS
 // (levels <= 6: 3 tri(64) doubles = 50 KB): a stage then costs an LDS round trip and a barrier instead of dependent global loads
 // (48 us per call at level 3 with the kernel above, where 45 stages move a few hundred values)
 __device__ inline int face_lds_index( int n, int t, int i, int j ) { return t * tri( n ) + row_start( n, j ) + i; }
-__global__ __launch_bounds__( 256 ) void p2_sor_face_edges_lds_kernel( const P2FaceSorArgs A )
+__device__ inline void p2_sor_face_edges_lds_body( double* u, const double* q, const P2FaceFrame& F, int N, int backwards, double relax )
 {
    extern __shared__ double lu[]; // [3][tri(n)]
-   const int f = blockIdx.x;
-   if ( !( ( A.mask >> ( 6 + f ) ) & 1u ) )
-      return;
-   const P2FaceFrame& F = A.F[f];
-   const int          n = A.N - 1, T = tri( n ), stages = 3 * ( 2 * n - 1 );
+   const int n = N - 1, T = tri( n ), stages = 3 * ( 2 * n - 1 );
    // every edge DoF of the face plane (inner ones and those on its boundary edges): (t, i, j) with i + j <= n - 1
    for ( int e = threadIdx.x; e < 3 * T; e += (int) blockDim.x )
    {
       const int t = e / T, r = e - t * T;
       const int j = row_of( n, r ), i = r - row_start( n, j );
-      lu[e]       = A.u[face_edge_index( F, n, t, i, j )];
+      lu[e]       = u[face_edge_index( F, n, t, i, j )];
    }
    __syncthreads();
    for ( int step = 0; step < stages; ++step )
    {
-      const int s = A.backwards ? stages - 1 - step : step;
+      const int s = backwards ? stages - 1 - step : step;
       const int t = s % 3, qq = s / 3;
       const int ylo = qq - n + 1 > 0 ? qq - n + 1 : 0, yhi = qq / 2;
       for ( int y = ylo + (int) threadIdx.x; y <= yhi; y += (int) blockDim.x )
@@ -2078,11 +2074,11 @@ __global__ __launch_bounds__( 256 ) void p2_sor_face_edges_lds_kernel( const P2F
          if ( !inner || x + y > n - 1 )
             continue;
          const int l   = face_lds_index( n, t, x, y );
-         double    sum = A.q[face_edge_index( F, n, t, x, y )];
+         double    sum = q[face_edge_index( F, n, t, x, y )];
 #pragma unroll
          for ( int k = 0; k < 4; ++k )
             sum -= F.w[t][1 + k] * lu[face_lds_index( n, kFaceNb[t][k][0], x + kFaceNb[t][k][1], y + kFaceNb[t][k][2] )];
-         lu[l] = ( 1.0 - A.relax ) * lu[l] + A.relax / F.w[t][0] * sum;
+         lu[l] = ( 1.0 - relax ) * lu[l] + relax / F.w[t][0] * sum;
       }
       __syncthreads();
    }
@@ -2092,8 +2088,37 @@ __global__ __launch_bounds__( 256 ) void p2_sor_face_edges_lds_kernel( const P2F
       const int  j = row_of( n, r ), i = r - row_start( n, j );
       const bool inner = t == 0 ? j >= 1 : ( t == 1 ? i + j <= n - 2 : i >= 1 );
       if ( inner )
-         A.u[face_edge_index( F, n, t, i, j )] = lu[e];
+         u[face_edge_index( F, n, t, i, j )] = lu[e];
    }
+}
+__global__ __launch_bounds__( 256 ) void p2_sor_face_edges_lds_kernel( const P2FaceSorArgs A )
+{
+   const int f = blockIdx.x;
+   if ( !( ( A.mask >> ( 6 + f ) ) & 1u ) )
+      return;
+   p2_sor_face_edges_lds_body( A.u, A.q, A.F[f], A.N, A.backwards, A.relax );
+}
+// up to HYTEG_HIP_MAX_BATCH macro-cells in one launch (blockIdx.y = cell): the cells' face frames (with the faces' total weights) come
+// from a device table the caller built once per level (hyteg_hip_p2_sor_face_frames)
+struct P2FaceSorBatchArgs
+{
+   double*            u[HYTEG_HIP_MAX_BATCH];
+   const double*      q[HYTEG_HIP_MAX_BATCH];
+   unsigned           mask[HYTEG_HIP_MAX_BATCH];
+   const P2FaceFrame* frames; // [cell][4]
+   int                N, backwards;
+   double             relax;
+};
+__global__ __launch_bounds__( 256 ) void p2_sor_face_edges_lds_batch_kernel( const P2FaceSorBatchArgs A )
+{
+   const int f = blockIdx.x, cell = blockIdx.y;
+   if ( !( ( A.mask[cell] >> ( 6 + f ) ) & 1u ) )
+      return;
+   __shared__ P2FaceFrame F;
+   if ( threadIdx.x == 0 )
+      F = A.frames[4 * cell + f];
+   __syncthreads();
+   p2_sor_face_edges_lds_body( A.u[cell], A.q[cell], F, A.N, A.backwards, A.relax );
 }
 } // namespace
 extern "C" {
@@ -2232,6 +2257,52 @@ HYTEG_HIP_API int hyteg_hip_p2_sor_face_edgedofs_cell( double* dst_edge, const d
    }
    else
       hipLaunchKernelGGL( p2_sor_face_edges_kernel, dim3( 4 ), dim3( 256 ), 0, as_stream( stream ), A );
+   HH_CHECK_HIP( hipGetLastError() );
+   return HYTEG_HIP_OK;
+}
+
+HYTEG_HIP_API size_t hyteg_hip_p2_sor_face_frames_bytes( void ) { return 4 * sizeof( P2FaceFrame ); }
+HYTEG_HIP_API int    hyteg_hip_p2_sor_face_frames( int level, const int* face_verts, const double* face_w, void* frames_host )
+{
+   HH_REQUIRE( face_verts && face_w && frames_host, "p2_sor_face_frames: null pointer" );
+   HH_REQUIRE( level >= 2 && level <= HYTEG_HIP_P2_MAX_LEVEL, "p2_sor_face_frames: level out of range (2..9)" );
+   P2FaceFrame* F = static_cast< P2FaceFrame* >( frames_host );
+   const int    n = 1 << level;
+   for ( int f = 0; f < 4; ++f )
+   {
+      int cls = 0;
+      F[f]    = P2FaceFrame{};
+      HH_REQUIRE( face_frame( face_verts + 3 * f, F[f], cls ) && cls == 6 + f, "p2_sor_face_frames: face_verts[f] must be the three cell-local vertex ids of face f" );
+      for ( int r = 0; r < 3; ++r )
+         F[f].O[r] *= n;
+      for ( int t = 0; t < 3; ++t )
+         for ( int k = 0; k < 5; ++k )
+            F[f].w[t][k] = face_w[15 * f + 5 * t + k];
+   }
+   return HYTEG_HIP_OK;
+}
+HYTEG_HIP_API int hyteg_hip_p2_sor_face_edgedofs_cells( int ncells, double* const* dst_edge, const double* const* q_edge, int level, const void* frames_dev,
+                                                        double relax, const unsigned* masks, int backwards, hyteg_hip_stream_t stream )
+{
+   HH_REQUIRE( dst_edge && q_edge && frames_dev && masks, "p2_sor_face_edgedofs_cells: null pointer" );
+   HH_REQUIRE( ncells >= 1 && ncells <= HYTEG_HIP_MAX_BATCH, "p2_sor_face_edgedofs_cells: 1 <= ncells <= HYTEG_HIP_MAX_BATCH" );
+   HH_REQUIRE( level >= 2 && level <= 6, "p2_sor_face_edgedofs_cells: levels 2..6 (the face's edge DoFs are staged in LDS)" );
+   P2FaceSorBatchArgs A{};
+   A.frames = static_cast< const P2FaceFrame* >( frames_dev ), A.N = ( 1 << level ) + 1, A.backwards = backwards ? 1 : 0, A.relax = relax;
+   unsigned any = 0;
+   for ( int c = 0; c < ncells; ++c )
+   {
+      HH_REQUIRE( dst_edge[c] && q_edge[c] && dst_edge[c] != q_edge[c], "p2_sor_face_edgedofs_cells: null array, or dst and q are the same" );
+      A.u[c] = dst_edge[c], A.q[c] = q_edge[c], A.mask[c] = masks[c] & ( 0xFu << 6 );
+      any |= A.mask[c];
+   }
+   if ( any == 0 )
+      return HYTEG_HIP_OK;
+   const size_t lds = (size_t) 3 * tri( A.N - 1 ) * sizeof( double );
+   if ( lds > 48 * 1024 )
+      HH_CHECK_HIP( hipFuncSetAttribute( reinterpret_cast< const void* >( p2_sor_face_edges_lds_batch_kernel ), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int) lds ) );
+   hipLaunchKernelGGL( p2_sor_face_edges_lds_batch_kernel, dim3( 4, (unsigned) ncells ), dim3( 256 ), lds, as_stream( stream ), A );
    HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;
 }

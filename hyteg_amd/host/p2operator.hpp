@@ -334,6 +334,7 @@ class P2ElementwiseOperator
       std::vector< const double* >             outside, closureVertex, closureEdge; // device tables per local cell
       std::vector< std::array< int, 12 > >     faceVerts;                            // per local cell: [face][3] local vertex ids by global id
       std::vector< std::array< double, 60 > >  faceW;                                // per local cell: [face][type][5] total weights
+      const double*                            framesDev = nullptr;                  // levels <= 6: the records of hyteg_hip_p2_sor_face_frames, cell after cell
    };
    const SorTables& sorTables( uint_t level ) const
    {
@@ -383,6 +384,14 @@ class P2ElementwiseOperator
             for ( int k = 0; k < 15; ++k )
                T.faceW[c.localIndex][15 * f + k] = faceTot[c.faces[f]][k];
          }
+      }
+      if ( level <= 6 && !T.faceVerts.empty() )
+      {
+         const size_t          words = hyteg_hip_p2_sor_face_frames_bytes() / sizeof( double );
+         std::vector< double > frames( words * T.faceVerts.size() );
+         for ( size_t c = 0; c < T.faceVerts.size(); ++c )
+            hipCheck( hyteg_hip_p2_sor_face_frames( (int) level, T.faceVerts[c].data(), T.faceW[c].data(), frames.data() + c * words ), "P2 smooth_sor: face frames" );
+         T.framesDev = storage_->uploadTable( frames );
       }
       return sorTables_.emplace( level, std::move( T ) ).first->second;
    }
@@ -443,6 +452,22 @@ class P2ElementwiseOperator
       };
       auto edgeDoFsOfMacroFaces = [&]() {
          edgeRightHandSide( F );
+         if ( T.framesDev && storage_->useBatch( level ) )
+         {
+            const auto   masks = storage_->masksFor( flag, false, F );
+            const size_t bytes = hyteg_hip_p2_sor_face_frames_bytes();
+            storage_->forCellChunks( [&]( int first, int count ) {
+               std::vector< double* >       u;
+               std::vector< const double* > q;
+               for ( int c = first; c < first + count; ++c )
+                  u.push_back( dst.getEdgeCellPointer( (uint_t) c, level ) ), q.push_back( t.getEdgeCellPointer( (uint_t) c, level ) );
+               hipCheck( hyteg_hip_p2_sor_face_edgedofs_cells( count, u.data(), q.data(), (int) level,
+                                                               reinterpret_cast< const char* >( T.framesDev ) + (size_t) first * bytes, relax,
+                                                               masks.data() + first, backwards ? 1 : 0, storage_->stream() ),
+                         "P2 smooth_sor: face edge DoFs (batched)" );
+            } );
+            return;
+         }
          for ( uint_t c = 0; c < storage_->getNumberOfLocalCells(); ++c )
             hipCheck( hyteg_hip_p2_sor_face_edgedofs_cell( dst.getEdgeCellPointer( c, level ), t.getEdgeCellPointer( c, level ), (int) level,
                                                            T.faceVerts[c].data(), T.faceW[c].data(), relax,

@@ -702,6 +702,13 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cells_kinds( int ncells, double
  *    Levels 2..9. */
 HYTEG_HIP_API int hyteg_hip_p2_operator_table_closure_split( const double* table_host, double* outside, double* closure_vertex, double* closure_edge );
 HYTEG_HIP_API int hyteg_hip_p2_operator_table_face_edge_weights( const double* table_host, const int* face_verts /* 3 */, double* w /* 15 */ );
+/* the same for up to HYTEG_HIP_MAX_BATCH macro-cells in one launch (levels 2..6): hyteg_hip_p2_sor_face_frames turns a cell's face_verts[4][3]
+ * and face_w[4][3][5] into hyteg_hip_p2_sor_face_frames_bytes() bytes (host; a multiple of 8); the caller keeps the records of its cells, one
+ * after the other, in device memory (frames_dev) */
+HYTEG_HIP_API size_t hyteg_hip_p2_sor_face_frames_bytes( void );
+HYTEG_HIP_API int    hyteg_hip_p2_sor_face_frames( int level, const int* face_verts /* 12 */, const double* face_w /* 60 */, void* frames_host );
+HYTEG_HIP_API int    hyteg_hip_p2_sor_face_edgedofs_cells( int ncells, double* const* dst_edge, const double* const* q_edge, int level, const void* frames_dev,
+                                                           double relax, const unsigned* masks, int backwards, hyteg_hip_stream_t stream );
 HYTEG_HIP_API int hyteg_hip_p2_sor_face_edgedofs_cell( double* dst_edge, const double* q_edge, int level, const int* face_verts /* 12 */,
                                                        const double* face_w /* 60 */, double relax, unsigned mask, int backwards,
                                                        hyteg_hip_stream_t stream );
