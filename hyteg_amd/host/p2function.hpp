@@ -59,6 +59,19 @@ class P2Function
    void interpolate( ValueType constant, uint_t level, DoFType flag = All ) const
    {
       vertexDoFFunction_.interpolate( constant, level, flag );
+      if ( storage_->useBatch( level ) )
+      {
+         const auto masks = storage_->masksFor( flag );
+         storage_->forCellChunks( [&]( int first, int count ) {
+            std::vector< double* > dst;
+            for ( int c = first; c < first + count; ++c )
+               dst.push_back( getEdgeCellPointer( (uint_t) c, level ) );
+            hipCheck( hyteg_hip_p2_edge_vector_cells_kinds( 3, count, dst.data(), 0, nullptr, &constant, (int) level, masks.data() + first, 0xFEu,
+                                                            storage_->stream() ),
+                      "P2Function::interpolate (batched)" );
+         } );
+         return;
+      }
       forCells( [&]( uint_t c, const MacroCell& cell ) {
          hipCheck( hyteg_hip_p2_edge_vector_cell_masked( 3, getEdgeCellPointer( c, level ), 0, nullptr, &constant, (int) level,
                                                          storage_->maskFor( cell, flag ), storage_->stream() ),
