@@ -529,31 +529,68 @@ class DenseCoarseGridSolver : public Solver< OperatorType >
       n_  = 4 * np_;
    }
    const P1Function< double >& comp( const FunctionType& f, uint_t c ) const { return c < 3 ? f.uvw()[c] : f.p(); }
+   // device-side packing (round 3; the first version moved every cell array through the host by itself: 281,000 synchronous copies
+   // at set-up and 288 per coarse-grid solve): index tables built once, one pack launch + one download per gather, one upload +
+   // one pack launch per cell array per scatter -- hyteg_hip_gather_entries( out, bases, buf, off, n ): out[k] = bases[buf[k]][off[k]]
+   void buildIndexTables() const
+   {
+      if ( gatherBuf_ )
+         return;
+      const uint_t      nCells = storage_->getNumberOfLocalCells();
+      const int64_t     total  = layout::cellSize( (int) level_ );
+      std::vector< int > gb( n_ ), go( n_ );
+      for ( uint_t c = 0; c < 4; ++c )
+         for ( uint_t g = 0; g < np_; ++g )
+         {
+            gb[c * np_ + g] = (int) ( c * nCells + reps_[g].cell ); // position of the array in basesOf( f )
+            go[c * np_ + g] = reps_[g].index;
+         }
+      gatherBuf_ = static_cast< const int* >( storage_->uploadBytes( gb.data(), gb.size() * sizeof( int ) ) );
+      gatherOff_ = static_cast< const int* >( storage_->uploadBytes( go.data(), go.size() * sizeof( int ) ) );
+      // scatter: entry i of the array of (component c, cell) reads V[ c np + pointOf[cell][i] ] -- one table for all components, the
+      // component's offset comes through the base pointer V + c np
+      std::vector< int > so( nCells * (size_t) total ), zeros( (size_t) total, 0 );
+      for ( uint_t cell = 0; cell < nCells; ++cell )
+         for ( int64_t i = 0; i < total; ++i )
+            so[cell * (size_t) total + (size_t) i] = pointOf_[cell][(size_t) i];
+      scatterOff_  = static_cast< const int* >( storage_->uploadBytes( so.data(), so.size() * sizeof( int ) ) );
+      scatterZero_ = static_cast< const int* >( storage_->uploadBytes( zeros.data(), zeros.size() * sizeof( int ) ) );
+      std::vector< double > none( n_ + 1, 0.0 );
+      packed_ = storage_->uploadTable( none );
+      std::vector< double* > vb;
+      for ( uint_t c = 0; c < 4; ++c )
+         vb.push_back( packed_ + c * np_ );
+      packedBases_ = storage_->pointerTable( vb );
+   }
+   double** basesOf( const FunctionType& f ) const
+   {
+      std::vector< double* > b;
+      for ( uint_t c = 0; c < 4; ++c )
+         for ( uint_t cell = 0; cell < storage_->getNumberOfLocalCells(); ++cell )
+            b.push_back( comp( f, c ).getCellPointer( cell, level_ ) );
+      return storage_->pointerTable( b );
+   }
    std::vector< double > gather( const FunctionType& f ) const
    {
+      buildIndexTables();
       std::vector< double > v( n_ );
-      const int64_t         total = layout::cellSize( (int) level_ );
-      std::vector< double > host( (size_t) total );
-      for ( uint_t c = 0; c < 4; ++c )
-         for ( uint_t cell = 0; cell < storage_->getNumberOfLocalCells(); ++cell )
-         {
-            comp( f, c ).copyCellToHost( cell, level_, host.data() );
-            for ( int64_t i = 0; i < total; ++i )
-               v[c * np_ + (uint_t) pointOf_[cell][(size_t) i]] = host[(size_t) i];
-         }
+      hipCheck( hyteg_hip_gather_entries( packed_, basesOf( f ), gatherBuf_, gatherOff_, (int) n_, storage_->stream() ), "dense coarse solver: gather" );
+      hipCheck( hyteg_hip_download( v.data(), packed_, n_ * sizeof( double ), storage_->stream() ), "dense coarse solver: download" );
+      hipCheck( hyteg_hip_stream_synchronize( storage_->stream() ), "dense coarse solver: sync" );
       return v;
    }
-   void scatter( const FunctionType& f, const std::vector< double >& v ) const
+   // components [cFirst, cLast] of f := v
+   void scatter( const FunctionType& f, const std::vector< double >& v, uint_t cFirst = 0, uint_t cLast = 3 ) const
    {
-      const int64_t         total = layout::cellSize( (int) level_ );
-      std::vector< double > host( (size_t) total );
-      for ( uint_t c = 0; c < 4; ++c )
+      buildIndexTables();
+      const int64_t total = layout::cellSize( (int) level_ );
+      hipCheck( hyteg_hip_upload( packed_, v.data(), n_ * sizeof( double ), storage_->stream() ), "dense coarse solver: upload" );
+      for ( uint_t c = cFirst; c <= cLast; ++c )
          for ( uint_t cell = 0; cell < storage_->getNumberOfLocalCells(); ++cell )
-         {
-            for ( int64_t i = 0; i < total; ++i )
-               host[(size_t) i] = v[c * np_ + (uint_t) pointOf_[cell][(size_t) i]];
-            comp( f, c ).copyCellFromHost( cell, level_, host.data() );
-         }
+            hipCheck( hyteg_hip_gather_entries( comp( f, c ).getCellPointer( cell, level_ ), packedBases_ + c, scatterZero_,
+                                                scatterOff_ + cell * (size_t) total, (int) total, storage_->stream() ),
+                      "dense coarse solver: scatter" );
+      hipCheck( hyteg_hip_stream_synchronize( storage_->stream() ), "dense coarse solver: sync" ); // v may go out of scope
    }
    void factorise( const OperatorType& A )
    {
@@ -571,11 +608,15 @@ class DenseCoarseGridSolver : public Solver< OperatorType >
       const uint_t          m = n_ + 1;
       std::vector< double > M( m * m, 0.0 );
       std::vector< double > unit( n_, 0.0 );
+      scatter( e_, unit );
       for ( uint_t j = 0; j < n_; ++j )
       {
-         unit.assign( n_, 0.0 );
+         // only the component that holds DoF j changes (and the previous one when j is a component's first DoF)
+         const uint_t c = j / np_;
+         if ( j > 0 )
+            unit[j - 1] = 0.0;
          unit[j] = 1.0;
-         scatter( e_, unit );
+         scatter( e_, unit, ( j % np_ == 0 && c > 0 ) ? c - 1 : c, c );
          Ae_.interpolate( 0.0, level_, All );
          A.apply( e_, Ae_, level_, flag );
          const auto col = gather( Ae_ );
@@ -629,6 +670,9 @@ class DenseCoarseGridSolver : public Solver< OperatorType >
    std::vector< bool >                 free_;
    std::vector< double >               lu_;
    std::vector< uint_t >               perm_;
+   mutable const int *                 gatherBuf_ = nullptr, *gatherOff_ = nullptr, *scatterOff_ = nullptr, *scatterZero_ = nullptr;
+   mutable double*                     packed_      = nullptr;
+   mutable double**                    packedBases_ = nullptr;
 };
 
 } // namespace hyteg
