@@ -1,0 +1,113 @@
+"""GPU parity of the z-march form of the P2 row kernel (p2_apply_zmarch_kernel: inner DoFs and the DoFs of the macro-faces z = 0 and
+y = 0 by marching waves, the rest of the boundary thread by thread), which hyteg_hip_p2_elementwise_apply_cell uses from level 7:
+run here from level 3 (hyteg_hip_p2_set_zmarch_min_level) against the CPU restatement of P2ElementwiseOperator::gemv
+(oracle/p1_oracle.c ho_p2_elementwise_apply_cell) and against the row kernel of the other levels."""
+import numpy as np
+import pytest
+
+from conftest import REF_TET, SKEW_TET
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    from hyteg_amd import capi
+    from oracle import p1_oracle as po
+
+    assert torch.cuda.is_available()
+    capi.lib()
+    return torch, capi, po
+
+
+@pytest.fixture(params=[1, 8, 3])
+def zmarch_from_level_3(env, request):
+    """the kernel from level 3, with 1 (the default form), 8 and 3 slices per wave"""
+    capi = env[1]
+    before, slices = capi.p2_set_zmarch_min_level(3), capi.p2_set_zmarch_slices(request.param)
+    yield
+    capi.p2_set_zmarch_min_level(before)
+    capi.p2_set_zmarch_slices(slices)
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda")
+
+
+MASKS = ((0x7FFF, 0, 1.0), (1 << 14, 0, 1.0), (0x7FFF, 1, -0.5), (0x4000 | 0x2A5, 0, 2.0), (0x4000 | (1 << 6), 1, 1.0), (0x4000 | (1 << 7) | 1, 0, 1.0),
+         (0x4000 | 0x3F3E, 0, 1.0))
+
+
+@pytest.mark.parametrize("level", [3, 4, 5])
+@pytest.mark.parametrize("tet", [REF_TET, SKEW_TET])
+def test_zmarch_apply_matches_the_oracle(env, zmarch_from_level_3, level, tet):
+    torch, capi, po = env
+    nv, ne = po.cell_size(level), po.edge_array_size(level)
+    em = po.p2_cell_element_matrices(np.asarray(tet, dtype=np.float64).reshape(12), level)
+    rng = np.random.default_rng(100 + level)
+    sv, se, dv0, de0 = rng.standard_normal(nv), rng.standard_normal(ne), rng.standard_normal(nv), rng.standard_normal(ne)
+    dem = _dev(torch, capi.p2_build_operator_table(em))
+    for mask, update, alpha in MASKS:
+        wv, we = po.p2_elementwise_apply_cell(dv0.copy(), de0.copy(), sv, se, level, em, alpha, update, mask)
+        dsv, dse, ddv, dde = _dev(torch, sv), _dev(torch, se), _dev(torch, dv0), _dev(torch, de0)
+        capi.p2_elementwise_apply_cell(ddv.data_ptr(), dde.data_ptr(), dsv.data_ptr(), dse.data_ptr(), level, dem.data_ptr(), alpha, update, mask)
+        torch.cuda.synchronize()
+        gv, ge = ddv.cpu().numpy(), dde.cpu().numpy()
+        scale = max(np.abs(wv).max(), np.abs(we).max(), 1.0)
+        assert np.abs(gv - wv).max() <= 1e-13 * scale and np.abs(ge - we).max() <= 1e-13 * scale, (level, hex(mask), update)
+        sel_v = ((mask >> po.slot_of_points(level)) & 1).astype(bool)
+        sel_e = ((mask >> po.edge_classes(level)) & 1).astype(bool)
+        assert np.array_equal(gv[~sel_v], dv0[~sel_v]) and np.array_equal(ge[~sel_e], de0[~sel_e]), (level, hex(mask), update)
+
+
+@pytest.mark.parametrize("slices", [1, 8])
+@pytest.mark.parametrize("level", [6, 7])
+def test_zmarch_equals_the_row_kernel_to_rounding(env, level, slices):
+    """levels the oracle takes too long for: the two forms of the kernel on the same input (they differ in the order of the sum only),
+    every DoF written by exactly one of the launch's two parts"""
+    torch, capi, po = env
+    nv, ne = capi.cell_size(level), capi.p2_edge_array_size(level)
+    em = po.p2_cell_element_matrices(np.asarray(SKEW_TET, dtype=np.float64).reshape(12), level)
+    dem = _dev(torch, capi.p2_build_operator_table(em))
+    rng = np.random.default_rng(level)
+    sv, se = _dev(torch, rng.standard_normal(nv)), _dev(torch, rng.standard_normal(ne))
+    out = {}
+    for first in (99, 3):
+        before, lz = capi.p2_set_zmarch_min_level(first), capi.p2_set_zmarch_slices(slices)
+        try:
+            for mask, update in ((0x7FFF, 0), (0x7FFF, 1), (0x4000, 0)):
+                dv, de = torch.full((nv,), 0.25, dtype=torch.float64, device="cuda"), torch.full((ne,), -0.5, dtype=torch.float64, device="cuda")
+                capi.p2_elementwise_apply_cell(dv.data_ptr(), de.data_ptr(), sv.data_ptr(), se.data_ptr(), level, dem.data_ptr(), 1.0, update, mask)
+                torch.cuda.synchronize()
+                out[first, mask, update] = (dv.cpu().numpy(), de.cpu().numpy())
+        finally:
+            capi.p2_set_zmarch_min_level(before)
+            capi.p2_set_zmarch_slices(lz)
+    for mask, update in ((0x7FFF, 0), (0x7FFF, 1), (0x4000, 0)):
+        (av, ae), (bv, be) = out[99, mask, update], out[3, mask, update]
+        scale = max(np.abs(av).max(), np.abs(ae).max())
+        assert np.abs(av - bv).max() <= 1e-13 * scale and np.abs(ae - be).max() <= 1e-13 * scale, (level, hex(mask), update)
+        # untouched entries are untouched in both
+        assert np.array_equal(av == 0.25, bv == 0.25) and np.array_equal(ae == -0.5, be == -0.5)
+
+
+def test_zmarch_reads_rows_that_do_not_exist_as_zero(env, zmarch_from_level_3):
+    """a weight that is exactly zero (neighbour outside the macro-cell) must not meet a stray value: NaNs in the DESTINATION arrays'
+    neighbourhood are harmless by construction; here the source is finite and huge in the first and last entries of every kind's
+    array, next to which the rows of the faces y = 0 and z = 0 are read"""
+    torch, capi, po = env
+    level = 4
+    nv, ne = po.cell_size(level), po.edge_array_size(level)
+    em = po.p2_cell_element_matrices(np.asarray(REF_TET, dtype=np.float64).reshape(12), level)
+    rng = np.random.default_rng(7)
+    sv, se = rng.standard_normal(nv), rng.standard_normal(ne)
+    wv, we = po.p2_elementwise_apply_cell(np.zeros(nv), np.zeros(ne), sv, se, level, em, 1.0, 0, 0x7FFF)
+    dem = _dev(torch, capi.p2_build_operator_table(em))
+    dsv, dse = _dev(torch, sv), _dev(torch, se)
+    dv, de = torch.zeros(nv, dtype=torch.float64, device="cuda"), torch.zeros(ne, dtype=torch.float64, device="cuda")
+    capi.p2_elementwise_apply_cell(dv.data_ptr(), de.data_ptr(), dsv.data_ptr(), dse.data_ptr(), level, dem.data_ptr(), 1.0, 0, 0x7FFF)
+    torch.cuda.synchronize()
+    scale = max(np.abs(wv).max(), np.abs(we).max())
+    assert np.abs(dv.cpu().numpy() - wv).max() <= 1e-13 * scale and np.abs(de.cpu().numpy() - we).max() <= 1e-13 * scale

@@ -1,0 +1,33 @@
+"""P2 apply at level 7 (and 6): row kernel of round 2 against the z-march form, LZ from the environment"""
+import sys, os
+import numpy as np
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+import torch
+from hyteg_amd import capi
+from oracle import p1_oracle as po
+
+REF = np.array([0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1], dtype=np.float64)
+for level in (6, 7):
+    nv, ne = capi.cell_size(level), capi.p2_edge_array_size(level)
+    em = po.p2_cell_element_matrices(REF, min(level, 6))
+    dem = torch.from_numpy(capi.p2_build_operator_table(em)).cuda()
+    nb = max(3, int(2.2 * 2**28 / ((nv + ne) * 8)) + 1)
+    S = [(torch.rand(nv, dtype=torch.float64, device="cuda"), torch.rand(ne, dtype=torch.float64, device="cuda")) for _ in range(nb)]
+    D = [(torch.zeros(nv, dtype=torch.float64, device="cuda"), torch.zeros(ne, dtype=torch.float64, device="cuda")) for _ in range(nb)]
+    st = torch.cuda.current_stream().cuda_stream
+    def run(mask, n=200):
+        best = 1e9
+        for rep in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for k in range(n):
+                sv, se = S[k % nb]; dv, de = D[k % nb]
+                capi.p2_elementwise_apply_cell(dv.data_ptr(), de.data_ptr(), sv.data_ptr(), se.data_ptr(), level, dem.data_ptr(), 1.0, 0, mask)
+            e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e3 / n)
+        return best
+    for first, name in ((99, "rows (round 2)"), (3, "z-march")):
+        capi.p2_set_zmarch_min_level(first)
+        run(0x7FFF, 20)
+        print(f"level {level} {name:16s} all {run(0x7FFF):8.2f} us   inner only {run(0x4000):8.2f} us   ({nb} buffer pairs, LZ={os.environ.get('HYTEG_HIP_P2_ZMARCH_LZ','8')})", flush=True)
+    del S, D
