@@ -121,8 +121,7 @@ SIGNATURES = {
     "hyteg_hip_p2_edge_dot_cell_masked": (_i, [_vp, _vp, _i, C.c_uint, _vp, _vp, _vp]),
     "hyteg_hip_p2_elementwise_apply_cell": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _d, _i, C.c_uint, _vp]),
     "hyteg_hip_p2_elementwise_apply_cell_kinds": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _d, _i, C.c_uint, C.c_uint, _vp]),
-    "hyteg_hip_p2_set_zmarch_min_level": (_i, [_i]),
-    "hyteg_hip_p2_set_zmarch_slices": (_i, [_i]),
+    "hyteg_hip_p2_set_class_rows_min_level": (_i, [_i]),
     "hyteg_hip_p1_vector_cells_dev": (_i, [_i, _i, C.POINTER(_vp), _i, C.POINTER(_vp), C.POINTER(_vp), _i, C.POINTER(C.c_uint), _vp]),
     "hyteg_hip_cg_scalars": (_i, [_vp, _i, _d, _d, _vp]),
     "hyteg_hip_p1_cg_small_max_entries": (_i, []),
@@ -517,14 +516,9 @@ def p2_edge_dot_cell_masked(a, b, level, mask, result_dev, workspace_dev, stream
     check(lib().hyteg_hip_p2_edge_dot_cell_masked(a, b, level, mask, result_dev, workspace_dev, stream), "p2_edge_dot_cell_masked")
 
 
-def p2_set_zmarch_slices(slices) -> int:
-    """slices per wave of the z-march row kernel (1 = one slice per wave, the default); returns the previous value"""
-    return int(lib().hyteg_hip_p2_set_zmarch_slices(int(slices)))
-
-
-def p2_set_zmarch_min_level(level) -> int:
-    """first level hyteg_hip_p2_elementwise_apply_cell uses the z-march row kernel at (tests: 3); returns the previous value"""
-    return int(lib().hyteg_hip_p2_set_zmarch_min_level(int(level)))
+def p2_set_class_rows_min_level(level) -> int:
+    """first level hyteg_hip_p2_elementwise_apply_cell uses the row kernel with every point class at (default 3; 99 = the kernels of rounds 1-2); returns the previous value"""
+    return int(lib().hyteg_hip_p2_set_class_rows_min_level(int(level)))
 
 
 def p2_elementwise_apply_cell(dst_v, dst_e, src_v, src_e, level, optable_dev, alpha=1.0, update=REPLACE, mask=0x7FFF, stream=0, kinds=0xFF):

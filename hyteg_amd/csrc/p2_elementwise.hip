@@ -1272,167 +1272,170 @@ __global__ __launch_bounds__( kThreads, 2 ) void p2_apply_fused_kernel( const Ti
 }
 
 // =====================================================================================================================
-// z-march form of the row kernel (round 3; levels >= kZmMinLevel, all destination kinds).  The 44 source rows of a position
-// (x-run, y, z) are 20 distinct COLUMNS (source kind, dy) read at dz = -1, 0, +1: the rows of slice z + 1 are the dz = 0 rows of
-// the next step and the dz = -1 rows of the one after.  A wave owns the x-run of row y over up to LZ consecutive slices and
-// marches in +z with four register slots per column (slices z-1, z, z+1 and the prefetch of z+2): 20 row loads per step instead
-// of 44, issued one step ahead of their use.  Same sources and weights as p2_rows_body_dpp; the sum runs in three partial sums
-// (dx = 0, +1, -1), so results agree with the other kernels to rounding, not bit for bit.
+// Row kernel with every point class (round 3; levels >= 3, all destination kinds, masks that include the inner DoFs): replaces the
+// launch of p2_rows_body_dpp + p2_boundary_body.  One wave owns a run of 62 positions of a row (y, z) of the vertex array (lanes
+// 1..62; lanes 0 and 63 hold the x-neighbours), loads the 44 source rows once and produces all eight kinds, as p2_rows_body_dpp does.
+// What is new:
+//   * BOUNDARY DoFs are computed by the same waves.  The point class of a DoF -- which adjacent micro-cells exist -- depends on
+//     four flags (z = 0, y = 0, x = 0, x + y + z = n; for an edge DoF: both end points).  The first two are wave-uniform, and within
+//     a row only its FIRST DoF can have x = 0 and only its LAST one x + y + z = n.  So three passes, each with ONE class per wave and
+//     therefore a wave-uniform weight row of the operator table (scalar loads, weights as SGPR operands): pass 0 all DoFs of the run
+//     off those two planes, pass 1 the DoF at x = 0 (tiles with x0 = 0, the four kinds that can lie in that plane), pass 2 the last
+//     DoF of the row (the tile that holds it, the four kinds that can lie on x + y + z = n).  Passes 1 and 2 run the whole wave for
+//     one lane's DoF (138 FMAs each) -- far cheaper than the thread-per-DoF kernel, whose 65-96 loads per DoF hit a cache line each
+//     on these two faces: level 7 (all DoFs) 44.4 -> 30.1 us, level 8 256 -> 156 us (profiles/r03_p2_class_rows.txt).
+//   * The sum of a DoF runs in three partial sums (entries with dx = 0, +1, -1, each in the order of the entry list); the two
+//     x-neighbour sums move by one lane at the end (two wave shifts per DoF instead of one per entry: 357 instead of 546 vector
+//     instructions per wave, 99 VGPRs, 4 waves per SIMD).  Results agree with the other kernels to rounding, not bit for bit.
+//   * Rows below y = 0 / z = 0 do not exist and are read as 0 (their base is moved beyond every array): the class weights of the
+//     neighbours outside the macro-cell are exactly 0 and never meet a stray value.  Positions beyond the ends of a row (lane 0 of
+//     the first tile, lanes past the last entry) read whatever the layout holds there, finite for finite input, and meet either a
+//     zero weight or a lane that stores nothing -- as in p2_term_class, which reads entry 0 for its zero weights.
 //
-// Point classes that depend on (y, z) only are computed here too, with the class's weight row (wave-uniform pointer): the
-// DoFs of the macro-faces z = 0 and y = 0 and of the macro-edge between them, except those that also lie on x = 0 or on
-// x + y + z = n.  Rows that do not exist (y + dy < 0, z + dz < 0, beyond the top of a kind's array) are read as 0 (vector
-// offset forced out of range), so a weight that is exactly 0 never meets a stray value.  The thread-per-DoF boundary kernel
-// keeps the DoFs with x = 0 or x + y + z = n (mask bits of classes 0, 6, 7 cleared in its launch).
+// Measured and not kept (same file): two positions per lane with 16-byte loads (NP = 2; range-checked dword by dword, so the half
+// of a pair beyond the end of the array reads as 0): 196 VGPRs, slower at every level (level 7: 32.2 us inner DoFs against 25.0);
+// a z-march (rows of slices z-1 .. z+2 in four register slots, 20 row loads per slice instead of 44): 184 VGPRs, 160 spilled
+// SGPRs, 3.7 us per slice and wave, 40.7 us at level 7; the launch with every load and store forced out of range and no FMAs
+// still takes 17 of 27 us -- the instruction stream of a wave, not the memory, is what these kernels are bound by.
 // =====================================================================================================================
-struct ColList
+constexpr int      kClassRowsMinLevel = 3;
+typedef int p2_v4i __attribute__( ( ext_vector_type( 4 ) ) );
+
+template < int C >
+struct DxUse
 {
-   int      n;
-   int      kind[24], dy[24];
-   unsigned dzmask[24]; // bit dz + 1: the column is read at that dz
-   int      ofRow[64];  // column of row r of kRows
+   bool plus, minus;
 };
-constexpr ColList build_col_list()
+template < int C >
+constexpr DxUse< C > build_dx_use()
 {
-   ColList L{};
-   for ( int r = 0; r < kRows.n; ++r )
+   DxUse< C >            U{};
+   constexpr KindStencil S = KindStencilOf< C >::value;
+   for ( int q = 0; q < S.n; ++q )
    {
-      int c = -1;
-      for ( int k = 0; k < L.n; ++k )
-         if ( L.kind[k] == kRows.kind[r] && L.dy[k] == kRows.dy[r] )
-            c = k;
-      if ( c < 0 )
-      {
-         c         = L.n++;
-         L.kind[c] = kRows.kind[r], L.dy[c] = kRows.dy[r];
-      }
-      L.dzmask[c] |= 1u << ( kRows.dz[r] + 1 );
-      L.ofRow[r] = c;
+      U.plus  = U.plus || S.dx[q] > 0;
+      U.minus = U.minus || S.dx[q] < 0;
    }
-   return L;
-}
-constexpr ColList kCols = build_col_list();
-static_assert( kCols.n <= 24, "column list" );
-constexpr int      kZmSlots        = 4;
-constexpr int      kZmMinLevel     = 99; // off by default: measured slower than the row kernel (profiles/r03_p2_zmarch_probe.txt)
-constexpr int      kZmDefaultSlices = 1;
-constexpr unsigned kZmUniformClasses = ( 1u << 0 ) | ( 1u << 6 ) | ( 1u << 7 ); // classes whose flags are (z == 0, y == 0) only
-
-typedef double ZmSlots[kZmSlots][kCols.n];
-
-// rows ( column, slice s ) of every column that plays one of ROLES (bits dz + 1) -> slot SLOT; is[c] = index of (x0, y, s) at width N - c
-template < int SLOT, unsigned ROLES >
-__device__ __forceinline__ void p2_zm_load_slice( ZmSlots& S, const int ( &is )[3], int N, int y, int s, bool sliceValid, int lane8,
-                                         __amdgpu_buffer_rsrc_t rsV, __amdgpu_buffer_rsrc_t rsE )
-{
-   [&]< int... J >( std::integer_sequence< int, J... > ) {
-      ( ( [&] {
-           constexpr int K = kCols.kind[J], DY = kCols.dy[J];
-           double        u = 0.0;
-           if constexpr ( ( kCols.dzmask[J] & ROLES ) != 0u )
-           {
-              constexpr int c      = K == 0 ? 0 : ( K == 7 ? 2 : 1 );
-              const bool    exists = sliceValid && y + DY >= 0 && y + DY + s <= N - c - 1 && !( lane8 & 4 );
-              const int     voff   = exists ? p2_rows_base< K, DY, 0 >( is, N, y, s ) + lane8 : -8;
-              const p2_v2i  v      = __builtin_amdgcn_raw_buffer_load_b64( K == 0 ? rsV : rsE, voff, 0, 0 );
-              u                    = __hiloint2double( v.y, v.x );
-           }
-           S[SLOT][J] = u;
-        }() ),
-        ... );
-   }
-   ( std::make_integer_sequence< int, kCols.n >{} );
+   return U;
 }
 
-// destination kind C at (x-run, y, z): slices z-1, z, z+1 in slots SM, S0, SP
-template < int C, int UPDATE, int SM, int S0, int SP >
-__device__ __forceinline__ void p2_zm_kind( const P2RowsArgs& A, const ZmSlots& S, const int ( &iz )[3], int lane, int x, int y, int z, unsigned mask,
-                                   __amdgpu_buffer_rsrc_t rdV, __amdgpu_buffer_rsrc_t rdE )
+// destination kind C at the NP positions xa .. xa + NP - 1 of row (y, z) a lane holds; R[row] = its NP source values in that row
+// PASS 0: the DoFs off the planes x = 0 and x + y + z = n (one class per row: flags z == 0, y == 0).  PASS 1: the DoF at x = 0 of the row
+// (kinds that can lie in that plane; tiles with x0 = 0).  PASS 2: the last DoF of the row, on x + y + z = n (kinds that can lie in that
+// plane; the tile that holds it), unless it is the one at x = 0.  Every pass has ONE point class per wave, so its weights are a
+// wave-uniform row of the operator table; passes 1 and 2 run the whole wave for one lane's DoF.
+template < int C, int UPDATE, int NP, int PASS >
+__device__ __forceinline__ void p2_classrows_kind( const P2RowsArgs& A, const double ( &R )[kRows.n][NP], const int ( &i0 )[3], int lane, int xa, int x0,
+                                              int y, int z, unsigned mask, __amdgpu_buffer_rsrc_t rdV, __amdgpu_buffer_rsrc_t rdE )
 {
    constexpr int  NQ = KindStencilOf< C >::value.n;
-   constexpr bool F0 = C == 0 || C == 1 || C == 2 || C == 4; // kinds whose DoFs can lie in the plane z = 0 / y = 0 (both end points)
-   constexpr bool F1 = C == 0 || C == 1 || C == 3 || C == 5;
-   const bool     f0 = F0 && z == 0, f1 = F1 && y == 0;
-   const int      cls  = f0 ? ( f1 ? 0 : 6 ) : ( f1 ? 7 : 14 );
-   constexpr int  OFF_INNER = stencil_offset( C ), OFF_CLASS = class_offset( C ); // forced constant evaluation (none of the table code on the device)
-   const int      woff = cls == 14 ? OFF_INNER : OFF_CLASS + cls * NQ;
+   constexpr bool F0 = C == 0 || C == 1 || C == 2 || C == 4; // kinds whose DoFs can lie in the plane z = 0 / y = 0 / x = 0 / x + y + z = n
+   constexpr bool F1 = C == 0 || C == 1 || C == 3 || C == 5; // (both end points of the edge)
+   constexpr bool F2 = C == 0 || C == 2 || C == 3 || C == 6;
+   constexpr bool F3 = C == 0 || C == 4 || C == 5 || C == 6;
+   if constexpr ( ( PASS == 1 && !F2 ) || ( PASS == 2 && !F3 ) )
+      return;
+   const int  Nn = A.F.N, nn = Nn - 1;
+   const int  top = ( C == 0 ? Nn - 1 : ( C == 7 ? nn - 2 : nn - 1 ) ) - y - z; // x of the last entry of the row in the kind's array
+   const bool f0 = F0 && z == 0, f1 = F1 && y == 0;
+   int        cls, xOnly = 0;
+   if constexpr ( PASS == 0 )
+      cls = f0 ? ( f1 ? 0 : 6 ) : ( f1 ? 7 : 14 );
+   else if constexpr ( PASS == 1 )
+   {
+      if ( x0 != 0 || top < 0 )
+         return;
+      cls = class_from_flags( f0, f1, 1, F3 && top == 0 );
+   }
+   else
+   {
+      xOnly = top;
+      if ( xOnly < ( F2 ? 1 : 0 ) || xOnly < x0 || xOnly >= x0 + 62 * NP )
+         return;
+      cls = class_from_flags( f0, f1, 0, 1 );
+   }
+   if ( !( ( mask >> cls ) & 1u ) ) // wave-uniform
+      return;
+   constexpr int OFF_INNER = stencil_offset( C ), OFF_CLASS = class_offset( C ); // forced constant evaluation (none of the table code on the device)
+   const int     woff      = cls == 14 ? OFF_INNER : OFF_CLASS + cls * NQ;
    typedef const __attribute__( ( address_space( 4 ) ) ) double* cptr_t;
-   const cptr_t w   = (cptr_t) ( A.F.table + woff );
-   // one partial sum per dx, in the order of the entry list; the sums over the x-neighbours move by one lane at the end (two wave
-   // shifts per DoF instead of one per entry: the shifted copies of 45 rows do not fit beside four slots of 20)
-   double a0 = 0.0, ap = 0.0, am = 0.0;
-   if ( !( mask & ( 1u << 19 ) ) ) // DEBUG
+   const cptr_t w = (cptr_t) ( A.F.table + woff );
+   double       a0[NP] = {}, ap[NP] = {}, am[NP] = {};
    [&]< int... Q >( std::integer_sequence< int, Q... > ) {
       ( ( [&] {
-           constexpr int I    = SrcIndex< C >::value.idx[Q];
-           constexpr int DX   = kSrc.dx[I], DZ = kSrc.dz[I];
-           constexpr int slot = DZ < 0 ? SM : ( DZ == 0 ? S0 : SP );
-           const double  r    = S[slot][kCols.ofRow[kRows.ofSrc[I]]];
-           if constexpr ( DX == 0 )
-              a0 = fma( w[Q], r, a0 );
-           else if constexpr ( DX > 0 )
-              ap = fma( w[Q], r, ap );
-           else
-              am = fma( w[Q], r, am );
+           constexpr int I   = SrcIndex< C >::value.idx[Q];
+           constexpr int DX  = kSrc.dx[I];
+           constexpr int row = kRows.ofSrc[I];
+           const double  wq  = w[Q];
+           for ( int p = 0; p < NP; ++p )
+              if constexpr ( DX == 0 )
+                 a0[p] = fma( wq, R[row][p], a0[p] );
+              else if constexpr ( DX > 0 )
+                 ap[p] = fma( wq, R[row][p], ap[p] );
+              else
+                 am[p] = fma( wq, R[row][p], am[p] );
         }() ),
         ... );
    }
    ( std::make_integer_sequence< int, NQ >{} );
-   double acc = A.F.alpha * ( ( a0 + p2_lane_plus_1( ap ) ) + p2_lane_minus_1( am ) );
-   const int N       = A.F.N, n = N - 1, s = x + y + z;
-   constexpr int c   = C == 0 ? 0 : ( C == 7 ? 2 : 1 );
-   const int     bk  = C == 0 ? 0 : ( C - 1 ) * (int) tet32( (unsigned) n );
-   // the DoF exists in its array and lies neither on x = 0 nor on x + y + z = n: p2_inner< C > without its conditions on y and z
-   bool here;
-   if constexpr ( C == 0 )
-      here = x >= 1 && s <= N - 2;
-   else if constexpr ( C == 1 )
-      here = s < n;
-   else if constexpr ( C == 2 || C == 3 )
-      here = x > 0 && s < n;
-   else if constexpr ( C == 6 )
-      here = x > 0 && s < n - 1;
-   else
-      here = s < n - 1;
-   const bool on   = lane >= 1 && lane <= kRowsDppCapacity && x >= 0 && here && ( ( mask >> cls ) & 1u ) && !( mask & ( 1u << 17 ) );
-   const int  voff = on ? ( bk + iz[c] + lane - 1 ) * 8 : -8;
-   const __amdgpu_buffer_rsrc_t rd = C == 0 ? rdV : rdE;
-   if constexpr ( UPDATE == HYTEG_HIP_ADD )
+   // position p takes the dx = +1 sum formed at position p + 1 and the dx = -1 sum formed at position p - 1 (in the next / previous lane
+   // at the ends of the lane's run)
+   constexpr DxUse< C > U = build_dx_use< C >();
+   double               acc[NP];
+   for ( int p = 0; p < NP; ++p )
+      acc[p] = a0[p];
+   if constexpr ( U.plus )
    {
-      const p2_v2i o = __builtin_amdgcn_raw_buffer_load_b64( rd, voff, 0, 0 );
-      acc            = __hiloint2double( o.y, o.x ) + acc;
+      const double next = p2_lane_plus_1( ap[0] );
+      for ( int p = 0; p < NP; ++p )
+         acc[p] += p + 1 < NP ? ap[p + 1 < NP ? p + 1 : 0] : next;
    }
-   __builtin_amdgcn_raw_buffer_store_b64( p2_v2i{ __double2loint( acc ), __double2hiint( acc ) }, rd, voff, 0, 0 );
+   if constexpr ( U.minus )
+   {
+      const double prev = p2_lane_minus_1( am[NP - 1] );
+      for ( int p = 0; p < NP; ++p )
+         acc[p] += p >= 1 ? am[p >= 1 ? p - 1 : 0] : prev;
+   }
+   const int     N  = A.F.N, n = N - 1;
+   constexpr int c  = C == 0 ? 0 : ( C == 7 ? 2 : 1 );
+   const int     bk = C == 0 ? 0 : ( C - 1 ) * (int) tet32( (unsigned) n );
+   const __amdgpu_buffer_rsrc_t rd = C == 0 ? rdV : rdE;
+   [&]< int... P >( std::integer_sequence< int, P... > ) {
+      ( ( [&] {
+           const int x = xa + P, s = x + y + z;
+           // the DoF exists in its array and lies neither on x = 0 nor on x + y + z = n: p2_inner< C > without its conditions on y and z
+           bool here;
+           if constexpr ( C == 0 )
+              here = x >= 1 && s <= N - 2;
+           else if constexpr ( C == 1 )
+              here = s < n;
+           else if constexpr ( C == 2 || C == 3 )
+              here = x > 0 && s < n;
+           else if constexpr ( C == 6 )
+              here = x > 0 && s < n - 1;
+           else
+              here = s < n - 1;
+           bool on = lane >= 1 && lane <= 62;
+           if constexpr ( PASS == 0 )
+              on = on && here;
+           else
+              on = on && x == xOnly;
+           const int  voff = on ? ( bk + i0[c] + NP * ( lane - 1 ) + P ) * 8 : -8;
+           double     v    = A.F.alpha * acc[P];
+           if constexpr ( UPDATE == HYTEG_HIP_ADD )
+           {
+              const p2_v2i o = __builtin_amdgcn_raw_buffer_load_b64( rd, voff, 0, 0 );
+              v              = __hiloint2double( o.y, o.x ) + v;
+           }
+           __builtin_amdgcn_raw_buffer_store_b64( p2_v2i{ __double2loint( v ), __double2hiint( v ) }, rd, voff, 0, 0 );
+        }() ),
+        ... );
+   }
+   ( std::make_integer_sequence< int, NP >{} );
 }
 
-struct ZmState
-{
-   int iz[3], ip[3]; // indices of (x0, y, z) and (x0, y, z + 1) at the three array widths
-   int z, left;      // current slice, slices left including this one
-};
-template < int UPDATE, int P >
-__device__ __forceinline__ void p2_zm_step( const P2RowsArgs& A, ZmSlots& S, ZmState& T, int lane, int x, int y, unsigned mask, __amdgpu_buffer_rsrc_t rsV,
-                                   __amdgpu_buffer_rsrc_t rsE, __amdgpu_buffer_rsrc_t rdV, __amdgpu_buffer_rsrc_t rdE )
-{
-   const int N = A.F.N;
-   int       ipp[3];
-   for ( int c = 0; c < 3; ++c )
-      ipp[c] = T.ip[c] + tri( N - c - ( T.z + 1 ) ) - y;
-   // slice z + 2, needed by the next step (if there is one), into the slot slice z - 2 has left
-   p2_zm_load_slice< ( P + 3 ) % kZmSlots, 7u >( S, ipp, N, y, T.z + 2, T.left > 1, lane * 8, rsV, rsE );
-   [&]< int... C >( std::integer_sequence< int, C... > ) {
-      ( p2_zm_kind< C, UPDATE, P % kZmSlots, ( P + 1 ) % kZmSlots, ( P + 2 ) % kZmSlots >( A, S, T.iz, lane, x, y, T.z, mask, rdV, rdE ), ... );
-   }
-   ( std::make_integer_sequence< int, 8 >{} );
-   for ( int c = 0; c < 3; ++c )
-      T.iz[c] = T.ip[c], T.ip[c] = ipp[c];
-   T.z += 1, T.left -= 1;
-}
-
-// SINGLE: one slice per wave (tiles with cnt = 1), every row read in the one role it has: the row kernel of round 2 with the per-dx
-// partial sums and the (y, z)-classes of this form
-template < int UPDATE, bool SINGLE = false >
-__device__ __forceinline__ void p2_zmarch_body( const P2RowsArgs& A, const Tile* tiles, int ntiles, int xcd_chunk, int block, unsigned mask )
+template < int UPDATE, int NP >
+__device__ __forceinline__ void p2_classrows_body( const P2RowsArgs& A, const Tile* tiles, int ntiles, int xcd_chunk, int block, unsigned mask )
 {
    if ( xcd_chunk > 0 )
    {
@@ -1443,113 +1446,87 @@ __device__ __forceinline__ void p2_zmarch_body( const P2RowsArgs& A, const Tile*
    const int t = __builtin_amdgcn_readfirstlane( block * kRowsWaves + ( (int) threadIdx.x >> 6 ) );
    if ( t >= ntiles )
       return;
-   const Tile tl   = tiles[t]; // a, pad[0], pad[1]: index of (x0, y, z0) at widths N, N-1, N-2; ya = y, yb = x0, z = z0, cnt = slices
-   if ( ( mask & ( 1u << 18 ) ) && tl.a >= 0 ) // DEBUG
-      return;
-   const int  lane = threadIdx.x & 63;
-   const int  N    = A.F.N;
-   const int  y = tl.ya, x = tl.yb - 1 + lane;
+   const Tile tl    = tiles[t]; // a, pad[0], pad[1]: index of (x0, y, z) at widths N, N-1, N-2; ya = y, yb = x0
+   const int  lane  = threadIdx.x & 63;
+   const int  N     = A.F.N;
+   const int  y = tl.ya, z = tl.z, xa = tl.yb + NP * ( lane - 1 ); // lane 0 holds the NP positions in front of x0
+   const int  i0[3] = { tl.a, tl.pad[0], tl.pad[1] };
    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc( const_cast< double* >( A.F.srcV ), 0, A.vbytes, 0x00020000 );
    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc( const_cast< double* >( A.F.srcE ), 0, A.ebytes, 0x00020000 );
    const __amdgpu_buffer_rsrc_t rdV = __builtin_amdgcn_make_buffer_rsrc( A.F.dstV, 0, A.vbytes, 0x00020000 );
    const __amdgpu_buffer_rsrc_t rdE = __builtin_amdgcn_make_buffer_rsrc( A.F.dstE, 0, A.ebytes, 0x00020000 );
-   ZmState T;
-   T.z = tl.z, T.left = tl.cnt;
-   T.iz[0] = tl.a, T.iz[1] = tl.pad[0], T.iz[2] = tl.pad[1];
-   int im[3];
-   for ( int c = 0; c < 3; ++c )
-   {
-      const int Wz = N - c - T.z; // first-row length of slice z in the array of width N - c
-      im[c]        = T.iz[c] - ( tri( Wz + 1 ) - y );
-      T.ip[c]      = T.iz[c] + tri( Wz ) - y;
+   const int  laneBytes = lane * 8 * NP;
+   // rows below y = 0 / z = 0 do not exist: their base is moved beyond every array (two scalar flags, one select per such row); rows
+   // beyond the top of a kind's array are read only by lanes whose results are not stored
+   const bool rowBelow = y >= 1, sliceBelow = z >= 1;
+   constexpr int kNowhere = (int) 0x80000000u;
+
+   double R[kRows.n][NP];
+   [&]< int... I >( std::integer_sequence< int, I... > ) {
+      ( ( [&] {
+           constexpr int K = kRows.kind[I], DY = kRows.dy[I], DZ = kRows.dz[I];
+           int           base = p2_rows_base< K, DY, DZ >( i0, N, y, z ) + 8 - 8 * NP; // p2_rows_base is biased by one element
+           if constexpr ( DY < 0 && DZ < 0 )
+              base = ( rowBelow && sliceBelow ) ? base : kNowhere;
+           else if constexpr ( DY < 0 )
+              base = rowBelow ? base : kNowhere;
+           else if constexpr ( DZ < 0 )
+              base = sliceBelow ? base : kNowhere;
+           if constexpr ( NP == 2 )
+           {
+              // a 16-byte load is range-checked dword by dword: the half of a pair that lies beyond the end of the array reads as 0
+              const p2_v4i v = __builtin_amdgcn_raw_buffer_load_b128( K == 0 ? rsV : rsE, base + laneBytes, 0, 0 );
+              R[I][0]        = __hiloint2double( v.y, v.x );
+              R[I][NP - 1]   = __hiloint2double( v.w, v.z );
+           }
+           else
+           {
+              const p2_v2i v = __builtin_amdgcn_raw_buffer_load_b64( K == 0 ? rsV : rsE, base + laneBytes, 0, 0 );
+              R[I][0]        = __hiloint2double( v.y, v.x );
+           }
+        }() ),
+        ... );
    }
-   ZmSlots S;
-   if constexpr ( SINGLE )
-   {
-      const int l8 = lane * 8 + ( ( mask >> 16 ) & 1u ) * 4; // DEBUG
-      p2_zm_load_slice< 0, 1u >( S, im, N, y, T.z - 1, T.z >= 1, l8, rsV, rsE );
-      p2_zm_load_slice< 1, 2u >( S, T.iz, N, y, T.z, true, l8, rsV, rsE );
-      p2_zm_load_slice< 2, 4u >( S, T.ip, N, y, T.z + 1, true, l8, rsV, rsE );
-      [&]< int... C >( std::integer_sequence< int, C... > ) {
-         ( p2_zm_kind< C, UPDATE, 0, 1, 2 >( A, S, T.iz, lane, x, y, T.z, mask, rdV, rdE ), ... );
+   ( std::make_integer_sequence< int, kRows.n >{} );
+
+   [&]< int... C >( std::integer_sequence< int, C... > ) {
+      ( p2_classrows_kind< C, UPDATE, NP, 0 >( A, R, i0, lane, xa, tl.yb, y, z, mask, rdV, rdE ), ... );
+      if ( mask & HYTEG_HIP_MASK_SHELL ) // wave-uniform: the DoFs on x = 0 and on x + y + z = n
+      {
+         ( p2_classrows_kind< C, UPDATE, NP, 1 >( A, R, i0, lane, xa, tl.yb, y, z, mask, rdV, rdE ), ... );
+         ( p2_classrows_kind< C, UPDATE, NP, 2 >( A, R, i0, lane, xa, tl.yb, y, z, mask, rdV, rdE ), ... );
       }
-      ( std::make_integer_sequence< int, 8 >{} );
-      return;
    }
-   p2_zm_load_slice< 0, 1u >( S, im, N, y, T.z - 1, T.z >= 1, lane * 8, rsV, rsE );
-   p2_zm_load_slice< 1, 3u >( S, T.iz, N, y, T.z, true, lane * 8, rsV, rsE );
-   p2_zm_load_slice< 2, 7u >( S, T.ip, N, y, T.z + 1, true, lane * 8, rsV, rsE );
-   [&]< int... J >( std::integer_sequence< int, J... > ) { ( ( S[3][J] = 0.0 ), ... ); }
-   ( std::make_integer_sequence< int, kCols.n >{} );
-   while ( T.left > 0 )
-   {
-      p2_zm_step< UPDATE, 0 >( A, S, T, lane, x, y, mask, rsV, rsE, rdV, rdE );
-      if ( T.left <= 0 )
-         break;
-      p2_zm_step< UPDATE, 1 >( A, S, T, lane, x, y, mask, rsV, rsE, rdV, rdE );
-      if ( T.left <= 0 )
-         break;
-      p2_zm_step< UPDATE, 2 >( A, S, T, lane, x, y, mask, rsV, rsE, rdV, rdE );
-      if ( T.left <= 0 )
-         break;
-      p2_zm_step< UPDATE, 3 >( A, S, T, lane, x, y, mask, rsV, rsE, rdV, rdE );
-   }
+   ( std::make_integer_sequence< int, 8 >{} );
 }
 
-// boundary DoFs with x = 0 or x + y + z = n (thread per DoF) first, then the z-march waves: one launch
-template < int UPDATE, bool SINGLE >
-__global__ __launch_bounds__( kThreads, 2 ) void p2_apply_zmarch_kernel( const Tile* tiles, int ntiles, int xcd_chunk, const P2RowsArgs A, unsigned mask,
-                                                                         int nbx )
+template < int UPDATE, int NP >
+__global__ __launch_bounds__( kThreads ) void p2_class_rows_kernel( const Tile* tiles, int ntiles, int xcd_chunk, const P2RowsArgs A, unsigned mask )
 {
-   if ( (int) blockIdx.x < 8 * nbx )
-   {
-      P2ClassArgs B;
-      B.F    = A.F;
-      B.mask = mask & HYTEG_HIP_MASK_SHELL & ~kZmUniformClasses;
-      p2_boundary_dispatch( B, (int) blockIdx.x / nbx, (int) blockIdx.x % nbx );
-      return;
-   }
-   p2_zmarch_body< UPDATE, SINGLE >( A, tiles, ntiles, xcd_chunk, (int) blockIdx.x - 8 * nbx, mask );
+   p2_classrows_body< UPDATE, NP >( A, tiles, ntiles, xcd_chunk, (int) blockIdx.x, mask );
 }
 
-template < int UPDATE, bool SINGLE >
-__global__ __launch_bounds__( kThreads, 2 ) void p2_zmarch_only_kernel( const Tile* tiles, int ntiles, int xcd_chunk, const P2RowsArgs A, unsigned mask )
-{
-   p2_zmarch_body< UPDATE, SINGLE >( A, tiles, ntiles, xcd_chunk, (int) blockIdx.x, mask );
-}
-
-// first level the z-march form is used at (HYTEG_HIP_P2_ZMARCH_MIN_LEVEL, hyteg_hip_p2_set_zmarch_min_level: tests run it at small
+// first level the row kernel with every point class is used at (HYTEG_HIP_P2_CLASS_ROWS_MIN_LEVEL, hyteg_hip_p2_set_class_rows_min_level: tests run it at small
 // levels, 99 = the row kernel of round 2 at every level)
-std::atomic< int >& zm_min_level()
+std::atomic< int >& class_rows_min_level()
 {
    static std::atomic< int > v( [] {
-      const char* e = std::getenv( "HYTEG_HIP_P2_ZMARCH_MIN_LEVEL" );
-      return e ? std::atoi( e ) : kZmMinLevel;
+      const char* e = std::getenv( "HYTEG_HIP_P2_CLASS_ROWS_MIN_LEVEL" );
+      return e ? std::atoi( e ) : kClassRowsMinLevel;
    }() );
    return v;
 }
 
-// slices per wave (HYTEG_HIP_P2_ZMARCH_LZ, hyteg_hip_p2_set_zmarch_slices): 1 = the SINGLE form
-std::atomic< int >& zm_slices()
+// tiles of the row kernel with every point class: (x0, y, z) with x0 a multiple of the capacity (62 positions per lane position), over the positions (x, y, z) with x + y + z <= N - 2 (where some kind
+// has a DoF off the planes x = 0 and x + y + z = n)
+int get_class_rows_tiles( int level, int capacity, TileTable* out )
 {
-   static std::atomic< int > v( [] {
-      const char* e = std::getenv( "HYTEG_HIP_P2_ZMARCH_LZ" );
-      const int   q = e ? std::atoi( e ) : kZmDefaultSlices;
-      return q >= 1 && q <= 64 ? q : kZmDefaultSlices;
-   }() );
-   return v;
-}
-
-// tiles of the z-march: (x0, y, z0) with x0 a multiple of 62, z0 a multiple of LZ, over the positions (x, y, z) with x + y + z <= N - 2
-// (where some kind has a DoF off the planes x = 0 and x + y + z = n)
-int get_zm_tiles( int level, int LZ, TileTable* out )
-{
-   static std::mutex                                          mtx;
+   static std::mutex                                         mtx;
    static std::map< std::tuple< int, int, int >, TileTable > cache;
-   int                                                        dev = 0;
+   int                                                  dev = 0;
    HH_CHECK_HIP( hipGetDevice( &dev ) );
    std::lock_guard< std::mutex > lock( mtx );
-   const auto                    key = std::make_tuple( dev, level, LZ );
+   const auto                    key = std::make_tuple( dev, level, capacity );
    auto                          it  = cache.find( key );
    if ( it != cache.end() )
    {
@@ -1558,16 +1535,16 @@ int get_zm_tiles( int level, int LZ, TileTable* out )
    }
    const int           N = ( 1 << level ) + 1;
    std::vector< Tile > host;
-   for ( int z0 = 0; z0 <= N - 2; z0 += LZ )
-      for ( int y = 0; y <= N - 2 - z0; ++y )
-         for ( int x0 = 0; x0 <= N - 2 - y - z0; x0 += kRowsDppCapacity )
+   for ( int z = 0; z <= N - 1; ++z )
+      for ( int y = 0; y <= N - 1 - z; ++y )
+         for ( int x0 = 0; x0 <= N - 1 - y - z; x0 += capacity )
          {
             Tile tl{};
-            tl.a      = cell_index( N, x0, y, z0 );
-            tl.pad[0] = cell_index( N - 1, x0, y, z0 );
-            tl.pad[1] = cell_index( N - 2, x0, y, z0 );
-            tl.ya = y, tl.yb = x0, tl.z = z0;
-            tl.cnt = std::min( LZ, N - 1 - y - x0 - z0 );
+            tl.a      = cell_index( N, x0, y, z );
+            tl.pad[0] = cell_index( N - 1, x0, y, z );
+            tl.pad[1] = cell_index( N - 2, x0, y, z );
+            tl.ya = y, tl.yb = x0, tl.z = z;
+            tl.cnt = std::min( capacity, N - y - z - x0 );
             host.push_back( tl );
          }
    TileTable tt;
@@ -1632,18 +1609,10 @@ extern "C" {
 
 HYTEG_HIP_API size_t hyteg_hip_p2_operator_table_size( void ) { return (size_t) kOperatorTableSize; }
 
-HYTEG_HIP_API int hyteg_hip_p2_set_zmarch_min_level( int level )
+HYTEG_HIP_API int hyteg_hip_p2_set_class_rows_min_level( int level )
 {
-   const int before = zm_min_level().load();
-   zm_min_level().store( level < 3 ? 3 : level );
-   return before;
-}
-
-HYTEG_HIP_API int hyteg_hip_p2_set_zmarch_slices( int slices )
-{
-   const int before = zm_slices().load();
-   if ( slices >= 1 && slices <= 64 )
-      zm_slices().store( slices );
+   const int before = class_rows_min_level().load();
+   class_rows_min_level().store( level < 3 ? 3 : level );
    return before;
 }
 
@@ -2103,15 +2072,11 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell_kinds( double*            
    const int  faces = 4 * tri( F.N );
    const int  nbx   = ( faces + kThreads - 1 ) / kThreads;
    const bool rows  = ( mask & HYTEG_HIP_MASK_INNER ) && level >= 3 && !perThread;
-   const int zmMinLevel = zm_min_level().load( std::memory_order_relaxed );
-   if ( rows && kind_mask == 0xFFu && level >= zmMinLevel )
+   if ( rows && kind_mask == 0xFFu && level >= class_rows_min_level().load( std::memory_order_relaxed ) )
    {
-      // all kinds at the fine levels: z-march waves (inner DoFs and the macro-faces z = 0, y = 0) + the rest of the boundary in one launch
-      const int zmLZ = zm_slices().load( std::memory_order_relaxed );
-      if ( const char* e = std::getenv( "HYTEG_HIP_P2_ZM_DEBUG" ) ) // DEBUG
-         mask |= (unsigned) std::atoi( e ) << 16;
+      // all kinds: one launch of row waves for the inner DoFs and every boundary class
       TileTable tt;
-      const int rc = get_zm_tiles( level, zmLZ, &tt );
+      const int rc = get_class_rows_tiles( level, 62, &tt );
       if ( rc != HYTEG_HIP_OK )
          return rc;
       P2RowsArgs R;
@@ -2126,26 +2091,12 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell_kinds( double*            
          R.xcd_chunk = (int) ( ( waveBlocks + 7 ) / 8 );
          waveBlocks  = 8u * (unsigned) R.xcd_chunk;
       }
-      const int nb = ( mask & HYTEG_HIP_MASK_SHELL & ~kZmUniformClasses ) ? nbx : 0;
-#define P2_LAUNCH_ZM( UPD, SGL )                                                                                                             \
-   do                                                                                                                                          \
-   {                                                                                                                                           \
-      if ( nb == 0 )                                                                                                                           \
-         hipLaunchKernelGGL( ( p2_zmarch_only_kernel< UPD, SGL > ), dim3( waveBlocks ), dim3( kThreads ), 0, s, R.tiles, R.ntiles, R.xcd_chunk, \
-                             R, mask );                                                                                                        \
-      else                                                                                                                                     \
-         hipLaunchKernelGGL( ( p2_apply_zmarch_kernel< UPD, SGL > ), dim3( 8 * nb + waveBlocks ), dim3( kThreads ), 0, s, R.tiles, R.ntiles,  \
-                             R.xcd_chunk, R, mask, nb );                                                                                       \
-   } while ( 0 )
-      if ( zmLZ == 1 && update == HYTEG_HIP_ADD )
-         P2_LAUNCH_ZM( HYTEG_HIP_ADD, true );
-      else if ( zmLZ == 1 )
-         P2_LAUNCH_ZM( HYTEG_HIP_REPLACE, true );
-      else if ( update == HYTEG_HIP_ADD )
-         P2_LAUNCH_ZM( HYTEG_HIP_ADD, false );
+      if ( update == HYTEG_HIP_ADD )
+         hipLaunchKernelGGL( ( p2_class_rows_kernel< HYTEG_HIP_ADD, 1 > ), dim3( waveBlocks ), dim3( kThreads ), 0, s, R.tiles, R.ntiles, R.xcd_chunk, R,
+                             mask );
       else
-         P2_LAUNCH_ZM( HYTEG_HIP_REPLACE, false );
-#undef P2_LAUNCH_ZM
+         hipLaunchKernelGGL( ( p2_class_rows_kernel< HYTEG_HIP_REPLACE, 1 > ), dim3( waveBlocks ), dim3( kThreads ), 0, s, R.tiles, R.ntiles,
+                             R.xcd_chunk, R, mask );
       HH_CHECK_HIP( hipGetLastError() );
       return HYTEG_HIP_OK;
    }

@@ -661,13 +661,11 @@ HYTEG_HIP_API int    hyteg_hip_p2_elementwise_apply_cell_kinds( double*         
                                                           unsigned           kind_mask,
                                                           hyteg_hip_stream_t stream );
 
-/* The level from which hyteg_hip_p2_elementwise_apply_cell( .., kind mask 0xFF ) uses the z-march form of the row kernel (default 7;
- * clamped to >= 3; 99 = never).  Returns the previous value.  Results of the two forms agree to rounding (different partial sums), so
- * this is a tuning and test switch, not part of the operator interface (no reference counterpart). */
-HYTEG_HIP_API int hyteg_hip_p2_set_zmarch_min_level( int level );
-/* Slices of the macro-cell one wave of that kernel marches through (1 .. 64; 1 = one slice per wave, every row read once per
- * wave and role, the default).  Returns the previous value; out-of-range arguments change nothing. */
-HYTEG_HIP_API int hyteg_hip_p2_set_zmarch_slices( int slices );
+/* The level from which hyteg_hip_p2_elementwise_apply_cell( .., kind mask 0xFF, mask with the inner DoFs ) uses the row kernel that
+ * computes every point class (default 3, its lowest; 99 = never: the row kernel for the inner DoFs + the thread-per-DoF boundary kernel
+ * of rounds 1-2).  Returns the previous value.  Results of the two agree to rounding (different partial sums), so this is a tuning and
+ * test switch, not part of the operator interface (no reference counterpart). */
+HYTEG_HIP_API int hyteg_hip_p2_set_class_rows_min_level( int level );
 
 /* hyteg_hip_p2_edge_vector_cell_kinds for up to HYTEG_HIP_MAX_BATCH macro-cells of one level in ONE launch (the EdgeDoFFunction loops over
  * the macro-cells of a rank, src/hyteg/edgedofspace/EdgeDoFFunction.cpp): dst and masks are HOST arrays of ncells entries, srcs a HOST

@@ -1,7 +1,8 @@
-"""GPU parity of the z-march form of the P2 row kernel (p2_apply_zmarch_kernel: inner DoFs and the DoFs of the macro-faces z = 0 and
-y = 0 by marching waves, the rest of the boundary thread by thread), which hyteg_hip_p2_elementwise_apply_cell uses from level 7:
-run here from level 3 (hyteg_hip_p2_set_zmarch_min_level) against the CPU restatement of P2ElementwiseOperator::gemv
-(oracle/p1_oracle.c ho_p2_elementwise_apply_cell) and against the row kernel of the other levels."""
+"""GPU parity of the P2 row kernel that computes every point class (p2_class_rows_kernel: inner DoFs and all boundary classes by row
+waves with wave-uniform class weights), which hyteg_hip_p2_elementwise_apply_cell uses from level 3, against the CPU restatement of
+P2ElementwiseOperator::gemv (oracle/p1_oracle.c ho_p2_elementwise_apply_cell), mask by mask, and against the kernels of rounds 1-2
+(row kernel for the inner DoFs + thread-per-DoF boundary kernel; hyteg_hip_p2_set_class_rows_min_level( 99 )) at the levels the
+oracle takes too long for."""
 import numpy as np
 import pytest
 
@@ -22,27 +23,25 @@ def env():
     return torch, capi, po
 
 
-@pytest.fixture(params=[1, 8, 3])
-def zmarch_from_level_3(env, request):
-    """the kernel from level 3, with 1 (the default form), 8 and 3 slices per wave"""
+@pytest.fixture()
+def class_rows_from_level_3(env):
     capi = env[1]
-    before, slices = capi.p2_set_zmarch_min_level(3), capi.p2_set_zmarch_slices(request.param)
+    before = capi.p2_set_class_rows_min_level(3)
     yield
-    capi.p2_set_zmarch_min_level(before)
-    capi.p2_set_zmarch_slices(slices)
+    capi.p2_set_class_rows_min_level(before)
 
 
 def _dev(torch, a):
     return torch.from_numpy(np.ascontiguousarray(a)).to("cuda")
 
 
-MASKS = ((0x7FFF, 0, 1.0), (1 << 14, 0, 1.0), (0x7FFF, 1, -0.5), (0x4000 | 0x2A5, 0, 2.0), (0x4000 | (1 << 6), 1, 1.0), (0x4000 | (1 << 7) | 1, 0, 1.0),
+MASKS = tuple((0x4000 | (1 << c), 0, 1.0) for c in range(14)) + tuple(((1 << 14) | (0x3FFF & ~(1 << c)), 1, 0.5) for c in (1, 5, 8, 9, 12)) + ((0x7FFF, 0, 1.0), (1 << 14, 0, 1.0), (0x7FFF, 1, -0.5), (0x4000 | 0x2A5, 0, 2.0), (0x4000 | (1 << 6), 1, 1.0), (0x4000 | (1 << 7) | 1, 0, 1.0),
          (0x4000 | 0x3F3E, 0, 1.0))
 
 
 @pytest.mark.parametrize("level", [3, 4, 5])
 @pytest.mark.parametrize("tet", [REF_TET, SKEW_TET])
-def test_zmarch_apply_matches_the_oracle(env, zmarch_from_level_3, level, tet):
+def test_class_rows_apply_matches_the_oracle(env, class_rows_from_level_3, level, tet):
     torch, capi, po = env
     nv, ne = po.cell_size(level), po.edge_array_size(level)
     em = po.p2_cell_element_matrices(np.asarray(tet, dtype=np.float64).reshape(12), level)
@@ -62,9 +61,8 @@ def test_zmarch_apply_matches_the_oracle(env, zmarch_from_level_3, level, tet):
         assert np.array_equal(gv[~sel_v], dv0[~sel_v]) and np.array_equal(ge[~sel_e], de0[~sel_e]), (level, hex(mask), update)
 
 
-@pytest.mark.parametrize("slices", [1, 8])
 @pytest.mark.parametrize("level", [6, 7])
-def test_zmarch_equals_the_row_kernel_to_rounding(env, level, slices):
+def test_class_rows_equal_the_kernels_of_round_2_to_rounding(env, level):
     """levels the oracle takes too long for: the two forms of the kernel on the same input (they differ in the order of the sum only),
     every DoF written by exactly one of the launch's two parts"""
     torch, capi, po = env
@@ -75,7 +73,7 @@ def test_zmarch_equals_the_row_kernel_to_rounding(env, level, slices):
     sv, se = _dev(torch, rng.standard_normal(nv)), _dev(torch, rng.standard_normal(ne))
     out = {}
     for first in (99, 3):
-        before, lz = capi.p2_set_zmarch_min_level(first), capi.p2_set_zmarch_slices(slices)
+        before = capi.p2_set_class_rows_min_level(first)
         try:
             for mask, update in ((0x7FFF, 0), (0x7FFF, 1), (0x4000, 0)):
                 dv, de = torch.full((nv,), 0.25, dtype=torch.float64, device="cuda"), torch.full((ne,), -0.5, dtype=torch.float64, device="cuda")
@@ -83,8 +81,7 @@ def test_zmarch_equals_the_row_kernel_to_rounding(env, level, slices):
                 torch.cuda.synchronize()
                 out[first, mask, update] = (dv.cpu().numpy(), de.cpu().numpy())
         finally:
-            capi.p2_set_zmarch_min_level(before)
-            capi.p2_set_zmarch_slices(lz)
+            capi.p2_set_class_rows_min_level(before)
     for mask, update in ((0x7FFF, 0), (0x7FFF, 1), (0x4000, 0)):
         (av, ae), (bv, be) = out[99, mask, update], out[3, mask, update]
         scale = max(np.abs(av).max(), np.abs(ae).max())
@@ -93,7 +90,7 @@ def test_zmarch_equals_the_row_kernel_to_rounding(env, level, slices):
         assert np.array_equal(av == 0.25, bv == 0.25) and np.array_equal(ae == -0.5, be == -0.5)
 
 
-def test_zmarch_reads_rows_that_do_not_exist_as_zero(env, zmarch_from_level_3):
+def test_class_rows_read_rows_that_do_not_exist_as_zero(env, class_rows_from_level_3):
     """a weight that is exactly zero (neighbour outside the macro-cell) must not meet a stray value: NaNs in the DESTINATION arrays'
     neighbourhood are harmless by construction; here the source is finite and huge in the first and last entries of every kind's
     array, next to which the rows of the faces y = 0 and z = 0 are read"""

@@ -1,4 +1,4 @@
-"""P2 apply at level 7 (and 6): row kernel of round 2 against the z-march form, LZ from the environment"""
+"""P2 apply, one macro-cell, levels 4-8: the kernels of round 2 (rows + thread-per-DoF boundary) against the row kernel with every point class"""
 import sys, os
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
@@ -7,7 +7,7 @@ from hyteg_amd import capi
 from oracle import p1_oracle as po
 
 REF = np.array([0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1], dtype=np.float64)
-for level in (6, 7):
+for level in (4, 5, 6, 7, 8):
     nv, ne = capi.cell_size(level), capi.p2_edge_array_size(level)
     em = po.p2_cell_element_matrices(REF, min(level, 6))
     dem = torch.from_numpy(capi.p2_build_operator_table(em)).cuda()
@@ -26,8 +26,8 @@ for level in (6, 7):
             e1.record(); torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) * 1e3 / n)
         return best
-    for first, name in ((99, "rows (round 2)"), (3, "z-march")):
-        capi.p2_set_zmarch_min_level(first)
+    for first, name in ((99, "rows (round 2)"), (3, "class rows")):
+        capi.p2_set_class_rows_min_level(first)
         run(0x7FFF, 20)
-        print(f"level {level} {name:16s} all {run(0x7FFF):8.2f} us   inner only {run(0x4000):8.2f} us   ({nb} buffer pairs, LZ={os.environ.get('HYTEG_HIP_P2_ZMARCH_LZ','8')})", flush=True)
+        print(f"level {level} {name:16s} all {run(0x7FFF):8.2f} us   inner only {run(0x4000):8.2f} us   ({nb} buffer pairs)", flush=True)
     del S, D
