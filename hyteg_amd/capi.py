@@ -516,6 +516,16 @@ def p2_edge_dot_cell_masked(a, b, level, mask, result_dev, workspace_dev, stream
     check(lib().hyteg_hip_p2_edge_dot_cell_masked(a, b, level, mask, result_dev, workspace_dev, stream), "p2_edge_dot_cell_masked")
 
 
+def p2_elementwise_apply_cells(dst_v, dst_e, src_v, src_e, level, optables_dev, masks, alpha=1.0, update=REPLACE, kinds=0xFF, stream=0):
+    """hyteg_hip_p2_elementwise_apply_cells_kinds: the cells of one launch (lists of device pointers, one operator table and one
+    point mask per cell), levels 2..6"""
+    n = len(dst_v)
+    arr = lambda xs: (C.c_void_p * n)(*[int(x) for x in xs])
+    check(lib().hyteg_hip_p2_elementwise_apply_cells_kinds(n, arr(dst_v), arr(dst_e), arr(src_v), arr(src_e), int(level), arr(optables_dev),
+                                                           float(alpha), int(update), (C.c_uint * n)(*[int(m) for m in masks]), int(kinds),
+                                                           stream), "p2_elementwise_apply_cells_kinds")
+
+
 def p2_set_class_rows_min_level(level) -> int:
     """first level hyteg_hip_p2_elementwise_apply_cell uses the row kernel with every point class at (default 3; 99 = the kernels of rounds 1-2); returns the previous value"""
     return int(lib().hyteg_hip_p2_set_class_rows_min_level(int(level)))

@@ -1506,6 +1506,19 @@ __global__ __launch_bounds__( kThreads ) void p2_class_rows_kernel( const Tile* 
    p2_classrows_body< UPDATE, NP >( A, tiles, ntiles, xcd_chunk, (int) blockIdx.x, mask );
 }
 
+// the same for up to HYTEG_HIP_MAX_BATCH macro-cells of one level (blockIdx.y = cell), as p2_inner_batch_kernel
+template < int UPDATE >
+__global__ __launch_bounds__( kThreads ) void p2_class_rows_batch_kernel( const Tile* tiles, int ntiles, const P2RowsArgs A, const P2BatchPtrs P )
+{
+   const int      cell = blockIdx.y;
+   const unsigned mask = P.mask[cell];
+   if ( mask == 0 )
+      return;
+   P2RowsArgs B = A;
+   B.F          = p2_batch_view( A.F, P, cell );
+   p2_classrows_body< UPDATE, 1 >( B, tiles, ntiles, 0, (int) blockIdx.x, mask );
+}
+
 // first level the row kernel with every point class is used at (HYTEG_HIP_P2_CLASS_ROWS_MIN_LEVEL, hyteg_hip_p2_set_class_rows_min_level: tests run it at small
 // levels, 99 = the row kernel of round 2 at every level)
 std::atomic< int >& class_rows_min_level()
@@ -2473,6 +2486,26 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cells_kinds( int ncells, double
    P2FastArgs F{};
    F.alpha = alpha, F.N = ( 1 << level ) + 1, F.update = update, F.kinds = kind_mask;
    hipStream_t s = as_stream( stream );
+   if ( kind_mask == 0xFFu && level >= class_rows_min_level().load( std::memory_order_relaxed ) )
+   {
+      // all kinds: row waves for the inner DoFs and every boundary class of every cell, one launch
+      TileTable tt;
+      const int rc = get_class_rows_tiles( level, 62, &tt );
+      if ( rc != HYTEG_HIP_OK )
+         return rc;
+      P2RowsArgs R;
+      R.F = F, R.tiles = tt.dev, R.ntiles = tt.count, R.xcd_chunk = 0;
+      const int n = F.N - 1;
+      R.vbytes    = (unsigned) ( tet64( F.N ) * 8 );
+      R.ebytes    = (unsigned) ( ( 6 * tet64( n ) + tet64( n - 1 ) ) * 8 );
+      const dim3 grid( (unsigned) ( ( tt.count + kRowsWaves - 1 ) / kRowsWaves ), (unsigned) ncells );
+      if ( update == HYTEG_HIP_ADD )
+         hipLaunchKernelGGL( ( p2_class_rows_batch_kernel< HYTEG_HIP_ADD > ), grid, dim3( kThreads ), 0, s, R.tiles, R.ntiles, R, P );
+      else
+         hipLaunchKernelGGL( ( p2_class_rows_batch_kernel< HYTEG_HIP_REPLACE > ), grid, dim3( kThreads ), 0, s, R.tiles, R.ntiles, R, P );
+      HH_CHECK_HIP( hipGetLastError() );
+      return HYTEG_HIP_OK;
+   }
    if ( any & HYTEG_HIP_MASK_INNER )
    {
       const int64_t largest = tet64( F.N );

@@ -108,3 +108,32 @@ def test_class_rows_read_rows_that_do_not_exist_as_zero(env, class_rows_from_lev
     torch.cuda.synchronize()
     scale = max(np.abs(wv).max(), np.abs(we).max())
     assert np.abs(dv.cpu().numpy() - wv).max() <= 1e-13 * scale and np.abs(de.cpu().numpy() - we).max() <= 1e-13 * scale
+
+
+@pytest.mark.parametrize("level", [3, 4])
+@pytest.mark.parametrize("update", [0, 1])
+def test_class_rows_batched_over_cells_match_the_oracle(env, level, update):
+    """hyteg_hip_p2_elementwise_apply_cells_kinds with every kind: one launch of row waves for all cells, each cell with its own
+    arrays, operator table and point mask (one of them without the inner DoFs, one empty)"""
+    torch, capi, po = env
+    from conftest import OCT_TET
+
+    nv, ne = po.cell_size(level), po.edge_array_size(level)
+    tets, masks = [REF_TET, SKEW_TET, OCT_TET, REF_TET, SKEW_TET], [0x7FFF, 0x4000 | 0x2A5, 0x3FFF, 0, 0x4000]
+    rng = np.random.default_rng(31 + level)
+    keep, want = [], []
+    lists = {k: [] for k in ("dv", "de", "sv", "se", "tab")}
+    for tet, mask in zip(tets, masks):
+        em = po.p2_cell_element_matrices(np.asarray(tet, dtype=np.float64).reshape(12), level)
+        sv, se, dv0, de0 = rng.standard_normal(nv), rng.standard_normal(ne), rng.standard_normal(nv), rng.standard_normal(ne)
+        want.append(po.p2_elementwise_apply_cell(dv0.copy(), de0.copy(), sv, se, level, em, -1.5, update, mask))
+        dev = [_dev(torch, a) for a in (dv0, de0, sv, se, capi.p2_build_operator_table(em))]
+        keep.append(dev)
+        for k, d in zip(("dv", "de", "sv", "se", "tab"), dev):
+            lists[k].append(d.data_ptr())
+    capi.p2_elementwise_apply_cells(lists["dv"], lists["de"], lists["sv"], lists["se"], level, lists["tab"], masks, -1.5, update)
+    torch.cuda.synchronize()
+    for (wv, we), dev in zip(want, keep):
+        gv, ge = dev[0].cpu().numpy(), dev[1].cpu().numpy()
+        scale = max(np.abs(wv).max(), np.abs(we).max(), 1.0)
+        assert np.abs(gv - wv).max() <= 1e-13 * scale and np.abs(ge - we).max() <= 1e-13 * scale
