@@ -1324,7 +1324,7 @@ constexpr DxUse< C > build_dx_use()
 // (kinds that can lie in that plane; tiles with x0 = 0).  PASS 2: the last DoF of the row, on x + y + z = n (kinds that can lie in that
 // plane; the tile that holds it), unless it is the one at x = 0.  Every pass has ONE point class per wave, so its weights are a
 // wave-uniform row of the operator table; passes 1 and 2 run the whole wave for one lane's DoF.
-template < int C, int UPDATE, int NP, int PASS >
+template < int C, int UPDATE, int NP, int PASS, bool RESTRICTED >
 __device__ __forceinline__ void p2_classrows_kind( const P2RowsArgs& A, const double ( &R )[kRows.n][NP], const int ( &i0 )[3], int lane, int xa, int x0,
                                               int y, int z, unsigned mask, __amdgpu_buffer_rsrc_t rdV, __amdgpu_buffer_rsrc_t rdE )
 {
@@ -1334,6 +1334,8 @@ __device__ __forceinline__ void p2_classrows_kind( const P2RowsArgs& A, const do
    constexpr bool F2 = C == 0 || C == 2 || C == 3 || C == 6;
    constexpr bool F3 = C == 0 || C == 4 || C == 5 || C == 6;
    if constexpr ( ( PASS == 1 && !F2 ) || ( PASS == 2 && !F3 ) )
+      return;
+   if ( RESTRICTED && !( ( A.F.kinds >> C ) & 1u ) ) // wave-uniform: a kind-restricted apply (the per-type sweeps of the P2 Gauss-Seidel smoother)
       return;
    const int  Nn = A.F.N, nn = Nn - 1;
    const int  top = ( C == 0 ? Nn - 1 : ( C == 7 ? nn - 2 : nn - 1 ) ) - y - z; // x of the last entry of the row in the kind's array
@@ -1434,7 +1436,9 @@ __device__ __forceinline__ void p2_classrows_kind( const P2RowsArgs& A, const do
    ( std::make_integer_sequence< int, NP >{} );
 }
 
-template < int UPDATE, int NP >
+// RESTRICTED: only the destination kinds of A.F.kinds are computed and only the rows they read are loaded (the others' bases are moved
+// beyond the arrays: the load is issued and returns 0 without touching memory)
+template < int UPDATE, int NP, bool RESTRICTED = false >
 __device__ __forceinline__ void p2_classrows_body( const P2RowsArgs& A, const Tile* tiles, int ntiles, int xcd_chunk, int block, unsigned mask )
 {
    if ( xcd_chunk > 0 )
@@ -1450,6 +1454,14 @@ __device__ __forceinline__ void p2_classrows_body( const P2RowsArgs& A, const Ti
    const int  lane  = threadIdx.x & 63;
    const int  N     = A.F.N;
    const int  y = tl.ya, z = tl.z, xa = tl.yb + NP * ( lane - 1 ); // lane 0 holds the NP positions in front of x0
+   if ( !( mask & HYTEG_HIP_MASK_INNER ) )
+   {
+      // boundary classes only: a tile off the planes y = 0, z = 0 that holds neither the first nor (one of) the last entries of its rows
+      // has nothing to compute
+      const bool ends = tl.yb == 0 || tl.yb + 62 * NP > N - 2 - y - z;
+      if ( !( mask & HYTEG_HIP_MASK_SHELL ) || !( ends || y == 0 || z == 0 ) )
+         return;
+   }
    const int  i0[3] = { tl.a, tl.pad[0], tl.pad[1] };
    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc( const_cast< double* >( A.F.srcV ), 0, A.vbytes, 0x00020000 );
    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc( const_cast< double* >( A.F.srcE ), 0, A.ebytes, 0x00020000 );
@@ -1466,6 +1478,8 @@ __device__ __forceinline__ void p2_classrows_body( const P2RowsArgs& A, const Ti
       ( ( [&] {
            constexpr int K = kRows.kind[I], DY = kRows.dy[I], DZ = kRows.dz[I];
            int           base = p2_rows_base< K, DY, DZ >( i0, N, y, z ) + 8 - 8 * NP; // p2_rows_base is biased by one element
+           if ( RESTRICTED && !( kRows.users[I] & A.F.kinds ) )
+              base = kNowhere;
            if constexpr ( DY < 0 && DZ < 0 )
               base = ( rowBelow && sliceBelow ) ? base : kNowhere;
            else if constexpr ( DY < 0 )
@@ -1490,24 +1504,24 @@ __device__ __forceinline__ void p2_classrows_body( const P2RowsArgs& A, const Ti
    ( std::make_integer_sequence< int, kRows.n >{} );
 
    [&]< int... C >( std::integer_sequence< int, C... > ) {
-      ( p2_classrows_kind< C, UPDATE, NP, 0 >( A, R, i0, lane, xa, tl.yb, y, z, mask, rdV, rdE ), ... );
+      ( p2_classrows_kind< C, UPDATE, NP, 0, RESTRICTED >( A, R, i0, lane, xa, tl.yb, y, z, mask, rdV, rdE ), ... );
       if ( mask & HYTEG_HIP_MASK_SHELL ) // wave-uniform: the DoFs on x = 0 and on x + y + z = n
       {
-         ( p2_classrows_kind< C, UPDATE, NP, 1 >( A, R, i0, lane, xa, tl.yb, y, z, mask, rdV, rdE ), ... );
-         ( p2_classrows_kind< C, UPDATE, NP, 2 >( A, R, i0, lane, xa, tl.yb, y, z, mask, rdV, rdE ), ... );
+         ( p2_classrows_kind< C, UPDATE, NP, 1, RESTRICTED >( A, R, i0, lane, xa, tl.yb, y, z, mask, rdV, rdE ), ... );
+         ( p2_classrows_kind< C, UPDATE, NP, 2, RESTRICTED >( A, R, i0, lane, xa, tl.yb, y, z, mask, rdV, rdE ), ... );
       }
    }
    ( std::make_integer_sequence< int, 8 >{} );
 }
 
-template < int UPDATE, int NP >
+template < int UPDATE, int NP, bool RESTRICTED >
 __global__ __launch_bounds__( kThreads ) void p2_class_rows_kernel( const Tile* tiles, int ntiles, int xcd_chunk, const P2RowsArgs A, unsigned mask )
 {
-   p2_classrows_body< UPDATE, NP >( A, tiles, ntiles, xcd_chunk, (int) blockIdx.x, mask );
+   p2_classrows_body< UPDATE, NP, RESTRICTED >( A, tiles, ntiles, xcd_chunk, (int) blockIdx.x, mask );
 }
 
 // the same for up to HYTEG_HIP_MAX_BATCH macro-cells of one level (blockIdx.y = cell), as p2_inner_batch_kernel
-template < int UPDATE >
+template < int UPDATE, bool RESTRICTED >
 __global__ __launch_bounds__( kThreads ) void p2_class_rows_batch_kernel( const Tile* tiles, int ntiles, const P2RowsArgs A, const P2BatchPtrs P )
 {
    const int      cell = blockIdx.y;
@@ -1516,7 +1530,7 @@ __global__ __launch_bounds__( kThreads ) void p2_class_rows_batch_kernel( const 
       return;
    P2RowsArgs B = A;
    B.F          = p2_batch_view( A.F, P, cell );
-   p2_classrows_body< UPDATE, 1 >( B, tiles, ntiles, 0, (int) blockIdx.x, mask );
+   p2_classrows_body< UPDATE, 1, RESTRICTED >( B, tiles, ntiles, 0, (int) blockIdx.x, mask );
 }
 
 // first level the row kernel with every point class is used at (HYTEG_HIP_P2_CLASS_ROWS_MIN_LEVEL, hyteg_hip_p2_set_class_rows_min_level: tests run it at small
@@ -2085,9 +2099,9 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell_kinds( double*            
    const int  faces = 4 * tri( F.N );
    const int  nbx   = ( faces + kThreads - 1 ) / kThreads;
    const bool rows  = ( mask & HYTEG_HIP_MASK_INNER ) && level >= 3 && !perThread;
-   if ( rows && kind_mask == 0xFFu && level >= class_rows_min_level().load( std::memory_order_relaxed ) )
+   if ( level >= 3 && !perThread && level >= class_rows_min_level().load( std::memory_order_relaxed ) )
    {
-      // all kinds: one launch of row waves for the inner DoFs and every boundary class
+      // one launch of row waves for the inner DoFs and every boundary class (all kinds, or the kinds of kind_mask)
       TileTable tt;
       const int rc = get_class_rows_tiles( level, 62, &tt );
       if ( rc != HYTEG_HIP_OK )
@@ -2104,12 +2118,17 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell_kinds( double*            
          R.xcd_chunk = (int) ( ( waveBlocks + 7 ) / 8 );
          waveBlocks  = 8u * (unsigned) R.xcd_chunk;
       }
-      if ( update == HYTEG_HIP_ADD )
-         hipLaunchKernelGGL( ( p2_class_rows_kernel< HYTEG_HIP_ADD, 1 > ), dim3( waveBlocks ), dim3( kThreads ), 0, s, R.tiles, R.ntiles, R.xcd_chunk, R,
-                             mask );
+#define P2_LAUNCH_CLASS_ROWS( UPD, RES )                                                                                                       \
+   hipLaunchKernelGGL( ( p2_class_rows_kernel< UPD, 1, RES > ), dim3( waveBlocks ), dim3( kThreads ), 0, s, R.tiles, R.ntiles, R.xcd_chunk, R, mask )
+      if ( kind_mask != 0xFFu && update == HYTEG_HIP_ADD )
+         P2_LAUNCH_CLASS_ROWS( HYTEG_HIP_ADD, true );
+      else if ( kind_mask != 0xFFu )
+         P2_LAUNCH_CLASS_ROWS( HYTEG_HIP_REPLACE, true );
+      else if ( update == HYTEG_HIP_ADD )
+         P2_LAUNCH_CLASS_ROWS( HYTEG_HIP_ADD, false );
       else
-         hipLaunchKernelGGL( ( p2_class_rows_kernel< HYTEG_HIP_REPLACE, 1 > ), dim3( waveBlocks ), dim3( kThreads ), 0, s, R.tiles, R.ntiles,
-                             R.xcd_chunk, R, mask );
+         P2_LAUNCH_CLASS_ROWS( HYTEG_HIP_REPLACE, false );
+#undef P2_LAUNCH_CLASS_ROWS
       HH_CHECK_HIP( hipGetLastError() );
       return HYTEG_HIP_OK;
    }
@@ -2486,9 +2505,9 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cells_kinds( int ncells, double
    P2FastArgs F{};
    F.alpha = alpha, F.N = ( 1 << level ) + 1, F.update = update, F.kinds = kind_mask;
    hipStream_t s = as_stream( stream );
-   if ( kind_mask == 0xFFu && level >= class_rows_min_level().load( std::memory_order_relaxed ) )
+   if ( level >= class_rows_min_level().load( std::memory_order_relaxed ) )
    {
-      // all kinds: row waves for the inner DoFs and every boundary class of every cell, one launch
+      // row waves for the inner DoFs and every boundary class of every cell, one launch (all kinds, or the kinds of kind_mask)
       TileTable tt;
       const int rc = get_class_rows_tiles( level, 62, &tt );
       if ( rc != HYTEG_HIP_OK )
@@ -2499,10 +2518,17 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cells_kinds( int ncells, double
       R.vbytes    = (unsigned) ( tet64( F.N ) * 8 );
       R.ebytes    = (unsigned) ( ( 6 * tet64( n ) + tet64( n - 1 ) ) * 8 );
       const dim3 grid( (unsigned) ( ( tt.count + kRowsWaves - 1 ) / kRowsWaves ), (unsigned) ncells );
-      if ( update == HYTEG_HIP_ADD )
-         hipLaunchKernelGGL( ( p2_class_rows_batch_kernel< HYTEG_HIP_ADD > ), grid, dim3( kThreads ), 0, s, R.tiles, R.ntiles, R, P );
+#define P2_LAUNCH_CLASS_ROWS( UPD, RES ) \
+   hipLaunchKernelGGL( ( p2_class_rows_batch_kernel< UPD, RES > ), grid, dim3( kThreads ), 0, s, R.tiles, R.ntiles, R, P )
+      if ( kind_mask != 0xFFu && update == HYTEG_HIP_ADD )
+         P2_LAUNCH_CLASS_ROWS( HYTEG_HIP_ADD, true );
+      else if ( kind_mask != 0xFFu )
+         P2_LAUNCH_CLASS_ROWS( HYTEG_HIP_REPLACE, true );
+      else if ( update == HYTEG_HIP_ADD )
+         P2_LAUNCH_CLASS_ROWS( HYTEG_HIP_ADD, false );
       else
-         hipLaunchKernelGGL( ( p2_class_rows_batch_kernel< HYTEG_HIP_REPLACE > ), grid, dim3( kThreads ), 0, s, R.tiles, R.ntiles, R, P );
+         P2_LAUNCH_CLASS_ROWS( HYTEG_HIP_REPLACE, false );
+#undef P2_LAUNCH_CLASS_ROWS
       HH_CHECK_HIP( hipGetLastError() );
       return HYTEG_HIP_OK;
    }

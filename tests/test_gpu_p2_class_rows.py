@@ -61,6 +61,37 @@ def test_class_rows_apply_matches_the_oracle(env, class_rows_from_level_3, level
         assert np.array_equal(gv[~sel_v], dv0[~sel_v]) and np.array_equal(ge[~sel_e], de0[~sel_e]), (level, hex(mask), update)
 
 
+@pytest.mark.parametrize("level", [3, 4])
+def test_class_rows_restricted_to_kinds_match_the_oracle(env, class_rows_from_level_3, level):
+    """the per-type applies of the P2 Gauss-Seidel smoother: some destination kinds only, with and without the inner DoFs"""
+    torch, capi, po = env
+    nv, ne = po.cell_size(level), po.edge_array_size(level)
+    em = po.p2_cell_element_matrices(np.asarray(SKEW_TET, dtype=np.float64).reshape(12), level)
+    rng = np.random.default_rng(200 + level)
+    sv, se, dv0, de0 = rng.standard_normal(nv), rng.standard_normal(ne), rng.standard_normal(nv), rng.standard_normal(ne)
+    dem = _dev(torch, capi.p2_build_operator_table(em))
+    n = 1 << level
+    tet = lambda w: w * (w + 1) * (w + 2) // 6
+    kind_of_edge = np.concatenate([np.full(tet(n), k) for k in range(1, 7)] + [np.full(tet(n - 1), 7)])
+    assert len(kind_of_edge) == ne
+    for kinds in (0x01, 0x02, 0x10, 0x80, 0xFE, 0x4D):
+        for mask, update in ((0x7FFF, 0), (0x4000, 1), (0x3FFF, 0), (0x3FFF, 1)):
+            # the oracle computes every kind; a kind-restricted apply leaves the other kinds' entries as they were
+            fv, fe = po.p2_elementwise_apply_cell(dv0.copy(), de0.copy(), sv, se, level, em, 1.25, update, mask)
+            wv = fv if kinds & 1 else dv0
+            we = np.where((kinds >> kind_of_edge) & 1, fe, de0)
+            dsv, dse, ddv, dde = _dev(torch, sv), _dev(torch, se), _dev(torch, dv0), _dev(torch, de0)
+            capi.p2_elementwise_apply_cell(ddv.data_ptr(), dde.data_ptr(), dsv.data_ptr(), dse.data_ptr(), level, dem.data_ptr(), 1.25, update, mask,
+                                           kinds=kinds)
+            torch.cuda.synchronize()
+            gv, ge = ddv.cpu().numpy(), dde.cpu().numpy()
+            scale = max(np.abs(fv).max(), np.abs(fe).max(), 1.0)
+            assert np.abs(gv - wv).max() <= 1e-13 * scale and np.abs(ge - we).max() <= 1e-13 * scale, (level, hex(kinds), hex(mask), update)
+            if not kinds & 1:
+                assert np.array_equal(gv, dv0)
+            assert np.array_equal(ge[((kinds >> kind_of_edge) & 1) == 0], de0[((kinds >> kind_of_edge) & 1) == 0])
+
+
 @pytest.mark.parametrize("level", [6, 7])
 def test_class_rows_equal_the_kernels_of_round_2_to_rounding(env, level):
     """levels the oracle takes too long for: the two forms of the kernel on the same input (they differ in the order of the sum only),
