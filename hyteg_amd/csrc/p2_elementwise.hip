@@ -1299,6 +1299,10 @@ __global__ __launch_bounds__( kThreads, 2 ) void p2_apply_fused_kernel( const Ti
 // still takes 17 of 27 us -- the instruction stream of a wave, not the memory, is what these kernels are bound by.
 // =====================================================================================================================
 constexpr int      kClassRowsMinLevel = 3;
+#ifndef HYTEG_P2_DST_AUX
+#define HYTEG_P2_DST_AUX 0
+#endif
+constexpr int      kClassRowsDstAux   = HYTEG_P2_DST_AUX; // cache policy of the destination arrays: 0 = plain; 2 = nontemporal measured: level 7 30.1 -> 29.1 us, level 8 156 -> 162, levels 4-5 +5 %
 typedef int p2_v4i __attribute__( ( ext_vector_type( 4 ) ) );
 
 template < int C >
@@ -1426,10 +1430,10 @@ __device__ __forceinline__ void p2_classrows_kind( const P2RowsArgs& A, const do
            double     v    = A.F.alpha * acc[P];
            if constexpr ( UPDATE == HYTEG_HIP_ADD )
            {
-              const p2_v2i o = __builtin_amdgcn_raw_buffer_load_b64( rd, voff, 0, 0 );
+              const p2_v2i o = __builtin_amdgcn_raw_buffer_load_b64( rd, voff, 0, kClassRowsDstAux );
               v              = __hiloint2double( o.y, o.x ) + v;
            }
-           __builtin_amdgcn_raw_buffer_store_b64( p2_v2i{ __double2loint( v ), __double2hiint( v ) }, rd, voff, 0, 0 );
+           __builtin_amdgcn_raw_buffer_store_b64( p2_v2i{ __double2loint( v ), __double2hiint( v ) }, rd, voff, 0, kClassRowsDstAux );
         }() ),
         ... );
    }
