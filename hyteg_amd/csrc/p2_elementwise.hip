@@ -2103,7 +2103,9 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell_kinds( double*            
    const int  faces = 4 * tri( F.N );
    const int  nbx   = ( faces + kThreads - 1 ) / kThreads;
    const bool rows  = ( mask & HYTEG_HIP_MASK_INNER ) && level >= 3 && !perThread;
-   if ( level >= 3 && !perThread && level >= class_rows_min_level().load( std::memory_order_relaxed ) )
+   // a kind-restricted apply (the per-type sweeps of the Gauss-Seidel smoother) takes the class-rows kernel from level 6: below, where the
+   // launches are latency-bound, the kernels of round 2 were 5 % faster on the sweep (profiles/r03_p2_class_rows.txt (D))
+   if ( level >= 3 && !perThread && level >= class_rows_min_level().load( std::memory_order_relaxed ) && ( kind_mask == 0xFFu || level >= 6 ) )
    {
       // one launch of row waves for the inner DoFs and every boundary class (all kinds, or the kinds of kind_mask)
       TileTable tt;
@@ -2509,9 +2511,9 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cells_kinds( int ncells, double
    P2FastArgs F{};
    F.alpha = alpha, F.N = ( 1 << level ) + 1, F.update = update, F.kinds = kind_mask;
    hipStream_t s = as_stream( stream );
-   if ( level >= class_rows_min_level().load( std::memory_order_relaxed ) )
+   if ( level >= class_rows_min_level().load( std::memory_order_relaxed ) && ( kind_mask == 0xFFu || level >= 6 ) )
    {
-      // row waves for the inner DoFs and every boundary class of every cell, one launch (all kinds, or the kinds of kind_mask)
+      // row waves for the inner DoFs and every boundary class of every cell, one launch (all kinds; a kind mask from level 6, as above)
       TileTable tt;
       const int rc = get_class_rows_tiles( level, 62, &tt );
       if ( rc != HYTEG_HIP_OK )

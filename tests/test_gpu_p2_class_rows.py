@@ -61,9 +61,10 @@ def test_class_rows_apply_matches_the_oracle(env, class_rows_from_level_3, level
         assert np.array_equal(gv[~sel_v], dv0[~sel_v]) and np.array_equal(ge[~sel_e], de0[~sel_e]), (level, hex(mask), update)
 
 
-@pytest.mark.parametrize("level", [3, 4])
+@pytest.mark.parametrize("level", [4, 6])
 def test_class_rows_restricted_to_kinds_match_the_oracle(env, class_rows_from_level_3, level):
-    """the per-type applies of the P2 Gauss-Seidel smoother: some destination kinds only, with and without the inner DoFs"""
+    """the per-type applies of the P2 Gauss-Seidel smoother: some destination kinds only, with and without the inner DoFs (level 6:
+    the class-rows kernel restricted to kinds; level 4: the kernels of round 2, which keep these applies below level 6)"""
     torch, capi, po = env
     nv, ne = po.cell_size(level), po.edge_array_size(level)
     em = po.p2_cell_element_matrices(np.asarray(SKEW_TET, dtype=np.float64).reshape(12), level)
