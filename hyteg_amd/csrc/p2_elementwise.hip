@@ -8,8 +8,10 @@
 // times its ten source values.  The lists and offsets follow from celldof::macrocell::getMicroVerticesFromMicroCell
 // (volumedofspace/CellDoFIndexing.hpp:155-198) and edgedof::calcEdgeDoFIndex / calcEdgeDoFOrientation
 // (edgedofspace/EdgeDoFIndexing.hpp:89-165); they are built once on the host.
-// First version: table-driven, one thread per destination DoF, direct loads.  Parity first; the roofline work
-// (row-wise register reuse as in the P1 z-march kernel) is the next step for this row.
+// Kernels in this file, by level: levels 0-1 the table-driven micro-cell gather (p2_elementwise_kernel, one thread group per DoF);
+// level 2 and kind-restricted applies below level 6: compile-time stencils, thread per DoF (p2_inner_body, p2_boundary_body) or by
+// rows (p2_rows_body_dpp); from level 3: p2_class_rows_kernel -- row waves that compute the inner DoFs and every boundary class
+// (round 3, the section "Row kernel with every point class" below).
 #include <algorithm>
 #include <atomic>
 #include <map>

@@ -169,3 +169,28 @@ def test_class_rows_batched_over_cells_match_the_oracle(env, level, update):
         gv, ge = dev[0].cpu().numpy(), dev[1].cpu().numpy()
         scale = max(np.abs(wv).max(), np.abs(we).max(), 1.0)
         assert np.abs(gv - wv).max() <= 1e-13 * scale and np.abs(ge - we).max() <= 1e-13 * scale
+
+
+def test_class_rows_equal_the_kernels_of_round_2_at_level_8(env):
+    """the largest level of BASELINE config 4's shape class on one GPU (183 MB of DoFs per function): compared on the device"""
+    torch, capi, po = env
+    level = 8
+    nv, ne = capi.cell_size(level), capi.p2_edge_array_size(level)
+    em = po.p2_cell_element_matrices(np.asarray(SKEW_TET, dtype=np.float64).reshape(12), level)
+    dem = _dev(torch, capi.p2_build_operator_table(em))
+    g = torch.Generator(device="cuda").manual_seed(8)
+    sv, se = torch.randn(nv, dtype=torch.float64, device="cuda", generator=g), torch.randn(ne, dtype=torch.float64, device="cuda", generator=g)
+    out = {}
+    for first in (99, 3):
+        before = capi.p2_set_class_rows_min_level(first)
+        try:
+            dv, de = torch.full((nv,), 0.25, dtype=torch.float64, device="cuda"), torch.full((ne,), -0.5, dtype=torch.float64, device="cuda")
+            capi.p2_elementwise_apply_cell(dv.data_ptr(), de.data_ptr(), sv.data_ptr(), se.data_ptr(), level, dem.data_ptr(), 1.0, 1, 0x7FFF)
+            torch.cuda.synchronize()
+            out[first] = (dv, de)
+        finally:
+            capi.p2_set_class_rows_min_level(before)
+    (av, ae), (bv, be) = out[99], out[3]
+    scale = max(float(av.abs().max()), float(ae.abs().max()))
+    assert float((av - bv).abs().max()) <= 1e-13 * scale and float((ae - be).abs().max()) <= 1e-13 * scale
+    assert int((bv == 0.25).sum()) == 0 and int((be == -0.5).sum()) == 0  # ADD onto every DoF: none left as it was
