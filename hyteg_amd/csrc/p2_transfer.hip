@@ -288,12 +288,29 @@ struct P2TransferArgs
    Nnc14                 nncInv;
 };
 
-// grid.y = fine kind; one thread per fine DoF of that kind
+// Which kind and which block of that kind's array a workgroup takes.  Grid ( blocks, 8 ): kind = blockIdx.y -- all blocks of kind 0 run
+// before those of kind 1, and every kind streams the whole source again (the restriction reads 95 MB for 23 MB of fine DoFs,
+// profiles/r03_p2_transfer_rows.txt).  Grid ( 64 * groups ), a measurement switch that is off: workgroups g, g + 8, ... run on the same XCD; XCD j takes block 8 r + j of
+// kind 0, then of kind 1, ... then block 8 ( r + 1 ) + j: the eight kinds of one region follow each other in the same L2.
+__device__ inline void kind_and_block( int& kind, int& block )
+{
+   if ( gridDim.y == 8 )
+   {
+      kind = blockIdx.y, block = blockIdx.x;
+      return;
+   }
+   const int g = blockIdx.x, q = g >> 3;
+   kind  = q & 7;
+   block = ( q >> 3 ) * 8 + ( g & 7 );
+}
+
+// one thread per fine DoF of a kind
 __global__ __launch_bounds__( kThreads ) void p2_prolongate_kernel( const P2TransferArgs A )
 {
-   const int     kind = blockIdx.y;
+   int kind, block;
+   kind_and_block( kind, block );
    const int     W    = width_of_kind( A.Nf, kind );
-   const int i    = (int) ( blockIdx.x * kThreads + threadIdx.x );
+   const int i    = (int) ( block * kThreads + threadIdx.x );
    if ( W <= 0 || i >= (int) tet32( (unsigned) W ) )
       return;
    int x, y, z;
@@ -314,15 +331,18 @@ __global__ __launch_bounds__( kThreads ) void p2_prolongate_kernel( const P2Tran
       acc           = fma( e[k].w, kc == 0 ? A.srcV[off] : A.srcE[off], acc );
    }
    double* out = kind == 0 ? A.dstV + i : A.dstE + ( kind - 1 ) * (int) tet32( (unsigned) ( A.Nf - 1 ) ) + i;
-   *out        = A.update == HYTEG_HIP_ADD ? *out + acc : acc;
+   if ( A.update == HYTEG_HIP_ADD )
+      acc += *out;
+   *out = acc;
 }
 
-// grid.y = coarse kind; one thread per coarse DoF of that kind
+// one thread per coarse DoF of a kind
 __global__ __launch_bounds__( kThreads ) void p2_restrict_kernel( const P2TransferArgs A )
 {
-   const int     kind = blockIdx.y;
+   int kind, block;
+   kind_and_block( kind, block );
    const int     W    = width_of_kind( A.Nc, kind );
-   const int i    = (int) ( blockIdx.x * kThreads + threadIdx.x );
+   const int i    = (int) ( block * kThreads + threadIdx.x );
    if ( W <= 0 || i >= (int) tet32( (unsigned) W ) )
       return;
    int x, y, z;
@@ -514,6 +534,18 @@ inline bool transfer_by_threads()
 
 } // namespace
 
+// HYTEG_HIP_P2_TRANSFER_INTERLEAVE=1: the kinds of one region follow each other on one XCD instead of grid ( blocks, 8 ), kind by kind.
+// Measured (profiles/r03_p2_transfer_rows.txt): the HBM reads of the restriction fall from 95 to 70 MB, but the launch takes 101 us
+// instead of 56 (prolongation 48.5 instead of 44.0) -- the kinds' very different term counts no longer balance over the XCDs.  Off.
+static bool kinds_interleaved()
+{
+   static const bool v = [] {
+      const char* e = std::getenv( "HYTEG_HIP_P2_TRANSFER_INTERLEAVE" );
+      return e && e[0] == '1';
+   }();
+   return v;
+}
+
 extern "C" {
 
 HYTEG_HIP_API int hyteg_hip_p2_prolongate_cell( double*            fine_vertex,
@@ -546,7 +578,13 @@ HYTEG_HIP_API int hyteg_hip_p2_prolongate_cell( double*            fine_vertex,
       return HYTEG_HIP_OK;
    }
    const int64_t most = tet64( A.Nf );
-   hipLaunchKernelGGL( p2_prolongate_kernel, dim3( (unsigned) ( ( most + kThreads - 1 ) / kThreads ), 8 ), dim3( kThreads ), 0, as_stream( stream ), A );
+   {
+      const unsigned blocks = (unsigned) ( ( most + kThreads - 1 ) / kThreads );
+      if ( kinds_interleaved() && blocks >= 16 )
+         hipLaunchKernelGGL( p2_prolongate_kernel, dim3( 64u * ( ( blocks + 7 ) / 8 ) ), dim3( kThreads ), 0, as_stream( stream ), A );
+      else
+         hipLaunchKernelGGL( p2_prolongate_kernel, dim3( blocks, 8 ), dim3( kThreads ), 0, as_stream( stream ), A );
+   }
    HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;
 }
@@ -585,7 +623,13 @@ HYTEG_HIP_API int hyteg_hip_p2_restrict_cell( double*            coarse_vertex,
       return HYTEG_HIP_OK;
    }
    const int64_t most = tet64( A.Nc );
-   hipLaunchKernelGGL( p2_restrict_kernel, dim3( (unsigned) ( ( most + kThreads - 1 ) / kThreads ), 8 ), dim3( kThreads ), 0, as_stream( stream ), A );
+   {
+      const unsigned blocks = (unsigned) ( ( most + kThreads - 1 ) / kThreads );
+      if ( kinds_interleaved() && blocks >= 16 )
+         hipLaunchKernelGGL( p2_restrict_kernel, dim3( 64u * ( ( blocks + 7 ) / 8 ) ), dim3( kThreads ), 0, as_stream( stream ), A );
+      else
+         hipLaunchKernelGGL( p2_restrict_kernel, dim3( blocks, 8 ), dim3( kThreads ), 0, as_stream( stream ), A );
+   }
    HH_CHECK_HIP( hipGetLastError() );
    return HYTEG_HIP_OK;
 }

@@ -22,5 +22,14 @@ for first in (3, 99):
     for k in range(60):
         sv, se = S[k % nb]; dv, de = D[k % nb]
         capi.p2_elementwise_apply_cell(dv.data_ptr(), de.data_ptr(), sv.data_ptr(), se.data_ptr(), level, dem.data_ptr(), 1.0, 0, 0x7FFF)
+# the P2 grid transfer between levels 6 and 7 on the same buffers (coarse side: own rotating arrays)
+nvc, nec = capi.cell_size(level - 1), capi.p2_edge_array_size(level - 1)
+CV = [torch.rand(nvc, dtype=torch.float64, device="cuda") for _ in range(nb)]
+CE = [torch.rand(nec, dtype=torch.float64, device="cuda") for _ in range(nb)]
+ONES = [1.0] * 14
+for k in range(40):
+    capi.p2_prolongate_cell(D[k % nb][0].data_ptr(), D[k % nb][1].data_ptr(), CV[k % nb].data_ptr(), CE[k % nb].data_ptr(), level - 1, 0, 0x7FFF, st)
+for k in range(40):
+    capi.p2_restrict_cell(CV[k % nb].data_ptr(), CE[k % nb].data_ptr(), S[k % nb][0].data_ptr(), S[k % nb][1].data_ptr(), level - 1, ONES, 0x7FFF, st)
 torch.cuda.synchronize()
 print("edge entries", ne, "vertex entries", nv, "pairs", nb)
