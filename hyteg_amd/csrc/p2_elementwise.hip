@@ -1301,6 +1301,10 @@ __global__ __launch_bounds__( kThreads, 2 ) void p2_apply_fused_kernel( const Ti
 // still takes 17 of 27 us -- the instruction stream of a wave, not the memory, is what these kernels are bound by.
 // =====================================================================================================================
 constexpr int      kClassRowsMinLevel = 3;
+#ifndef HYTEG_P2_CLASS_ROWS_WAVES
+#define HYTEG_P2_CLASS_ROWS_WAVES 4
+#endif
+constexpr int      kClassRowsWaves    = HYTEG_P2_CLASS_ROWS_WAVES; // waves per workgroup
 #ifndef HYTEG_P2_DST_AUX
 #define HYTEG_P2_DST_AUX 0
 #endif
@@ -1453,7 +1457,7 @@ __device__ __forceinline__ void p2_classrows_body( const P2RowsArgs& A, const Ti
          return;
       block = ( block & 7 ) * xcd_chunk + ( block >> 3 );
    }
-   const int t = __builtin_amdgcn_readfirstlane( block * kRowsWaves + ( (int) threadIdx.x >> 6 ) );
+   const int t = __builtin_amdgcn_readfirstlane( block * kClassRowsWaves + ( (int) threadIdx.x >> 6 ) );
    if ( t >= ntiles )
       return;
    const Tile tl    = tiles[t]; // a, pad[0], pad[1]: index of (x0, y, z) at widths N, N-1, N-2; ya = y, yb = x0
@@ -1521,14 +1525,14 @@ __device__ __forceinline__ void p2_classrows_body( const P2RowsArgs& A, const Ti
 }
 
 template < int UPDATE, int NP, bool RESTRICTED >
-__global__ __launch_bounds__( kThreads ) void p2_class_rows_kernel( const Tile* tiles, int ntiles, int xcd_chunk, const P2RowsArgs A, unsigned mask )
+__global__ __launch_bounds__( 64 * kClassRowsWaves ) void p2_class_rows_kernel( const Tile* tiles, int ntiles, int xcd_chunk, const P2RowsArgs A, unsigned mask )
 {
    p2_classrows_body< UPDATE, NP, RESTRICTED >( A, tiles, ntiles, xcd_chunk, (int) blockIdx.x, mask );
 }
 
 // the same for up to HYTEG_HIP_MAX_BATCH macro-cells of one level (blockIdx.y = cell), as p2_inner_batch_kernel
 template < int UPDATE, bool RESTRICTED >
-__global__ __launch_bounds__( kThreads ) void p2_class_rows_batch_kernel( const Tile* tiles, int ntiles, const P2RowsArgs A, const P2BatchPtrs P )
+__global__ __launch_bounds__( 64 * kClassRowsWaves ) void p2_class_rows_batch_kernel( const Tile* tiles, int ntiles, const P2RowsArgs A, const P2BatchPtrs P )
 {
    const int      cell = blockIdx.y;
    const unsigned mask = P.mask[cell];
@@ -2119,7 +2123,7 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell_kinds( double*            
       const int n = F.N - 1;
       R.vbytes    = (unsigned) ( tet64( F.N ) * 8 );
       R.ebytes    = (unsigned) ( ( 6 * tet64( n ) + tet64( n - 1 ) ) * 8 );
-      unsigned waveBlocks = (unsigned) ( ( tt.count + kRowsWaves - 1 ) / kRowsWaves );
+      unsigned waveBlocks = (unsigned) ( ( tt.count + kClassRowsWaves - 1 ) / kClassRowsWaves );
       R.xcd_chunk         = 0;
       if ( waveBlocks >= 64 )
       {
@@ -2127,7 +2131,7 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cell_kinds( double*            
          waveBlocks  = 8u * (unsigned) R.xcd_chunk;
       }
 #define P2_LAUNCH_CLASS_ROWS( UPD, RES )                                                                                                       \
-   hipLaunchKernelGGL( ( p2_class_rows_kernel< UPD, 1, RES > ), dim3( waveBlocks ), dim3( kThreads ), 0, s, R.tiles, R.ntiles, R.xcd_chunk, R, mask )
+   hipLaunchKernelGGL( ( p2_class_rows_kernel< UPD, 1, RES > ), dim3( waveBlocks ), dim3( 64 * kClassRowsWaves ), 0, s, R.tiles, R.ntiles, R.xcd_chunk, R, mask )
       if ( kind_mask != 0xFFu && update == HYTEG_HIP_ADD )
          P2_LAUNCH_CLASS_ROWS( HYTEG_HIP_ADD, true );
       else if ( kind_mask != 0xFFu )
@@ -2525,9 +2529,9 @@ HYTEG_HIP_API int hyteg_hip_p2_elementwise_apply_cells_kinds( int ncells, double
       const int n = F.N - 1;
       R.vbytes    = (unsigned) ( tet64( F.N ) * 8 );
       R.ebytes    = (unsigned) ( ( 6 * tet64( n ) + tet64( n - 1 ) ) * 8 );
-      const dim3 grid( (unsigned) ( ( tt.count + kRowsWaves - 1 ) / kRowsWaves ), (unsigned) ncells );
+      const dim3 grid( (unsigned) ( ( tt.count + kClassRowsWaves - 1 ) / kClassRowsWaves ), (unsigned) ncells );
 #define P2_LAUNCH_CLASS_ROWS( UPD, RES ) \
-   hipLaunchKernelGGL( ( p2_class_rows_batch_kernel< UPD, RES > ), grid, dim3( kThreads ), 0, s, R.tiles, R.ntiles, R, P )
+   hipLaunchKernelGGL( ( p2_class_rows_batch_kernel< UPD, RES > ), grid, dim3( 64 * kClassRowsWaves ), 0, s, R.tiles, R.ntiles, R, P )
       if ( kind_mask != 0xFFu && update == HYTEG_HIP_ADD )
          P2_LAUNCH_CLASS_ROWS( HYTEG_HIP_ADD, true );
       else if ( kind_mask != 0xFFu )

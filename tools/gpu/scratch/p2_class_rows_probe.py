@@ -4,10 +4,13 @@ import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 import torch
 from hyteg_amd import capi
+if os.environ.get("HYTEG_PROBE_LIB"):  # a library built with other compile-time parameters (e.g. -DHYTEG_P2_CLASS_ROWS_WAVES=1)
+    from pathlib import Path
+    capi._LIB_PATH = Path(os.environ["HYTEG_PROBE_LIB"])
 from oracle import p1_oracle as po
 
 REF = np.array([0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1], dtype=np.float64)
-for level in (4, 5, 6, 7, 8):
+for level in [int(x) for x in os.environ.get("HYTEG_PROBE_LEVELS", "4,5,6,7,8").split(",")]:
     nv, ne = capi.cell_size(level), capi.p2_edge_array_size(level)
     em = po.p2_cell_element_matrices(REF, min(level, 6))
     dem = torch.from_numpy(capi.p2_build_operator_table(em)).cuda()
